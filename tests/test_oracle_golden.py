@@ -1,0 +1,173 @@
+"""The CPU oracle (oracle/ref_model.py) against vectors produced by the reference itself
+(oracle/gen_golden.py, run in the build container where /root/reference is mounted)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as R
+from oracle import logmel_ref as LM
+from tests.helpers import golden_model_case, load_npz, rel_err
+
+CASES = ["model_small_ragged.npz", "model_small_full.npz"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_reference(case):
+    cfg, sd, batch, z = golden_model_case(case)
+    out = R.forward_losses(sd, cfg, batch)
+    assert rel_err(out["enc_out"].detach(), z["fwd/enc_out"]) < 2e-6
+    assert np.array_equal(out["gold"].numpy(), z["fwd/gold"])
+    assert rel_err(out["pred"].detach(), z["fwd/pred"]) < 2e-6
+    assert abs(float(out["loss"]) - float(z["fwd/loss"])) < 1e-5 * abs(float(z["fwd/loss"]))
+    ys_in, ys_out = R.decoder_preprocess(batch["tgt_for_input"])
+    assert np.array_equal(ys_in.numpy(), z["fwd/ys_in"])
+    assert np.array_equal(ys_out.numpy(), z["fwd/ys_out"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_pe_buffer_head(case):
+    cfg, sd, batch, z = golden_model_case(case)
+    for k in [k for k in z.files if k.startswith("pe_head/")]:
+        assert np.allclose(sd[k[8:]][:, :64].numpy(), z[k], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cer_matches_reference(case):
+    cfg, sd, batch, z = golden_model_case(case)
+    V = int(z["cfg/V"])
+    id2token = ["$", "%", "^", "&"] + [chr(0x4E00 + i) for i in range(V - 4)]
+    cer = R.cer_percent(torch.from_numpy(z["fwd/pred"]), torch.from_numpy(z["fwd/gold"]), id2token)
+    assert abs(cer - float(z["fwd/cer"][0])) < 1e-3
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_train_steps_match_reference(case):
+    cfg, sd, batch, z = golden_model_case(case)
+    tr = R.RefTrainer(sd, cfg, warmup=int(z["cfg/warm_up"]))
+    r = tr.iterate(batch)
+    for k in tr.trainable:
+        g = z["grad/" + k]
+        # w_ks.bias gradients are analytically 0 (softmax shift invariance): absolute floor
+        assert np.allclose(r["grads"][k].numpy(), g, rtol=2e-4, atol=2e-6), k
+    assert abs(float(r["grad_norm"]) - float(z["step/grad_norm"])) < 1e-4 * float(z["step/grad_norm"])
+    assert abs(r["lr"] - float(z["step/lr"])) < 1e-12
+    # w_ks.bias: its true gradient is exactly 0, what is left is fp32 rounding noise (~1e-8) that
+    # Adam (eps=1e-9) normalises to +-lr: not comparable between any two implementations.
+    cmp = [k for k in tr.trainable if not k.endswith("w_ks.bias")]
+    for k in cmp:
+        assert np.allclose(tr.sd[k].numpy(), z["step/" + k], rtol=1e-5, atol=2e-6), k
+    r2 = tr.iterate(batch)
+    assert abs(float(r2["loss"]) - float(z["step2/loss"])) < 2e-4 * abs(float(z["step2/loss"]))
+    assert abs(r2["lr"] - float(z["step2/lr"])) < 1e-12
+    for k in cmp:
+        assert np.allclose(tr.sd[k].numpy(), z["step2/" + k], rtol=2e-4, atol=2e-5), k
+
+
+def test_cross_mask_quirk_reproduced():
+    """transformer_official.py:78 passes TEXT lengths as encoder lengths: frames >= max(text_len)
+    cannot influence the logits in ref_compat mode, but do in wave_len mode."""
+    cfg, sd, batch, z = golden_model_case("model_small_ragged.npz")
+    b2 = dict(batch)
+    w = batch["wave"].clone()
+    w[:, 8:] += 1.0                      # all tgt_len <= 7
+    w[1, 17:] = 0; w[2, 9:] = 0; w[3, 13:] = 0
+    b2["wave"] = w
+    # encoder self-attention sees every valid frame, so enc_out changes everywhere; only the
+    # decoder's view is cut: perturb the encoder OUTPUT instead
+    enc = R.encoder_forward(sd, cfg, batch["wave"], batch["wave_len"])
+    enc2 = enc.clone(); enc2[:, 8:] += 3.0
+    p1, _ = R.decoder_forward(sd, cfg, batch["tgt_for_input"], enc, batch["tgt_len"])
+    p2, _ = R.decoder_forward(sd, cfg, batch["tgt_for_input"], enc2, batch["tgt_len"])
+    assert float((p1 - p2).abs().max()) == 0.0
+    p3, _ = R.decoder_forward(sd, cfg, batch["tgt_for_input"], enc2, batch["wave_len"])
+    assert float((p1 - p3).abs().max()) > 1e-3
+
+
+def test_op_goldens():
+    z = load_npz("ops.npz")
+    # SDPA
+    q, k, v = (torch.from_numpy(z["sdpa/" + n]) for n in "qkv")
+    klen = torch.from_numpy(z["sdpa/klen"])
+    s = torch.einsum("bqd,bkd->bqk", q, k) / 4.0
+    s = s.masked_fill(~R.valid_mask(klen, k.shape[1]).unsqueeze(1), float("-inf"))
+    p = torch.softmax(s, -1)
+    assert np.allclose(p.numpy(), z["sdpa/attn"], atol=1e-6)
+    assert np.allclose(torch.bmm(p, v).numpy(), z["sdpa/out"], atol=1e-5)
+    # MHA fwd + bwd
+    sd = {k[7:]: torch.from_numpy(z[k]).requires_grad_(True) for k in z.files if k.startswith("mha/sd/")}
+    x = torch.from_numpy(z["mha/x"]).requires_grad_(True)
+    lens = torch.from_numpy(z["mha/lens"])
+    masked = (~R.valid_mask(lens, 10)).unsqueeze(1).expand(3, 10, 10)
+    y = R.multi_head_attention(sd, "", x, x, masked, 4, 8)
+    assert np.allclose(y.detach().numpy(), z["mha/y"], atol=2e-6)
+    (y * torch.from_numpy(z["mha/w"])).sum().backward()
+    assert np.allclose(x.grad.numpy(), z["mha/dx"], atol=2e-5)
+    for n, p_ in sd.items():
+        assert np.allclose(p_.grad.numpy(), z["mha/grad/" + n], atol=5e-5), n
+    # FFN
+    sd = {k[7:]: torch.from_numpy(z[k]).requires_grad_(True) for k in z.files if k.startswith("ffn/sd/")}
+    x = torch.from_numpy(z["ffn/x"]).requires_grad_(True)
+    y = R.feed_forward(sd, "", x)
+    assert np.allclose(y.detach().numpy(), z["ffn/y"], atol=2e-6)
+    (y * torch.from_numpy(z["ffn/w"])).sum().backward()
+    assert np.allclose(x.grad.numpy(), z["ffn/dx"], atol=2e-5)
+    for n, p_ in sd.items():
+        assert np.allclose(p_.grad.numpy(), z["ffn/grad/" + n], atol=5e-5), n
+    # PE
+    assert np.allclose(R.positional_encoding(200, 32).numpy(), z["pe/d32"], atol=1e-6)
+    pe = R.positional_encoding(5000, 512).numpy()
+    assert np.allclose(pe[z["pe/d512_rows"]], z["pe/d512"], atol=1e-6)
+    # masks
+    L = torch.from_numpy(z["mask/lens"])
+    keep = R.valid_mask(L, 7)
+    assert np.array_equal(keep.float().unsqueeze(-1).numpy(), z["mask/non_pad"])
+    assert np.array_equal((~keep).unsqueeze(1).expand(3, 4, 7).numpy().astype(np.uint8), z["mask/attn_pad"])
+    assert np.array_equal(R.valid_mask(L, 7, loop=True).numpy(), keep.numpy())
+    seq = torch.from_numpy(z["mask/seq"])
+    assert np.array_equal(torch.triu(torch.ones(5, 5, dtype=torch.uint8), 1).expand(3, 5, 5).numpy(), z["mask/subseq"])
+    assert np.array_equal(seq.eq(3).unsqueeze(1).expand(3, 5, 5).numpy().astype(np.uint8), z["mask/keypad"])
+    # CE both branches
+    pred, gold = torch.from_numpy(z["loss/pred"]), torch.from_numpy(z["loss/gold"])
+    assert abs(float(R.ce_loss(pred, gold)) - float(z["loss/ce"])) < 1e-6
+    assert abs(float(R.ce_loss(pred, gold, 0.1)) - float(z["loss/ce_smooth01"])) < 1e-6
+    # Noam
+    steps = z["noam/steps"]
+    assert np.allclose([R.noam_rate(int(s), 512, 4000) for s in steps], z["noam/rate_512_4000"], rtol=1e-13)
+    assert np.allclose([R.noam_rate(int(s), 32, 25, 2.0) for s in steps], z["noam/rate_32_25_f2"], rtol=1e-13)
+    # LFR (pinned by the reference's own build_LFR_features)
+    for T in (1, 2, 3, 4, 7, 10, 11, 12):
+        x = np.arange(T * 3, dtype=np.float32).reshape(T, 3) + 0.5
+        assert np.array_equal(LM.build_lfr(x, 4, 3), z[f"lfr/T{T}_m4n3"])
+    x9 = z["lfr/x9"]
+    assert np.array_equal(LM.build_lfr(x9, 1, 1), z["lfr/x9_m1n1"])
+    assert np.array_equal(LM.build_lfr(x9, 3, 1), z["lfr/x9_m3n1"])
+    assert np.array_equal(LM.build_lfr(x9, 1, 2), z["lfr/x9_m1n2"])
+    # CER convention
+    id2token = ["$", "%", "^", "&"] + [chr(0x4E00 + i) for i in range(8)]
+    vals = []
+    for h, g in zip(z["cer/hyp"], z["cer/ref"]):
+        hs, gs = R.ids_to_str(h, id2token), R.ids_to_str(g, id2token)
+        vals.append(R.edit_distance(hs, gs) / len(gs.split(" ")))
+    assert np.allclose(vals, z["cer/vals"])
+
+
+def test_logmel_oracle_selfconsistency():
+    """Spectrogram is 'parity unpinned' (torchaudio absent); check the published definition via
+    an independent scipy STFT and basic properties."""
+    import scipy.signal as ss
+    rng = np.random.RandomState(0)
+    wav = rng.randn(16000 * 2 + 37) * 0.1
+    lm = LM.log_mel(wav, 80)
+    assert lm.shape == (1 + len(wav) // 160, 80)
+    xp = np.pad(wav, (200, 200), mode="reflect")
+    f, t, Z = ss.stft(xp, fs=16000, window=LM.hann_periodic(), nperseg=400, noverlap=240, nfft=400,
+                      boundary=None, padded=False, detrend=False, return_onesided=True)
+    Z = Z * LM.hann_periodic().sum()          # undo scipy's window-sum scaling
+    spec = np.abs(Z.T) ** 2
+    ref = np.log(spec @ LM.mel_filterbank(80) + 1e-20)
+    assert np.allclose(lm[: ref.shape[0]], ref, atol=1e-8)
+    fb = LM.mel_filterbank(80)
+    assert fb.shape == (201, 80) and fb.min() >= 0 and (fb.sum(0) > 0).all()
+    assert fb[: 1].sum() == 0                  # 0 Hz bin is below f_min = 40 Hz
+    n = LM.utt_normalize(lm)
+    assert abs(n.mean()) < 1e-12 and abs(n.std(ddof=1) - 1) < 1e-12
