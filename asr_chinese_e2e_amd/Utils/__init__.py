@@ -1,0 +1,2 @@
+from .pack import Pack
+from .score import calculate_cer, edit_distance

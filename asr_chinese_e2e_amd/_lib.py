@@ -1,0 +1,89 @@
+"""ctypes binding of libasr_hip.so (the C ABI declared in include/asr_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent the
+import of the product path fails loudly.  Build it with
+    make -C asr_chinese_e2e_amd/csrc        (or  python -c "import __graft_entry__ as g; g.build()")
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasr_hip.so")
+
+ASR_F32, ASR_BF16 = 0, 1
+ACT_NONE, ACT_RELU = 0, 1
+ABI_VERSION = 1
+
+P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
+SIGNATURES = {
+    "asr_abi_version": (I, []),
+    "asr_last_error": (I, [c_char_p, Z]),
+    "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "asr_add_ln_bwd_workspace_bytes": (Z, [I, I]),
+    "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
+    "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
+    "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
+    "asr_ctc_workspace_bytes": (Z, [I, I, I]),
+    "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, P, Z, I, P]),
+    "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),
+    "asr_dec_preprocess": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "asr_embed_pe_fwd": (I, [P, P, P, P, F, I, I, I, I, I, P]),
+    "asr_embed_bwd": (I, [P, P, P, F, I, I, I, I, P]),
+    "asr_relu_fwd": (I, [P, Z, I, P]),
+    "asr_relu_bwd": (I, [P, P, P, P, Z, I, I, I, P]),
+    "asr_colsum_workspace_bytes": (Z, [I, I]),
+    "asr_colsum": (I, [P, P, P, Z, I, I, I, I, I, P]),
+    "asr_cast": (I, [P, P, Z, I, I, P]),
+    "asr_sumsq_workspace_bytes": (Z, [Z]),
+    "asr_grad_sumsq": (I, [P, Z, P, P, Z, P]),
+    "asr_noam_hyper": (I, [P, P, F, F, F, F, F, F, P]),
+    "asr_adam_step": (I, [P, P, P, P, P, Z, P, P, F, F, F, F, I, P]),
+    "asr_loss_combine": (I, [P, I, P, P, I, F, F, P, P]),
+    "asr_gemm_nt_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "asr_gemm_tn_workspace_bytes": (Z, [I, I, I]),
+    "asr_gemm_tn_bf16": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "asr_logmel_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "asr_utt_norm_lfr_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+}
+
+
+class AsrHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `make -C asr_chinese_e2e_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise ImportError(f"{LIB_PATH} does not export {name}: rebuild the extension") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.asr_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"libasr_hip.so ABI version {v}, binding expects {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib.asr_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    """Raise on a negative ASR_E* code, as the reference raises Python exceptions."""
+    if rc != 0:
+        names = {-1: "ASR_EINVAL", -2: "ASR_EDTYPE", -3: "ASR_EWORKSPACE", -4: "ASR_EHIP"}
+        raise AsrHipError(f"{what}: {names.get(rc, rc)}: {last_error()}")

@@ -1,0 +1,145 @@
+// Shared device/host helpers for libasr_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/asr_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+// ---- error reporting (host) -----------------------------------------------------------------
+void asr_set_error(const char* fmt, ...);
+#define ASR_FAIL(code, ...)        \
+    do {                           \
+        asr_set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+#define ASR_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) ASR_FAIL(ASR_EHIP, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- element load/store in fp32 -------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 4 consecutive elements <-> f32x4 (16-B loads for f32, 8-B for bf16)
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    bf16x4 v = *(const bf16x4*)p;
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *(bf16x4*)p = r;
+}
+// 8 consecutive elements (32-B f32 / 16-B bf16)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&r)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&r)[8]) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&r)[8]) {
+    bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&r)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&r)[8]) {
+    f32x4 a = {r[0], r[1], r[2], r[3]}, b = {r[4], r[5], r[6], r[7]};
+    *(f32x4*)p = a;
+    *(f32x4*)(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&r)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)r[i];
+    *(bf16x8*)p = v;
+}
+
+// ---- wave-level reductions (64 lanes, DPP/shuffle, no LDS) ----------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blocks of up to 1024 threads; `red` is >= 16 floats of LDS.  All threads
+// get the result.  Contains two barriers.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+__device__ __forceinline__ float log_add(float a, float b) {
+    // log(exp(a)+exp(b)) with -inf handling
+    float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(__expf(a - m) + __expf(b - m));
+}
+
+// out[c] (+)= sum_p part[p*pstride + c], c < ncols.  32 columns x 8 partial groups per block.
+static __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int P,
+                                                              size_t pstride, int ncols,
+                                                              float* __restrict__ out,
+                                                              int accumulate) {
+    __shared__ float red[8][33];
+    const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cg;
+    float s = 0.f;
+    if (col < ncols)
+        for (int p = pg; p < P; p += 8) s += part[(size_t)p * pstride + col];
+    red[pg][cg] = s;
+    __syncthreads();
+    if (pg == 0 && col < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cg];
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,261 @@
+// Fused residual-add + LayerNorm (+PE, + pad-row zeroing), forward and backward.
+// HBM-bound: one wave owns one row at a time, every element is read once and written once with
+// 16-byte (bf16) / 32-byte (f32) per-lane accesses; row statistics use wave shuffles only.
+// Algorithmic bytes per row (d elements of size e): fwd = (x + res read, y + xhat written) = 4*d*e
+// (3*d*e without residual); bwd = (dy [+dy2] + xhat read, dz written) = 3*d*e (4*d*e with dy2).
+#include "asr_common.h"
+
+namespace {
+
+constexpr int LN_WAVES = 4;  // waves (rows in flight) per workgroup
+
+// per-lane slice of one row: N values. VEC8: value c*8+j is column c*512 + lane*8 + j;
+// otherwise value k is column k*64 + lane (masked by col < d).
+template <typename T, int N, bool VEC8> struct RowSlice {
+    static __device__ __forceinline__ void load(const T* p, int d, int lane, float (&v)[N]) {
+        if constexpr (VEC8) {
+#pragma unroll
+            for (int c = 0; c < N / 8; ++c) load8<T>(p + c * 512 + lane * 8, *(float(*)[8]) & v[c * 8]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                int col = k * 64 + lane;
+                v[k] = col < d ? to_f32<T>(p[col]) : 0.f;
+            }
+        }
+    }
+    static __device__ __forceinline__ void loadf(const float* p, int d, int lane, float (&v)[N]) {
+        RowSlice<float, N, VEC8>::load(p, d, lane, v);
+    }
+    static __device__ __forceinline__ void store(T* p, int d, int lane, const float (&v)[N]) {
+        if constexpr (VEC8) {
+#pragma unroll
+            for (int c = 0; c < N / 8; ++c) store8<T>(p + c * 512 + lane * 8, *(const float(*)[8]) & v[c * 8]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                int col = k * 64 + lane;
+                if (col < d) p[col] = from_f32<T>(v[k]);
+            }
+        }
+    }
+    static __device__ __forceinline__ void storef(float* p, int d, int lane, const float (&v)[N]) {
+        RowSlice<float, N, VEC8>::store(p, d, lane, v);
+    }
+};
+
+template <typename T, int N, bool VEC8>
+__global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ pe, const int32_t* __restrict__ lens,
+    T* __restrict__ y, T* __restrict__ xhat, float* __restrict__ rstd_out, int rows, int T_, int d) {
+    using RS = RowSlice<T, N, VEC8>;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float g[N], bt[N];
+    RS::loadf(gamma, d, lane, g);
+    RS::loadf(beta, d, lane, bt);
+    const float inv_d = 1.f / (float)d;
+    for (int row = blockIdx.x * LN_WAVES + w; row < rows; row += gridDim.x * LN_WAVES) {
+        const int b = row / T_, t = row - b * T_;
+        float z[N];
+        RS::load(x + (size_t)row * d, d, lane, z);
+        if (res) {
+            float r[N];
+            RS::load(res + (size_t)row * d, d, lane, r);
+#pragma unroll
+            for (int i = 0; i < N; ++i) z[i] += r[i];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s += z[i];
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            // padded lanes of the scalar path hold z = 0: exclude them from the variance
+            float c = z[i] - mean;
+            if constexpr (!VEC8) c = (i * 64 + lane < d) ? c : 0.f;
+            z[i] = c;
+            q += c * c;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+        const bool keep = lens ? (t < lens[b]) : true;
+        float out[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            z[i] *= rstd;
+            out[i] = z[i] * g[i] + bt[i];
+        }
+        if (pe) {
+            float p[N];
+            RS::loadf(pe + (size_t)t * d, d, lane, p);
+#pragma unroll
+            for (int i = 0; i < N; ++i) out[i] += p[i];
+        }
+        if (!keep) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) out[i] = 0.f;
+        }
+        RS::store(xhat + (size_t)row * d, d, lane, z);
+        RS::store(y + (size_t)row * d, d, lane, out);
+        if (lane == 0) rstd_out[row] = rstd;
+    }
+}
+
+// partial column sums land in ws as [wave_slot][3][d] f32 (slot = blockIdx*LN_WAVES + wave)
+template <typename T, int N, bool VEC8>
+__global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ xhat,
+    const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+    const int32_t* __restrict__ lens, T* __restrict__ dz, float* __restrict__ ws, int rows, int T_,
+    int d) {
+    using RS = RowSlice<T, N, VEC8>;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float g[N], acc_g[N], acc_b[N], acc_z[N];
+    RS::loadf(gamma, d, lane, g);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc_g[i] = acc_b[i] = acc_z[i] = 0.f;
+    const float inv_d = 1.f / (float)d;
+    for (int row = blockIdx.x * LN_WAVES + w; row < rows; row += gridDim.x * LN_WAVES) {
+        const int b = row / T_, t = row - b * T_;
+        const bool keep = lens ? (t < lens[b]) : true;
+        float o[N];
+        if (keep) {
+            float gy[N], xh[N];
+            RS::load(dy + (size_t)row * d, d, lane, gy);
+            if (dy2) {
+                float e[N];
+                RS::load(dy2 + (size_t)row * d, d, lane, e);
+#pragma unroll
+                for (int i = 0; i < N; ++i) gy[i] += e[i];
+            }
+            RS::load(xhat + (size_t)row * d, d, lane, xh);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                acc_g[i] += gy[i] * xh[i];
+                acc_b[i] += gy[i];
+                gy[i] *= g[i];
+                s1 += gy[i];
+                s2 += gy[i] * xh[i];
+            }
+            s1 = wave_sum(s1) * inv_d;
+            s2 = wave_sum(s2) * inv_d;
+            const float rstd = rstd_in[row];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                o[i] = rstd * (gy[i] - s1 - xh[i] * s2);
+                if constexpr (!VEC8) o[i] = (i * 64 + lane < d) ? o[i] : 0.f;
+                acc_z[i] += o[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) o[i] = 0.f;
+        }
+        RS::store(dz + (size_t)row * d, d, lane, o);
+    }
+    float* slot = ws + (size_t)(blockIdx.x * LN_WAVES + w) * 3 * d;
+    RS::storef(slot, d, lane, acc_g);
+    RS::storef(slot + d, d, lane, acc_b);
+    RS::storef(slot + 2 * d, d, lane, acc_z);
+}
+
+}  // namespace
+
+static int ln_grid(int rows) {
+    int g = ceil_div(rows, LN_WAVES);
+    return g < 512 ? g : 512;
+}
+
+extern "C" size_t asr_add_ln_bwd_workspace_bytes(int rows, int d) {
+    return (size_t)ln_grid(rows) * LN_WAVES * 3 * d * sizeof(float);
+}
+
+template <typename T>
+static int launch_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                         const float* pe, const int32_t* lens, void* y, void* xhat, float* rstd,
+                         int rows, int T_, int d, hipStream_t st) {
+    const int grid = ln_grid(rows);
+#define LN_FWD(N, V)                                                                              \
+    add_ln_fwd_kernel<T, N, V><<<grid, LN_WAVES * WAVE, 0, st>>>(                                  \
+        (const T*)x, (const T*)res, gamma, beta, pe, lens, (T*)y, (T*)xhat, rstd, rows, T_, d)
+    if (d % 512 == 0 && d <= 2048) {
+        switch (d / 512) {
+            case 1: LN_FWD(8, true); break;
+            case 2: LN_FWD(16, true); break;
+            case 3: LN_FWD(24, true); break;
+            default: LN_FWD(32, true); break;
+        }
+    } else {
+        const int nk = ceil_div(d, 64);
+        if (nk <= 1) LN_FWD(1, false);
+        else if (nk <= 2) LN_FWD(2, false);
+        else if (nk <= 4) LN_FWD(4, false);
+        else if (nk <= 8) LN_FWD(8, false);
+        else if (nk <= 16) LN_FWD(16, false);
+        else LN_FWD(32, false);
+    }
+#undef LN_FWD
+    return 0;
+}
+
+extern "C" int asr_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                              const float* pe, const int32_t* lens, void* y, void* xhat,
+                              float* rstd, int B, int T, int d, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !xhat || !rstd) ASR_FAIL(ASR_EINVAL, "asr_add_ln_fwd: null pointer");
+    if (B <= 0 || T <= 0 || d <= 0 || d > 2048) ASR_FAIL(ASR_EINVAL, "asr_add_ln_fwd: bad shape B=%d T=%d d=%d", B, T, d);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ASR_F32) launch_ln_fwd<float>(x, res, gamma, beta, pe, lens, y, xhat, rstd, B * T, T, d, st);
+    else if (dtype == ASR_BF16) launch_ln_fwd<bf16_t>(x, res, gamma, beta, pe, lens, y, xhat, rstd, B * T, T, d, st);
+    else ASR_FAIL(ASR_EDTYPE, "asr_add_ln_fwd: dtype %d", dtype);
+    ASR_CHECK_LAUNCH("asr_add_ln_fwd");
+    return ASR_OK;
+}
+
+template <typename T>
+static void launch_ln_bwd(const void* dy, const void* dy2, const void* xhat, const float* rstd,
+                          const float* gamma, const int32_t* lens, void* dz, float* ws, int rows,
+                          int T_, int d, hipStream_t st) {
+    const int grid = ln_grid(rows);
+#define LN_BWD(N, V)                                                                      \
+    add_ln_bwd_kernel<T, N, V><<<grid, LN_WAVES * WAVE, 0, st>>>(                          \
+        (const T*)dy, (const T*)dy2, (const T*)xhat, rstd, gamma, lens, (T*)dz, ws, rows, T_, d)
+    if (d % 512 == 0 && d <= 2048) {
+        switch (d / 512) {
+            case 1: LN_BWD(8, true); break;
+            case 2: LN_BWD(16, true); break;
+            case 3: LN_BWD(24, true); break;
+            default: LN_BWD(32, true); break;
+        }
+    } else {
+        const int nk = ceil_div(d, 64);
+        if (nk <= 1) LN_BWD(1, false);
+        else if (nk <= 2) LN_BWD(2, false);
+        else if (nk <= 4) LN_BWD(4, false);
+        else if (nk <= 8) LN_BWD(8, false);
+        else if (nk <= 16) LN_BWD(16, false);
+        else LN_BWD(32, false);
+    }
+#undef LN_BWD
+}
+
+extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat, const float* rstd,
+                              const float* gamma, const int32_t* lens, void* dz, float* dgamma,
+                              float* dbeta, float* dbias, void* ws, size_t ws_bytes, int B, int T,
+                              int d, int dtype, void* stream) {
+    if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !ws) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: null pointer");
+    if (B <= 0 || T <= 0 || d <= 0 || d > 2048) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: bad shape B=%d T=%d d=%d", B, T, d);
+    const int rows = B * T;
+    if (ws_bytes < asr_add_ln_bwd_workspace_bytes(rows, d)) ASR_FAIL(ASR_EWORKSPACE, "asr_add_ln_bwd: workspace %zu < %zu", ws_bytes, asr_add_ln_bwd_workspace_bytes(rows, d));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ASR_F32) launch_ln_bwd<float>(dy, dy2, xhat, rstd, gamma, lens, dz, (float*)ws, rows, T, d, st);
+    else if (dtype == ASR_BF16) launch_ln_bwd<bf16_t>(dy, dy2, xhat, rstd, gamma, lens, dz, (float*)ws, rows, T, d, st);
+    else ASR_FAIL(ASR_EDTYPE, "asr_add_ln_bwd: dtype %d", dtype);
+    const int P = ln_grid(rows) * LN_WAVES;
+    const int fgrid = ceil_div(d, 32);
+    colsum_finalize_kernel<<<fgrid, 256, 0, st>>>((const float*)ws, P, (size_t)3 * d, d, dgamma, 1);
+    colsum_finalize_kernel<<<fgrid, 256, 0, st>>>((const float*)ws + d, P, (size_t)3 * d, d, dbeta, 1);
+    if (dbias) colsum_finalize_kernel<<<fgrid, 256, 0, st>>>((const float*)ws + 2 * d, P, (size_t)3 * d, d, dbias, 1);
+    ASR_CHECK_LAUNCH("asr_add_ln_bwd");
+    return ASR_OK;
+}

@@ -1,0 +1,406 @@
+// Error reporting, element-wise glue, column sums, decoder target preparation, embedding,
+// and the fused clip + Noam + Adam optimizer over the flat parameter buffer.
+#include <stdarg.h>
+
+#include "asr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void asr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int asr_abi_version(void) { return ASR_ABI_VERSION; }
+
+extern "C" int asr_last_error(char* buf, size_t n) {
+    if (buf && n) {
+        strncpy(buf, g_err, n - 1);
+        buf[n - 1] = 0;
+    }
+    return (int)strlen(g_err);
+}
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+static int ew_grid(size_t nvec) {
+    size_t g = (nvec + EW_BLOCK - 1) / EW_BLOCK;
+    return (int)(g < 2048 ? (g ? g : 1) : 2048);  // cap + grid-stride (guide G11)
+}
+
+template <typename T> __global__ __launch_bounds__(EW_BLOCK) void relu_fwd_kernel(T* x, size_t n8, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < n8; i += (size_t)gridDim.x * EW_BLOCK) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        store8<T>(x + i * 8, v);
+    }
+    if (blockIdx.x == 0) {  // tail
+        size_t i = n8 * 8 + threadIdx.x;
+        if (i < n) x[i] = from_f32<T>(fmaxf(to_f32<T>(x[i]), 0.f));
+    }
+}
+
+template <typename S, typename D> __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const S* s, D* d, size_t n8, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < n8; i += (size_t)gridDim.x * EW_BLOCK) {
+        float v[8];
+        load8<S>(s + i * 8, v);
+        store8<D>(d + i * 8, v);
+    }
+    if (blockIdx.x == 0) {
+        size_t i = n8 * 8 + threadIdx.x;
+        if (i < n) d[i] = from_f32<D>(to_f32<S>(s[i]));
+    }
+}
+
+// Column sums: a block covers 64 columns-groups of CW columns and strides over rows; each wave
+// keeps CW per-lane accumulators, partials go to ws[slot][cols].
+constexpr int CS_WAVES = 4;
+template <typename T, bool RELU_BWD>
+__global__ __launch_bounds__(CS_WAVES* WAVE) void colsum_partial_kernel(T* __restrict__ x, const T* __restrict__ a,
+                                                                         float* __restrict__ ws, int rows, int cols, int ld,
+                                                                         int row_slots) {
+    // grid.x = column tiles of 256 (4 per lane), grid.y = row_slots; slot = blockIdx.y*CS_WAVES + wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 256 + lane * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool full = (c0 + 3 < cols) && (ld % 4 == 0);
+    for (int r = blockIdx.y * CS_WAVES + w; r < rows; r += row_slots * CS_WAVES) {
+        T* p = x + (size_t)r * ld + c0;
+        if (full) {
+            f32x4 v = load4<T>(p);
+            if constexpr (RELU_BWD) {
+                f32x4 av = load4<T>(a + (size_t)r * ld + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = av[j] > 0.f ? v[j] : 0.f;
+                store4<T>(p, v);
+            }
+            acc += v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < cols) {
+                    float v = to_f32<T>(p[j]);
+                    if constexpr (RELU_BWD) {
+                        v = to_f32<T>(a[(size_t)r * ld + c0 + j]) > 0.f ? v : 0.f;
+                        p[j] = from_f32<T>(v);
+                    }
+                    acc[j] += v;
+                }
+        }
+    }
+    float* slot = ws + (size_t)(blockIdx.y * CS_WAVES + w) * cols;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c0 + j < cols) slot[c0 + j] = acc[j];
+}
+
+static int cs_row_slots(int rows, int cols) {
+    int ctiles = ceil_div(cols, 256);
+    int want = 2048 / ctiles;  // ~2048 workgroups in total
+    int maxs = ceil_div(rows, CS_WAVES);
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    return want;
+}
+
+// ---- decoder target preparation --------------------------------------------------------------
+__global__ void dec_preprocess_kernel(const int64_t* __restrict__ tgt, int32_t* ys_in, int32_t* ys_out,
+                                      int32_t* labels32, int32_t* dec_len, int32_t* lab_len, float* n_valid,
+                                      int B, int Lmax, int sos, int eos) {
+    // one thread per utterance (B is small, rows are short); thread 0 also sums n_valid
+    __shared__ int cnt[1024];
+    const int b = threadIdx.x;
+    int n = 0;
+    if (b < B) {
+        const int To = Lmax + 1;
+        int32_t* yi = ys_in + (size_t)b * To;
+        int32_t* yo = ys_out + (size_t)b * To;
+        int32_t* lb = labels32 + (size_t)b * Lmax;
+        yi[0] = sos;
+        for (int j = 0; j < Lmax; ++j) {
+            int v = (int)tgt[(size_t)b * Lmax + j];
+            if (v != 0) {  // y[y != IGNORE_ID]
+                lb[n] = v;
+                yi[1 + n] = v;
+                yo[n] = v;
+                ++n;
+            }
+        }
+        yo[n] = eos;
+        for (int j = n + 1; j < To; ++j) { yi[j] = eos; yo[j] = 0; }
+        for (int j = n; j < Lmax; ++j) lb[j] = 0;
+        dec_len[b] = n + 1;
+        lab_len[b] = n;
+    }
+    cnt[threadIdx.x] = (b < B) ? n + 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < B; ++i) s += cnt[i];
+        *n_valid = (float)s;
+    }
+}
+
+// ---- embedding -------------------------------------------------------------------------------
+template <typename T, typename W>
+__global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int32_t* __restrict__ ids, const W* __restrict__ emb,
+                                                           const float* __restrict__ pe, T* __restrict__ y, float scale,
+                                                           int rows, int To, int d, int V) {
+    const int row = blockIdx.x;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const int t = row % To;
+    for (int c = threadIdx.x; c < d; c += blockDim.x)
+        y[(size_t)row * d + c] = from_f32<T>(to_f32<W>(emb[(size_t)id * d + c]) * scale + pe[(size_t)t * d + c]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dy,
+                                                        float* __restrict__ demb, float scale, int d, int V) {
+    const int row = blockIdx.x;
+    const int id = ids[row];
+    if (id < 0 || id >= V) return;
+    for (int c = threadIdx.x; c < d; c += blockDim.x)
+        atomicAdd(&demb[(size_t)id * d + c], to_f32<T>(dy[(size_t)row * d + c]) * scale);
+}
+
+// ---- optimizer -------------------------------------------------------------------------------
+constexpr int SS_BLOCK = 256;
+__global__ __launch_bounds__(SS_BLOCK) void sumsq_partial_kernel(const float* __restrict__ g, size_t n4, size_t n, float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (size_t i = blockIdx.x * (size_t)SS_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * SS_BLOCK) {
+        f32x4 v = *(const f32x4*)(g + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0) {
+        size_t i = n4 * 4 + threadIdx.x;
+        if (i < n) s += g[i] * g[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restrict__ part, int P, float* out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < P; i += 256) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = s;
+}
+static int ss_grid(size_t n) {
+    size_t g = (n / 4 + SS_BLOCK - 1) / SS_BLOCK;
+    return (int)(g < 1024 ? (g ? g : 1) : 1024);
+}
+
+__global__ void noam_hyper_kernel(int32_t* step, float* hyper, float model_size, float warmup, float factor,
+                                  float lr_const, float b1, float b2) {
+    const int s = *step + 1;
+    *step = s;
+    const double sd = (double)s;
+    double lr = lr_const;
+    if (warmup > 0.f) {
+        double a = pow(sd, -0.5), b = sd * pow((double)warmup, -1.5);
+        lr = (double)factor * pow((double)model_size, -0.5) * (a < b ? a : b);
+    }
+    hyper[0] = (float)lr;
+    hyper[1] = (float)(1.0 - pow((double)b1, sd));
+    hyper[2] = (float)sqrt(1.0 - pow((double)b2, sd));
+    hyper[3] = (float)s;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ p_lp, size_t n4, size_t n,
+                                                        const float* __restrict__ hyper, const float* __restrict__ sumsq,
+                                                        float max_norm, float b1, float b2, float eps, int write_clipped) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2];
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        const float norm = sqrtf(*sumsq);
+        coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+    }
+    const float step_size = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * EW_BLOCK) {
+        f32x4 gv = *(const f32x4*)(g + i * 4), mv = *(const f32x4*)(m + i * 4), vv = *(const f32x4*)(v + i * 4), pv = *(const f32x4*)(p + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = gv[j] * coef;
+            gv[j] = gg;
+            mv[j] = b1 * mv[j] + (1.f - b1) * gg;
+            vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
+            pv[j] -= step_size * mv[j] / (sqrtf(vv[j]) / bc2s + eps);
+        }
+        *(f32x4*)(m + i * 4) = mv;
+        *(f32x4*)(v + i * 4) = vv;
+        *(f32x4*)(p + i * 4) = pv;
+        if (write_clipped) *(f32x4*)(g + i * 4) = gv;
+        if (p_lp) store4<bf16_t>(p_lp + i * 4, pv);
+    }
+    if (blockIdx.x == 0) {
+        size_t i = n4 * 4 + threadIdx.x;
+        if (i < n) {
+            const float gg = g[i] * coef;
+            const float mm = b1 * m[i] + (1.f - b1) * gg;
+            const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+            const float pp = p[i] - step_size * mm / (sqrtf(vv) / bc2s + eps);
+            m[i] = mm; v[i] = vv; p[i] = pp;
+            if (write_clipped) g[i] = gg;
+            if (p_lp) p_lp[i] = (bf16_t)pp;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_combine_kernel(const float* row_nll, int M, const float* n_valid, const float* nll, int B,
+                                                           float w_ce, float w_ctc, float* loss) {
+    __shared__ float red[16];
+    float s = 0.f, c = 0.f;
+    if (row_nll) for (int i = threadIdx.x; i < M; i += 256) s += row_nll[i];
+    if (nll) for (int i = threadIdx.x; i < B; i += 256) c += nll[i];
+    s = block_sum(s, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        const float ce = row_nll ? s / *n_valid : 0.f;
+        const float ctc = nll ? c / (float)B : 0.f;
+        loss[0] = (row_nll ? w_ce * ce : 0.f) + (nll ? w_ctc * ctc : 0.f);
+        loss[1] = ce;
+        loss[2] = ctc;
+    }
+}
+
+}  // namespace
+
+extern "C" int asr_relu_fwd(void* x, size_t n, int dtype, void* stream) {
+    if (!x) ASR_FAIL(ASR_EINVAL, "asr_relu_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ASR_F32) relu_fwd_kernel<float><<<ew_grid(n / 8), EW_BLOCK, 0, st>>>((float*)x, n / 8, n);
+    else if (dtype == ASR_BF16) relu_fwd_kernel<bf16_t><<<ew_grid(n / 8), EW_BLOCK, 0, st>>>((bf16_t*)x, n / 8, n);
+    else ASR_FAIL(ASR_EDTYPE, "asr_relu_fwd: dtype %d", dtype);
+    ASR_CHECK_LAUNCH("asr_relu_fwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_cast(const void* src, void* dst, size_t n, int sd, int dd, void* stream) {
+    if (!src || !dst) ASR_FAIL(ASR_EINVAL, "asr_cast: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = ew_grid(n / 8);
+    if (sd == ASR_F32 && dd == ASR_BF16) cast_kernel<float, bf16_t><<<g, EW_BLOCK, 0, st>>>((const float*)src, (bf16_t*)dst, n / 8, n);
+    else if (sd == ASR_BF16 && dd == ASR_F32) cast_kernel<bf16_t, float><<<g, EW_BLOCK, 0, st>>>((const bf16_t*)src, (float*)dst, n / 8, n);
+    else if (sd == ASR_F32 && dd == ASR_F32) cast_kernel<float, float><<<g, EW_BLOCK, 0, st>>>((const float*)src, (float*)dst, n / 8, n);
+    else if (sd == ASR_BF16 && dd == ASR_BF16) cast_kernel<bf16_t, bf16_t><<<g, EW_BLOCK, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, n / 8, n);
+    else ASR_FAIL(ASR_EDTYPE, "asr_cast: dtypes %d -> %d", sd, dd);
+    ASR_CHECK_LAUNCH("asr_cast");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_colsum_workspace_bytes(int rows, int cols) {
+    return (size_t)cs_row_slots(rows, cols) * CS_WAVES * cols * sizeof(float);
+}
+
+template <bool RELU_BWD>
+static int colsum_impl(void* x, const void* a, float* out, void* ws, size_t ws_bytes, int rows, int cols, int ld,
+                       int accumulate, int dtype, hipStream_t st, const char* name) {
+    if (!x || (RELU_BWD && !a)) ASR_FAIL(ASR_EINVAL, "%s: null pointer", name);
+    if (rows <= 0 || cols <= 0 || ld < cols) ASR_FAIL(ASR_EINVAL, "%s: bad shape rows=%d cols=%d ld=%d", name, rows, cols, ld);
+    const bool want_sum = out != nullptr;
+    if (want_sum && (!ws || ws_bytes < asr_colsum_workspace_bytes(rows, cols))) ASR_FAIL(ASR_EWORKSPACE, "%s: workspace too small", name);
+    const int slots = cs_row_slots(rows, cols);
+    dim3 grid(ceil_div(cols, 256), slots);
+    // without `out` (relu_bwd only) the partials still need somewhere to go: require ws then too
+    if (!ws || ws_bytes < asr_colsum_workspace_bytes(rows, cols)) ASR_FAIL(ASR_EWORKSPACE, "%s: workspace too small", name);
+    if (dtype == ASR_F32) colsum_partial_kernel<float, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((float*)x, (const float*)a, (float*)ws, rows, cols, ld, slots);
+    else if (dtype == ASR_BF16) colsum_partial_kernel<bf16_t, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((bf16_t*)x, (const bf16_t*)a, (float*)ws, rows, cols, ld, slots);
+    else ASR_FAIL(ASR_EDTYPE, "%s: dtype %d", name, dtype);
+    if (want_sum) colsum_finalize_kernel<<<ceil_div(cols, 32), 256, 0, st>>>((const float*)ws, slots * CS_WAVES, (size_t)cols, cols, out, accumulate);
+    ASR_CHECK_LAUNCH(name);
+    return ASR_OK;
+}
+
+extern "C" int asr_colsum(const void* x, float* out, void* ws, size_t ws_bytes, int rows, int cols, int ld, int accumulate,
+                          int dtype, void* stream) {
+    if (!out) ASR_FAIL(ASR_EINVAL, "asr_colsum: null out");
+    return colsum_impl<false>((void*)x, nullptr, out, ws, ws_bytes, rows, cols, ld, accumulate, dtype, (hipStream_t)stream, "asr_colsum");
+}
+
+extern "C" int asr_relu_bwd(void* da, const void* a, float* dbias, void* ws, size_t ws_bytes, int rows, int cols, int dtype,
+                            void* stream) {
+    return colsum_impl<true>(da, a, dbias, ws, ws_bytes, rows, cols, cols, 1, dtype, (hipStream_t)stream, "asr_relu_bwd");
+}
+
+extern "C" int asr_dec_preprocess(const int64_t* tgt, int32_t* ys_in, int32_t* ys_out, int32_t* labels32, int32_t* dec_len,
+                                  int32_t* lab_len, float* n_valid, int B, int Lmax, int sos, int eos, void* stream) {
+    if (!tgt || !ys_in || !ys_out || !labels32 || !dec_len || !lab_len || !n_valid) ASR_FAIL(ASR_EINVAL, "asr_dec_preprocess: null pointer");
+    if (B <= 0 || B > 1024 || Lmax <= 0) ASR_FAIL(ASR_EINVAL, "asr_dec_preprocess: bad shape B=%d Lmax=%d (B <= 1024)", B, Lmax);
+    const int threads = ceil_div(B, 64) * 64;
+    dec_preprocess_kernel<<<1, threads, 0, (hipStream_t)stream>>>(tgt, ys_in, ys_out, labels32, dec_len, lab_len, n_valid, B, Lmax, sos, eos);
+    ASR_CHECK_LAUNCH("asr_dec_preprocess");
+    return ASR_OK;
+}
+
+extern "C" int asr_embed_pe_fwd(const int32_t* ids, const void* emb, const float* pe, void* y, float scale, int B, int To, int d,
+                                int V, int dtype, void* stream) {
+    if (!ids || !emb || !pe || !y) ASR_FAIL(ASR_EINVAL, "asr_embed_pe_fwd: null pointer");
+    if (B <= 0 || To <= 0 || d <= 0 || V <= 0) ASR_FAIL(ASR_EINVAL, "asr_embed_pe_fwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    // the gather always reads the fp32 master embedding (exact), whatever the activation dtype
+    if (dtype == ASR_F32) embed_pe_fwd_kernel<float, float><<<B * To, 256, 0, st>>>(ids, (const float*)emb, pe, (float*)y, scale, B * To, To, d, V);
+    else if (dtype == ASR_BF16) embed_pe_fwd_kernel<bf16_t, float><<<B * To, 256, 0, st>>>(ids, (const float*)emb, pe, (bf16_t*)y, scale, B * To, To, d, V);
+    else ASR_FAIL(ASR_EDTYPE, "asr_embed_pe_fwd: dtype %d", dtype);
+    ASR_CHECK_LAUNCH("asr_embed_pe_fwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, float scale, int rows, int d, int V, int dtype,
+                             void* stream) {
+    if (!ids || !dy || !demb) ASR_FAIL(ASR_EINVAL, "asr_embed_bwd: null pointer");
+    if (rows <= 0 || d <= 0) ASR_FAIL(ASR_EINVAL, "asr_embed_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ASR_F32) embed_bwd_kernel<float><<<rows, 256, 0, st>>>(ids, (const float*)dy, demb, scale, d, V);
+    else if (dtype == ASR_BF16) embed_bwd_kernel<bf16_t><<<rows, 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, d, V);
+    else ASR_FAIL(ASR_EDTYPE, "asr_embed_bwd: dtype %d", dtype);
+    ASR_CHECK_LAUNCH("asr_embed_bwd");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_sumsq_workspace_bytes(size_t n) { return (size_t)ss_grid(n) * sizeof(float); }
+
+extern "C" int asr_grad_sumsq(const float* g, size_t n, float* sumsq, void* ws, size_t ws_bytes, void* stream) {
+    if (!g || !sumsq || !ws) ASR_FAIL(ASR_EINVAL, "asr_grad_sumsq: null pointer");
+    if (ws_bytes < asr_sumsq_workspace_bytes(n)) ASR_FAIL(ASR_EWORKSPACE, "asr_grad_sumsq: workspace too small");
+    if (((uintptr_t)g) % 16) ASR_FAIL(ASR_EINVAL, "asr_grad_sumsq: g must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ss_grid(n);
+    sumsq_partial_kernel<<<grid, SS_BLOCK, 0, st>>>(g, n / 4, n, (float*)ws);
+    sum_finalize_kernel<<<1, 256, 0, st>>>((const float*)ws, grid, sumsq);
+    ASR_CHECK_LAUNCH("asr_grad_sumsq");
+    return ASR_OK;
+}
+
+extern "C" int asr_noam_hyper(int32_t* step, float* hyper, float model_size, float warmup, float factor, float lr_const, float b1,
+                              float b2, void* stream) {
+    if (!step || !hyper) ASR_FAIL(ASR_EINVAL, "asr_noam_hyper: null pointer");
+    noam_hyper_kernel<<<1, 1, 0, (hipStream_t)stream>>>(step, hyper, model_size, warmup, factor, lr_const, b1, b2);
+    ASR_CHECK_LAUNCH("asr_noam_hyper");
+    return ASR_OK;
+}
+
+extern "C" int asr_adam_step(float* p, float* g, float* m, float* v, void* p_lp, size_t n, const float* hyper, const float* sumsq,
+                             float max_norm, float b1, float b2, float eps, int write_clipped, void* stream) {
+    if (!p || !g || !m || !v || !hyper) ASR_FAIL(ASR_EINVAL, "asr_adam_step: null pointer");
+    if (max_norm > 0.f && !sumsq) ASR_FAIL(ASR_EINVAL, "asr_adam_step: clipping needs sumsq");
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) % 16) ASR_FAIL(ASR_EINVAL, "asr_adam_step: buffers must be 16-byte aligned");
+    adam_kernel<<<ew_grid(n / 4), EW_BLOCK, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_lp, n / 4, n, hyper, sumsq, max_norm, b1, b2, eps, write_clipped);
+    ASR_CHECK_LAUNCH("asr_adam_step");
+    return ASR_OK;
+}
+
+extern "C" int asr_loss_combine(const float* row_nll, int M, const float* n_valid, const float* nll, int B, float w_ce, float w_ctc,
+                                float* loss, void* stream) {
+    if (!loss || (row_nll && !n_valid)) ASR_FAIL(ASR_EINVAL, "asr_loss_combine: null pointer");
+    loss_combine_kernel<<<1, 256, 0, (hipStream_t)stream>>>(row_nll, M, n_valid, nll, B, w_ce, w_ctc, loss);
+    ASR_CHECK_LAUNCH("asr_loss_combine");
+    return ASR_OK;
+}

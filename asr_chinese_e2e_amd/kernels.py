@@ -1,0 +1,329 @@
+"""Tensor-level wrappers over the C ABI: each takes torch CUDA tensors, checks what the kernel
+assumes (device, dtype, contiguity, shapes) ON THE HOST before launching, and passes raw device
+pointers + the current HIP stream.  PyTorch is only the allocator / stream provider here.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ASR_BF16, ASR_F32, ACT_NONE, ACT_RELU, check, lib
+
+_DT = {torch.float32: ASR_F32, torch.bfloat16: ASR_BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("the HIP path needs CUDA (ROCm) tensors; there is no CPU fallback")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("expected a contiguous float32 tensor")
+
+
+def _chk_i32(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise ValueError("expected a contiguous int32 tensor")
+
+
+class Workspace:
+    """Grow-only scratch buffer (never shrinks, so pointers stay valid under graph replay once
+    the high-water mark has been reached during warm-up)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = max(int(nbytes), 16)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+# --------------------------------------------------------------------------------- LayerNorm
+def add_ln_fwd(x, res, gamma, beta, pe, lens, B, T, y=None, xhat=None, rstd=None):
+    """y = LN(x + res) * gamma + beta (+ pe[t]), rows t >= lens[b] zeroed.  xhat may alias x."""
+    d = x.shape[-1]
+    assert x.is_contiguous() and x.numel() == B * T * d
+    if res is not None:
+        assert res.is_contiguous() and res.shape == x.shape and res.dtype == x.dtype
+    _chk_f32(gamma, beta, pe)
+    _chk_i32(lens)
+    assert gamma.numel() == d and beta.numel() == d
+    if pe is not None:
+        assert pe.shape[-1] == d and pe.shape[-2] >= T
+    if lens is not None:
+        assert lens.numel() == B
+    y = torch.empty_like(x) if y is None else y
+    xhat = torch.empty_like(x) if xhat is None else xhat
+    rstd = torch.empty(B * T, dtype=torch.float32, device=x.device) if rstd is None else rstd
+    check(lib.asr_add_ln_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(pe), _p(lens), _p(y), _p(xhat), _p(rstd),
+                             B, T, d, _dt(x), _stream()), "asr_add_ln_fwd")
+    return y, xhat, rstd
+
+
+def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws, dz=None):
+    d = dy.shape[-1]
+    assert dy.is_contiguous() and xhat.is_contiguous() and dy.numel() == B * T * d == xhat.numel()
+    assert xhat.dtype == dy.dtype and (dy2 is None or (dy2.dtype == dy.dtype and dy2.is_contiguous() and dy2.numel() == dy.numel()))
+    _chk_f32(rstd, gamma, dgamma, dbeta, dbias)
+    _chk_i32(lens)
+    assert rstd.numel() == B * T and dgamma.numel() == d and dbeta.numel() == d and (dbias is None or dbias.numel() == d)
+    dz = torch.empty_like(dy) if dz is None else dz
+    nbytes = lib.asr_add_ln_bwd_workspace_bytes(B * T, d)
+    w = ws.get(nbytes)
+    check(lib.asr_add_ln_bwd(_p(dy), _p(dy2), _p(xhat), _p(rstd), _p(gamma), _p(lens), _p(dz), _p(dgamma), _p(dbeta),
+                             _p(dbias), _p(w), w.numel(), B, T, d, _dt(dy), _stream()), "asr_add_ln_bwd")
+    return dz
+
+
+# --------------------------------------------------------------------------------- attention
+def _strided_rows(t, H, dk):
+    """t is a (rows, >=H*dk) view whose last dim is contiguous; returns row stride in elements."""
+    assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == H * dk
+    return t.stride(0)
+
+
+def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None):
+    """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer)."""
+    ldq, ldk, ldv = _strided_rows(q, H, dk), _strided_rows(k, H, dk), _strided_rows(v, H, dk)
+    assert q.shape[0] == B * Tq and k.shape[0] == B * Tk and v.shape[0] == B * Tk
+    assert q.dtype == k.dtype == v.dtype
+    _chk_i32(k_len)
+    assert k_len is None or k_len.numel() == B
+    o = torch.empty(B * Tq, H * dk, dtype=q.dtype, device=q.device) if o is None else o
+    ldo = _strided_rows(o, H, dk)
+    lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if lse is None else lse
+    scale = float(dk) ** -0.5 if scale is None else float(scale)
+    check(lib.asr_sdpa_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(k_len), B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo,
+                           int(causal), int(window), scale, _dt(q), _stream()), "asr_sdpa_fwd")
+    return o, lse
+
+
+def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=False, window=-1, scale=None, delta=None):
+    ldq, ldk, ldv, ldo = (_strided_rows(t, H, dk) for t in (q, k, v, o))
+    assert _strided_rows(do, H, dk) == ldo and _strided_rows(dq, H, dk) == ldq
+    assert _strided_rows(dk_, H, dk) == ldk and _strided_rows(dv, H, dk) == ldv
+    assert q.dtype == k.dtype == v.dtype == o.dtype == do.dtype == dq.dtype == dk_.dtype == dv.dtype
+    _chk_i32(k_len)
+    _chk_f32(lse)
+    delta = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if delta is None else delta
+    scale = float(dk) ** -0.5 if scale is None else float(scale)
+    check(lib.asr_sdpa_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk_), _p(dv), _p(k_len),
+                           B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, int(causal), int(window), scale, _dt(q), _stream()),
+          "asr_sdpa_bwd")
+    return dq, dk_, dv
+
+
+# --------------------------------------------------------------------------------- losses
+def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, zero_infinity=False, dlogits=None,
+                want_grad=True, nll=None):
+    """logits (B,T,V); returns (nll (B,), dlogits or None).  dlogits may alias logits."""
+    B, T, V = logits.shape
+    assert logits.is_contiguous()
+    _chk_i32(in_len, labels, lab_len)
+    Lmax = labels.shape[1]
+    assert labels.shape[0] == B and in_len.numel() == B and lab_len.numel() == B
+    nll = torch.empty(B, dtype=torch.float32, device=logits.device) if nll is None else nll
+    if want_grad and dlogits is None:
+        dlogits = torch.empty_like(logits)
+    if dlogits is not None:
+        assert dlogits.is_contiguous() and dlogits.shape == logits.shape and dlogits.dtype == logits.dtype
+    w = ws.get(lib.asr_ctc_workspace_bytes(B, T, Lmax))
+    check(lib.asr_ctc_fwd_bwd(_p(logits), _p(dlogits), _p(in_len), _p(labels), _p(lab_len), _p(nll), B, T, V, Lmax,
+                              int(blank), float(grad_scale), int(zero_infinity), _p(w), w.numel(), _dt(logits), _stream()),
+          "asr_ctc_fwd_bwd")
+    return nll, dlogits
+
+
+def xent_fwd_bwd(logits, gold, n_valid, ignore_index=0, smoothing=0.0, grad_scale=1.0, dlogits=None, want_grad=True,
+                 row_nll=None):
+    M, V = logits.shape
+    assert logits.is_contiguous() and gold.numel() == M
+    _chk_i32(gold)
+    _chk_f32(n_valid)
+    row_nll = torch.empty(M, dtype=torch.float32, device=logits.device) if row_nll is None else row_nll
+    if want_grad and dlogits is None:
+        dlogits = torch.empty_like(logits)
+    check(lib.asr_xent_fwd_bwd(_p(logits), _p(gold), _p(n_valid), _p(row_nll), _p(dlogits), M, V, int(ignore_index),
+                               float(smoothing), float(grad_scale), _dt(logits), _stream()), "asr_xent_fwd_bwd")
+    return row_nll, dlogits
+
+
+def loss_combine(row_nll, n_valid, nll, w_ce, w_ctc, out=None):
+    dev = (row_nll if row_nll is not None else nll).device
+    out = torch.empty(3, dtype=torch.float32, device=dev) if out is None else out
+    M = row_nll.numel() if row_nll is not None else 0
+    B = nll.numel() if nll is not None else 0
+    check(lib.asr_loss_combine(_p(row_nll), M, _p(n_valid), _p(nll), B, float(w_ce), float(w_ctc), _p(out), _stream()),
+          "asr_loss_combine")
+    return out
+
+
+# --------------------------------------------------------------------------------- decoder glue
+def dec_preprocess(tgt, sos=2, eos=3):
+    """tgt (B, Lmax) int64 zero-padded -> ys_in, ys_out (B, Lmax+1) int32, labels32, dec_len, lab_len, n_valid."""
+    assert tgt.dtype == torch.int64 and tgt.is_contiguous() and tgt.dim() == 2
+    B, Lmax = tgt.shape
+    dev = tgt.device
+    ys_in = torch.empty(B, Lmax + 1, dtype=torch.int32, device=dev)
+    ys_out = torch.empty(B, Lmax + 1, dtype=torch.int32, device=dev)
+    labels32 = torch.empty(B, Lmax, dtype=torch.int32, device=dev)
+    dec_len = torch.empty(B, dtype=torch.int32, device=dev)
+    lab_len = torch.empty(B, dtype=torch.int32, device=dev)
+    n_valid = torch.empty(1, dtype=torch.float32, device=dev)
+    check(lib.asr_dec_preprocess(_p(tgt), _p(ys_in), _p(ys_out), _p(labels32), _p(dec_len), _p(lab_len), _p(n_valid),
+                                 B, Lmax, sos, eos, _stream()), "asr_dec_preprocess")
+    return ys_in, ys_out, labels32, dec_len, lab_len, n_valid
+
+
+def embed_pe_fwd(ids, emb, pe, scale, B, To, dtype, y=None):
+    V, d = emb.shape
+    _chk_i32(ids)
+    _chk_f32(emb, pe)
+    assert ids.numel() == B * To and pe.shape[-1] == d and pe.shape[-2] >= To
+    y = torch.empty(B * To, d, dtype=dtype, device=emb.device) if y is None else y
+    check(lib.asr_embed_pe_fwd(_p(ids), _p(emb), _p(pe), _p(y), float(scale), B, To, d, V, _dt(y), _stream()),
+          "asr_embed_pe_fwd")
+    return y
+
+
+def embed_bwd(ids, dy, demb, scale):
+    V, d = demb.shape
+    _chk_i32(ids)
+    _chk_f32(demb)
+    assert dy.is_contiguous() and dy.shape[-1] == d and dy.numel() == ids.numel() * d
+    check(lib.asr_embed_bwd(_p(ids), _p(dy), _p(demb), float(scale), ids.numel(), d, V, _dt(dy), _stream()),
+          "asr_embed_bwd")
+
+
+# --------------------------------------------------------------------------------- elementwise
+def relu_(x):
+    assert x.is_contiguous()
+    check(lib.asr_relu_fwd(_p(x), x.numel(), _dt(x), _stream()), "asr_relu_fwd")
+    return x
+
+
+def relu_bwd_(da, a, dbias, ws):
+    """da *= (a > 0) in place; dbias (f32) += column sums."""
+    assert da.is_contiguous() and a.is_contiguous() and da.shape == a.shape and da.dtype == a.dtype and da.dim() == 2
+    _chk_f32(dbias)
+    rows, cols = da.shape
+    w = ws.get(lib.asr_colsum_workspace_bytes(rows, cols))
+    check(lib.asr_relu_bwd(_p(da), _p(a), _p(dbias), _p(w), w.numel(), rows, cols, _dt(da), _stream()), "asr_relu_bwd")
+    return da
+
+
+def colsum(x, out, ws, accumulate=True):
+    assert x.dim() == 2 and x.stride(1) == 1
+    _chk_f32(out)
+    rows, cols = x.shape
+    assert out.numel() == cols
+    w = ws.get(lib.asr_colsum_workspace_bytes(rows, cols))
+    check(lib.asr_colsum(_p(x), _p(out), _p(w), w.numel(), rows, cols, x.stride(0), int(accumulate), _dt(x), _stream()),
+          "asr_colsum")
+    return out
+
+
+def cast(src, dst):
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    check(lib.asr_cast(_p(src), _p(dst), src.numel(), _dt(src), _dt(dst), _stream()), "asr_cast")
+    return dst
+
+
+# --------------------------------------------------------------------------------- optimizer
+def grad_sumsq(g, out, ws):
+    _chk_f32(g, out)
+    w = ws.get(lib.asr_sumsq_workspace_bytes(g.numel()))
+    check(lib.asr_grad_sumsq(_p(g), g.numel(), _p(out), _p(w), w.numel(), _stream()), "asr_grad_sumsq")
+    return out
+
+
+def noam_hyper(step, hyper, model_size, warmup, factor, lr_const, b1, b2):
+    _chk_i32(step)
+    _chk_f32(hyper)
+    assert hyper.numel() >= 4
+    check(lib.asr_noam_hyper(_p(step), _p(hyper), float(model_size), float(warmup), float(factor), float(lr_const),
+                             float(b1), float(b2), _stream()), "asr_noam_hyper")
+
+
+def adam_step(p, g, m, v, p_lp, hyper, sumsq, max_norm, b1, b2, eps, write_clipped=True):
+    _chk_f32(p, g, m, v, hyper, sumsq)
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    if p_lp is not None:
+        assert p_lp.dtype == torch.bfloat16 and p_lp.numel() == n and p_lp.is_contiguous()
+    check(lib.asr_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, _p(hyper), _p(sumsq), float(max_norm), float(b1),
+                            float(b2), float(eps), int(write_clipped), _stream()), "asr_adam_step")
+
+
+# --------------------------------------------------------------------------------- GEMM
+def gemm_nt_supported(M, N, K, lda, ldb, ldc):
+    return K % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and ldc % 4 == 0
+
+
+def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None):
+    """out (M,N) = act(a (M,K) @ w (N,K)^T + bias) (+ res); bf16 operands, MFMA kernel."""
+    assert a.dtype == w.dtype == out.dtype == torch.bfloat16
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and out.shape == (M, N) and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    _chk_f32(bias)
+    if res is not None:
+        assert res.dtype == torch.bfloat16 and res.shape == out.shape and res.stride() == out.stride()
+    check(lib.asr_gemm_nt_bf16(_p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0),
+                               out.stride(0), int(act), _stream()), "asr_gemm_nt_bf16")
+    return out
+
+
+def gemm_tn(dy, x, dw, accumulate=True):
+    """dw (N,K) f32 (+)= dy (M,N)^T @ x (M,K); bf16 operands, MFMA kernel."""
+    assert dy.dtype == x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and dw.shape == (N, K) and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
+    check(lib.asr_gemm_tn_bf16(_p(dy), _p(x), _p(dw), M, N, K, dy.stride(0), x.stride(0), dw.stride(0),
+                               int(accumulate), None, 0, _stream()), "asr_gemm_tn_bf16")
+    return dw
+
+
+# --------------------------------------------------------------------------------- front end
+def logmel(wav, wav_len, window, melfb, Tmax, feat=None):
+    _chk_f32(wav, window, melfb)
+    _chk_i32(wav_len)
+    B, Smax = wav.shape
+    n_mels = melfb.shape[1]
+    assert melfb.shape[0] == 201 and window.numel() == 400 and wav_len.numel() == B
+    feat = torch.empty(B, Tmax, n_mels, dtype=torch.float32, device=wav.device) if feat is None else feat
+    check(lib.asr_logmel_fwd(_p(wav), _p(wav_len), _p(window), _p(melfb), _p(feat), B, Smax, Tmax, n_mels, _stream()),
+          "asr_logmel_fwd")
+    return feat
+
+
+def utt_norm_lfr(feat, wav_len, m, n, Tlfr_max, dtype=torch.float32):
+    _chk_f32(feat)
+    _chk_i32(wav_len)
+    B, Tmax, n_mels = feat.shape
+    out = torch.empty(B, Tlfr_max, m * n_mels, dtype=dtype, device=feat.device)
+    out_len = torch.empty(B, dtype=torch.int32, device=feat.device)
+    check(lib.asr_utt_norm_lfr_fwd(_p(feat), _p(wav_len), _p(out), _p(out_len), B, Tmax, n_mels, m, n, Tlfr_max,
+                                   _dt(out), _stream()), "asr_utt_norm_lfr_fwd")
+    return out, out_len

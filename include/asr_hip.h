@@ -1,0 +1,233 @@
+/*
+ * asr_hip.h - C ABI of libasr_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the training
+ * hot path of the Speech-Transformer of zqs01/ASR_chinese_e2e (+ the CTC branch that
+ * BASELINE.json's north_star adds).
+ *
+ * The reference is pure Python on stock PyTorch ops and has NO native / FFI boundary of its own
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the reference op SEQUENCE
+ * (file:line under the reference tree) that it replaces; the Python-side binding a maintainer
+ * would add is shown in INTEGRATION.md (ctypes, mirrored in asr_chinese_e2e_amd/_lib.py).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No torch types, no exceptions.
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host.
+ *   - no allocation, no synchronisation, no host<->device copy inside any entry point: each call
+ *     only enqueues kernels on `stream` (a hipStream_t passed as void*), so every entry point can
+ *     be captured into a hipGraph.  Scratch memory comes from the caller (`ws`, sized by the
+ *     matching asr_*_workspace_bytes query).
+ *   - return value: ASR_OK (0) or a negative ASR_E* code; asr_last_error() gives the per-thread
+ *     message.  Stateless and re-entrant; ordering is stream order only.
+ *   - activations are padded-dense row-major (B, T, d) == (B*T, d); utterance b owns rows
+ *     [b*T, (b+1)*T) of which the first len[b] are valid.  All masks are derived in-kernel from
+ *     int32 length vectors - the reference's materialised (B,Tq,Tk) bool masks
+ *     (Predictor/Models/utils.py:100-144) never exist.
+ *   - dtype: ASR_F32 or ASR_BF16 is the STORAGE type of activation tensors; all arithmetic
+ *     accumulates in fp32.  Parameters, optimizer state, statistics and losses are fp32.
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_ABI_VERSION 1
+
+typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
+
+#define ASR_OK 0
+#define ASR_EINVAL (-1)     /* bad shape / null pointer / unsupported size */
+#define ASR_EDTYPE (-2)     /* unsupported dtype for this op */
+#define ASR_EWORKSPACE (-3) /* workspace too small */
+#define ASR_EHIP (-4)       /* HIP runtime reported an error at launch */
+
+#define ASR_ACT_NONE 0
+#define ASR_ACT_RELU 1
+
+int asr_abi_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
+int asr_last_error(char* buf, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused residual-add + LayerNorm (+ positional encoding) (+ pad-row zeroing).
+ * Replaces:  layer_norm(fc(x)+residual) ; enc_output *= non_pad_mask
+ *              Predictor/Models/attention.py:59-60, module.py:72-75,
+ *              transformer_official.py:208, 211, 449, 453, 456
+ *            layer_norm_in(linear_in(x)) + positional_encoding   transformer_official.py:175-177
+ *   z = x + res (res may be NULL);  xhat = (z - mean) * rstd  (eps 1e-5, biased variance)
+ *   y = xhat * gamma + beta  (+ pe[t] if pe != NULL)   ;   y = 0 for rows t >= lens[b] if lens
+ * x, res, y, xhat: (B*T, d) `dtype`; xhat may alias x.  gamma, beta: (d) f32; pe: (>=T, d) f32;
+ * rstd: (B*T) f32; lens: (B) int32 or NULL.  d must be a multiple of 64 and <= 2048.
+ */
+int asr_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                   const float* pe, const int32_t* lens, void* y, void* xhat, float* rstd,
+                   int B, int T, int d, int dtype, void* stream);
+
+/* Backward of the above.  dy (+ dy2 if not NULL) is the gradient wrt y.
+ *   g = (dy + dy2) * mask * gamma ;  dz = rstd * (g - mean(g) - xhat * mean(g * xhat))
+ * dz: (B*T, d) `dtype` (gradient wrt x and wrt res).  Column sums over all rows are ACCUMULATED
+ * (+=) into f32 vectors: dgamma += sum (dy*mask*xhat), dbeta += sum (dy*mask), and, if dbias is
+ * not NULL, dbias += sum dz (bias gradient of the GEMM that produced x).
+ * ws: asr_add_ln_bwd_workspace_bytes(B*T, d) bytes of scratch.
+ */
+size_t asr_add_ln_bwd_workspace_bytes(int rows, int d);
+int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat, const float* rstd,
+                   const float* gamma, const int32_t* lens, void* dz, float* dgamma, float* dbeta,
+                   float* dbias, void* ws, size_t ws_bytes, int B, int T, int d, int dtype,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked scaled-dot-product attention, flash style (scores never materialised).
+ * Replaces:  bmm(q,k^T)/temperature -> masked_fill(mask,-inf) -> softmax -> bmm(attn,v)
+ *              Predictor/Models/attention.py:76-84, with the head split/merge permutes of
+ *              attention.py:43-57 folded into strided addressing, and the masks of
+ *              utils.py:100-144 / transformer_official.py:292-303 computed from lengths.
+ * q: rows b*Tq+t, k/v: rows b*Tk+t; head h lives at columns [h*dk, (h+1)*dk) of a row whose
+ * stride is ldq / ldk / ldv / ldo ELEMENTS (so q,k,v can point into one fused QKV buffer).
+ * Key j is visible to query i of utterance b iff  j < k_len[b]  and (!causal or j <= i)
+ * and (window < 0 or |i - j| <= window).  lse: (B, H, Tq) f32 = log sum exp of scaled scores.
+ * ASR_BF16 runs on MFMA (dk must be 64); ASR_F32 is an exact-fp32 VALU path (dk <= 128).
+ */
+int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                 const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
+                 int ldv, int ldo, int causal, int window, float scale, int dtype, void* stream);
+
+/* Backward: given do (same layout as o) computes dq, dk, dv (layouts/strides of q, k, v).
+ * delta: (B, H, Tq) f32 scratch (rowsum(do*o)), written by the call. */
+int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                 const float* lse, float* delta, void* dq, void* dk_, void* dv,
+                 const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
+                 int ldv, int ldo, int causal, int window, float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CTC loss, forward-backward, fused with log-softmax over the vocabulary.
+ * NOT in the reference (it has only cross-entropy, Predictor/Utils/loss.py:26-51); required by
+ * BASELINE.json north_star.  Semantics = torch.nn.functional.ctc_loss(log_softmax(logits), ...,
+ * blank, reduction='none') and its gradient wrt logits (ATen native/LossCTC.cpp).
+ * logits: (B, T, V) `dtype`;  in_len: (B) int32 frames per utterance (<= T);
+ * labels: (B, Lmax) int32 padded; lab_len: (B) int32 (<= Lmax, 2*Lmax+1 <= 1024).
+ * nll: (B) f32 = -log p(labels | x) (+inf when infeasible; 0 if zero_infinity).
+ * dlogits: (B, T, V) `dtype` (may alias logits) = grad_scale * d(sum_b nll_b)/dlogits,
+ * rows t >= in_len[b] are 0.  If dlogits is NULL only nll is computed.
+ */
+size_t asr_ctc_workspace_bytes(int B, int T, int Lmax);
+int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len,
+                    const int32_t* labels, const int32_t* lab_len, float* nll, int B, int T, int V,
+                    int Lmax, int blank, float grad_scale, int zero_infinity, void* ws,
+                    size_t ws_bytes, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Softmax cross-entropy with ignore_index, forward + gradient in one pass over the logits.
+ * Replaces:  F.cross_entropy(pred, gold, ignore_index=0, reduction='mean')  Utils/loss.py:47-49
+ *            (+ label smoothing branch Utils/loss.py:30-45 when smoothing > 0)
+ * logits: (M, V) `dtype`; gold: (M) int32.  row_nll: (M) f32 per-row loss (0 for ignored rows).
+ * dlogits (may alias logits, may be NULL) = grad_scale / n_valid * d(sum row_nll)/dlogits where
+ * n_valid is read from device memory (*n_valid, f32, e.g. written by asr_dec_preprocess).
+ */
+int asr_xent_fwd_bwd(const void* logits, const int32_t* gold, const float* n_valid,
+                     float* row_nll, void* dlogits, int M, int V, int ignore_index,
+                     float smoothing, float grad_scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder target preparation on device.
+ * Replaces:  Decoder.preprocess (python list loop) transformer_official.py:260-275
+ * tgt: (B, Lmax) int64 zero-padded label ids.  Writes (B, Lmax+1) int32:
+ *   ys_in  = [sos, y..., eos-padding],  ys_out = [y..., eos, 0-padding]
+ * dec_len[b] = 1 + #nonzero(tgt[b]) (rows of ys_in that are not eos padding),
+ * lab_len[b] = #nonzero(tgt[b]), labels32 = compacted labels (B, Lmax) int32 (for CTC),
+ * *n_valid = number of non-zero entries of ys_out (f32).
+ */
+int asr_dec_preprocess(const int64_t* tgt, int32_t* ys_in, int32_t* ys_out, int32_t* labels32,
+                       int32_t* dec_len, int32_t* lab_len, float* n_valid, int B, int Lmax,
+                       int sos, int eos, void* stream);
+
+/* Embedding gather * scale + positional encoding.
+ * Replaces:  tgt_word_emb(ys_in) * x_logit_scale + positional_encoding
+ *              transformer_official.py:306-307
+ * ids: (B*To) int32; emb: (V, d) `wdtype` storage of the embedding used for the gather;
+ * pe: (>=To, d) f32; y: (B*To, d) `dtype`. */
+int asr_embed_pe_fwd(const int32_t* ids, const void* emb, const float* pe, void* y, float scale,
+                     int B, int To, int d, int V, int dtype, void* stream);
+/* demb (V, d) f32 += scale * scatter-add over rows of dy ((B*To, d) `dtype`). */
+int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, float scale, int rows, int d,
+                  int V, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise / reductions used between GEMMs.
+ */
+/* x = relu(x) in place, (n) `dtype`.  Replaces F.relu in module.py:70. */
+int asr_relu_fwd(void* x, size_t n, int dtype, void* stream);
+/* da = da * (a > 0) in place over (rows, cols); if dbias != NULL also dbias (cols) f32 +=
+ * column sums of the masked da.  ws: asr_colsum_workspace_bytes(rows, cols). */
+int asr_relu_bwd(void* da, const void* a, float* dbias, void* ws, size_t ws_bytes, int rows,
+                 int cols, int dtype, void* stream);
+/* out (cols) f32 (+)= column sums of x (rows, cols) with row stride ld elements. */
+size_t asr_colsum_workspace_bytes(int rows, int cols);
+int asr_colsum(const void* x, float* out, void* ws, size_t ws_bytes, int rows, int cols, int ld,
+               int accumulate, int dtype, void* stream);
+/* dst (n) `dst_dtype` = src (n) `src_dtype`  (f32 <-> bf16 conversion / copy) */
+int asr_cast(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused optimizer over the flat parameter / gradient buffers.
+ * Replaces:  clip_grad_norm_(params, 5.0) ; NoamOpt.step() -> Adam.step()
+ *              transformer_official.py:102-103, Trainer/optimizer.py:15-28, main.py:81-83
+ * asr_grad_sumsq: *sumsq (f32) = sum g^2 over n f32 elements (ws: asr_sumsq_workspace_bytes(n)).
+ * asr_noam_hyper:  step += 1 (device int32); hyper[0] = lr = factor * model_size^-0.5 *
+ *   min(step^-0.5, step*warmup^-1.5) (or lr_const if warmup <= 0); hyper[1] = 1 - b1^step;
+ *   hyper[2] = sqrt(1 - b2^step).
+ * asr_adam_step: coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (no clipping if max_norm <= 0);
+ *   g' = g*coef; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2;
+ *   p -= lr/bc1 * m / (sqrt(v)/bc2s + eps); if p_lp != NULL the bf16 shadow copy is refreshed.
+ *   If write_clipped != 0 the clipped gradient is written back to g (clip_grad_norm_ is in-place).
+ */
+size_t asr_sumsq_workspace_bytes(size_t n);
+int asr_grad_sumsq(const float* g, size_t n, float* sumsq, void* ws, size_t ws_bytes, void* stream);
+int asr_noam_hyper(int32_t* step, float* hyper, float model_size, float warmup, float factor,
+                   float lr_const, float b1, float b2, void* stream);
+int asr_adam_step(float* p, float* g, float* m, float* v, void* p_lp, size_t n,
+                  const float* hyper, const float* sumsq, float max_norm, float b1, float b2,
+                  float eps, int write_clipped, void* stream);
+/* loss[0] = w_ce * sum(row_nll[0..M)) / *n_valid + w_ctc * sum(nll[0..B)) / B ;
+ * loss[1] = the CE term, loss[2] = the CTC term (either input may be NULL with weight 0). */
+int asr_loss_combine(const float* row_nll, int M, const float* n_valid, const float* nll, int B,
+                     float w_ce, float w_ctc, float* loss, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense projections on MFMA:  C = act(A * W^T + bias)  ("NT": both operands K-contiguous).
+ * Replaces:  nn.Linear / Conv1d(k=1) forward  attention.py:43-45, 59; module.py:70;
+ *            transformer_official.py:176, 321  (and, with transposed operands, their dgrad).
+ * A: (M, K) lda, W: (N, K) ldb, C: (M, N) ldc, all bf16; bias: (N) f32 or NULL;
+ * if res != NULL, C += res (M, N) ldc (used to accumulate the residual gradient).
+ */
+int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void* res, void* C,
+                     int M, int N, int K, int lda, int ldb, int ldc, int act, void* stream);
+/* Weight gradient  dW (N, K) f32 (+)= dY^T (M, N)^T * X (M, K)   ("TN": reduction over rows). */
+size_t asr_gemm_tn_workspace_bytes(int M, int N, int K);
+int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy,
+                     int ldx, int ldw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Log-mel front end on device.
+ * Replaces:  MelSpectrogram(sr=16000, ws=400, hop=160, n_mels) -> log(x+1e-20)
+ *              Predictor/data_handler/processor.py:33-40
+ *            (f - mean)/std (scalar, unbiased) and build_LFR_features   processor.py:42-46, 74-100
+ * wav: (B, Smax) f32, wav_len: (B) int32 samples.  feat: (B, Tmax, n_mels) f32 log-mel with
+ * Tmax >= 1 + Smax/160; frames t >= 1 + wav_len[b]/160 are written as 0.
+ * melfb: (201, n_mels) f32 filterbank; window: (400) f32; twiddle: (400) float2 cos/sin table.
+ */
+int asr_logmel_fwd(const float* wav, const int32_t* wav_len, const float* window,
+                   const float* melfb, float* feat, int B, int Smax, int Tmax, int n_mels,
+                   void* stream);
+/* out: (B, Tlfr_max, m*n_mels) `dtype`, out_len[b] = ceil(T_b / n); padded rows 0. */
+int asr_utt_norm_lfr_fwd(const float* feat, const int32_t* wav_len, void* out, int32_t* out_len,
+                         int B, int Tmax, int n_mels, int m, int n, int Tlfr_max, int dtype,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */
