@@ -1,0 +1,340 @@
+"""TransformerOffical / TransformerCTC: the reference's model plugin surface on the HIP engine.
+
+Mirrors Predictor/Models/transformer_official.py:34-125 of the reference:
+    Model(config, vocab); .cuda(); .parameters(); .state_dict() with the SAME key names;
+    .iterate(pack, optimizer=..., is_train=...) -> (metrics Pack{loss, cer}, None);
+    .forward(pack) -> Pack{pred, gold}; .cal_metrics(output, pack); .get_default_config()
+so the reference's main.py / Trainer11 drive it unchanged.  What runs underneath is the explicit
+forward/backward engine (engine.py) on hand-written HIP kernels - there is no autograd graph
+and NO CPU fallback: iterate() on CPU tensors raises.
+
+Additions required by BASELINE.json's north_star (not in the reference):
+  * config.ctc_weight = lambda in [0,1]: joint loss lambda*CTC + (1-lambda)*CE via a `ctc_lo`
+    head on the encoder output (lambda = 0 reproduces the reference exactly),
+  * TransformerCTC: encoder + CTC only (BASELINE config 2),
+  * config.cross_mask: "ref_compat" reproduces the reference's decoder cross-attention mask built
+    from TEXT lengths (transformer_official.py:78, 301-303); "wave_len" is the corrected mask,
+  * config.dtype: "bf16" (default) or "fp32" (exact-fp32 parity mode),
+  * config.attn_window: +-w frame band on encoder self-attention (long-form config), -1 = full.
+"""
+import math
+
+import torch
+
+from .. import engine as E
+from .. import kernels as K
+from ..Bases import BaseConfig, BaseModel
+from ..Utils import Pack, calculate_cer
+
+SOS_ID, EOS_ID, PAD_ID = 2, 3, 0   # transformer_official.py:53-54, Utils/loss.py:5
+PE_MAXLEN = 5000                   # transformer_official.py:49, 65
+CLIP_NORM = 5.0                    # transformer_official.py:102
+
+
+def _set_nested(root, dotted, value, is_buffer=False):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, torch.nn.Module())
+        mod = getattr(mod, p)
+    if is_buffer:
+        mod.register_buffer(parts[-1], value)
+    else:
+        mod.register_parameter(parts[-1], value)
+
+
+class _SpeechTransformer(BaseModel):
+    USE_DECODER = True
+
+    def __init__(self, config, vocab):
+        super().__init__()
+        self.config = config
+        self.vocab = vocab
+        c = config
+        self.use_decoder = self.USE_DECODER
+        lam = float(getattr(c, "ctc_weight", 0.0))
+        self.ctc_weight = lam if self.use_decoder else 1.0
+        self.use_ctc = (lam > 0.0) or not self.use_decoder
+        self.cross_mask = getattr(c, "cross_mask", "ref_compat")
+        self.lowp = str(getattr(c, "dtype", "bf16")).lower() in ("bf16", "bfloat16")
+        self.attn_window = int(getattr(c, "attn_window", -1))
+        self.cer_in_iterate = bool(getattr(c, "cer_in_iterate", True))
+        if float(getattr(c, "dropout", 0.0)) != 0.0 and not getattr(c, "allow_dropout_ignored", False):
+            # dropout sites of the reference: transformer_official.py:175, 306; attention.py:59, 83; module.py:73
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP engine yet: pass dropout=0.0 "
+                                      "(or allow_dropout_ignored=True to run without it)")
+        d, H, dk, ff = c.d_model, c.num_head, c.hidden_size, c.ff_size
+        d_in = c.n_mels * c.lfr_m
+        V = vocab.vocab_size
+        self.V = V
+
+        # ---- parameter blocks in FORWARD order (backward finishes them in reverse: dist.py)
+        blocks = [[("encoder.linear_in.weight", (d, d_in))], [("encoder.linear_in.bias", (d,))],
+                  [("encoder.layer_norm_in.weight", (d,))], [("encoder.layer_norm_in.bias", (d,))]]
+        for i in range(c.layer_num):
+            blocks += E.mha_param_block(f"encoder.layer_stack.{i}.slf_attn.", H, dk, d)
+            blocks += E.ffn_param_block(f"encoder.layer_stack.{i}.pos_ffn.", d, ff)
+        if self.use_ctc:
+            blocks += [[("ctc_lo.weight", (V, d))], [("ctc_lo.bias", (V,))]]
+        if self.use_decoder:
+            blocks += [[("decoder.tgt_word_emb.weight", (V, d))]]
+            for i in range(c.layer_num):
+                blocks += E.mha_param_block(f"decoder.layer_stack.{i}.slf_attn.", H, dk, d)
+                blocks += E.mha_param_block(f"decoder.layer_stack.{i}.enc_attn.", H, dk, d)
+                blocks += E.ffn_param_block(f"decoder.layer_stack.{i}.pos_ffn.", d, ff)
+        self._flat = E.FlatParams(blocks)
+        self._engine = None
+        self._flat_device = None
+
+        # ---- nn.Parameters with the reference's names / shapes / init distributions
+        order = self._state_order(c.layer_num)
+        for name in order:
+            if name.endswith("positional_encoding.pe"):
+                _set_nested(self, name, E.positional_encoding(PE_MAXLEN, d), is_buffer=True)
+            elif name == "decoder.tgt_word_prj.weight":
+                _set_nested(self, name, self.decoder.tgt_word_emb.weight)   # tied (transformer_official.py:253-256)
+            else:
+                wname = name[:-5] + ".weight" if name.endswith(".bias") else name
+                wshape = self._flat.index[wname][1]
+                _set_nested(self, name, torch.nn.Parameter(self._init_tensor(name, self._flat.index[name][1], wshape, d, dk)))
+
+    # state_dict key order of the reference (module registration order)
+    def _state_order(self, L):
+        def mha(pre):
+            return [pre + n for n in ("w_qs.weight", "w_qs.bias", "w_ks.weight", "w_ks.bias", "w_vs.weight", "w_vs.bias",
+                                      "layer_norm.weight", "layer_norm.bias", "fc.weight", "fc.bias")]
+
+        def ffn(pre):
+            return [pre + n for n in ("w_1.weight", "w_1.bias", "w_2.weight", "w_2.bias", "layer_norm.weight", "layer_norm.bias")]
+
+        names = ["encoder.linear_in.weight", "encoder.linear_in.bias", "encoder.layer_norm_in.weight",
+                 "encoder.layer_norm_in.bias", "encoder.positional_encoding.pe"]
+        for i in range(L):
+            names += mha(f"encoder.layer_stack.{i}.slf_attn.") + ffn(f"encoder.layer_stack.{i}.pos_ffn.")
+        if self.use_decoder:
+            names += ["decoder.tgt_word_emb.weight", "decoder.positional_encoding.pe"]
+            for i in range(L):
+                names += mha(f"decoder.layer_stack.{i}.slf_attn.") + mha(f"decoder.layer_stack.{i}.enc_attn.") + ffn(f"decoder.layer_stack.{i}.pos_ffn.")
+            names += ["decoder.tgt_word_prj.weight"]
+        if self.use_ctc:
+            names += ["ctc_lo.weight", "ctc_lo.bias"]
+        return names
+
+    @staticmethod
+    def _init_tensor(name, shape, wshape, d, dk):
+        """attention.py:16-28, transformer_official.py:147-156, 242-256, torch defaults elsewhere."""
+        t = torch.empty(*shape)
+        leaf = name.rsplit(".", 2)[-2]
+        if leaf in ("layer_norm", "layer_norm_in"):
+            return t.fill_(1.0) if name.endswith(".weight") else t.zero_()
+        fan_out, fan_in = wshape[0], wshape[1]
+        if name == "decoder.tgt_word_emb.weight":
+            return t.normal_(0.0, 1.0)            # nn.Embedding default; the tied projection reuses it
+        if name.endswith(".weight"):
+            if leaf in ("w_qs", "w_ks", "w_vs"):
+                return t.normal_(0.0, math.sqrt(2.0 / (d + dk)))
+            if leaf in ("fc", "linear_in", "ctc_lo"):
+                return t.normal_(0.0, math.sqrt(2.0 / (fan_in + fan_out)))   # xavier_normal_
+        bound = 1.0 / math.sqrt(fan_in)            # Linear / Conv1d default: U(+-1/sqrt(fan_in)), weights and biases
+        return t.uniform_(-bound, bound)
+
+    # ------------------------------------------------------------------ flat storage management
+    def _named_flat_params(self):
+        for name, p in self.named_parameters():
+            yield name, p
+
+    def _ensure_engine(self, device):
+        """(Re)build the flat HBM buffers when the parameters are not views of them (first call,
+        after .cuda()/.to(), after load_state_dict on a fresh module)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the HIP engine runs on an MI355X only: move the model and batch to 'cuda' "
+                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+        f = self._flat
+        ok = self._engine is not None and self._flat_device == device
+        if ok:
+            for name, p in self._named_flat_params():
+                off, shape = f.index[name]
+                if p.data_ptr() != f.p.data_ptr() + 4 * off:
+                    ok = False
+                    break
+        if ok:
+            return self._engine
+        old = {name: p.detach().to(device=device, dtype=torch.float32) for name, p in self._named_flat_params()}
+        f.allocate(device, self.lowp)
+        for name, p in self._named_flat_params():
+            view = f.view(f.p, name)
+            view.copy_(old[name].view(view.shape))
+            p.data = view
+            p.grad = f.view(f.g, name)
+        f.refresh_lowp()
+        for b in self.buffers():
+            b.data = b.data.to(device)
+        pe = self.encoder.positional_encoding.pe[0].to(device).contiguous()
+        self._engine = E.Engine(f, self.config, self.V, self.use_decoder, self.use_ctc, pe)
+        self._flat_device = device
+        return self._engine
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        state_dict = {k: v for k, v in state_dict.items()}
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._flat.p is not None:
+            self._flat.refresh_lowp()
+        return out
+
+    def zero_flat_grads(self):
+        f = self._flat
+        f.g.zero_()
+        for name, p in self._named_flat_params():
+            if p.grad is None or p.grad.data_ptr() != f.g.data_ptr() + 4 * f.index[name][0]:
+                p.grad = f.view(f.g, name)
+
+    # ------------------------------------------------------------------ reference API
+    def _prepare(self, input):
+        wave = input.wave
+        eng = self._ensure_engine(wave.device)
+        x = wave if wave.dtype == eng.dtype else wave.to(eng.dtype)
+        x = x.contiguous()
+        wave_len = input.wave_len.to(torch.int32)
+        tgt = input.tgt_for_input.contiguous()
+        prep = K.dec_preprocess(tgt, SOS_ID, EOS_ID)
+        return eng, x, wave_len, prep
+
+    def forward(self, input):
+        """transformer_official.py:68-81 (inference-style forward; no gradients)."""
+        eng, x, wave_len, prep = self._prepare(input)
+        B, T, _ = x.shape
+        enc, _ = eng.encoder_fwd(x, wave_len, self.attn_window)
+        pack = Pack()
+        pack.add(encoder_out=enc.view(B, T, -1))
+        if self.use_decoder:
+            cross_len = input.tgt_len.to(torch.int32) if self.cross_mask == "ref_compat" else wave_len
+            pred, _ = eng.decoder_fwd(prep, enc, cross_len, B, T)
+            pack.add(pred=pred.view(B, -1, self.V), gold=prep[1].long())
+        if self.use_ctc:
+            logits = eng.ctc_lo.fwd(enc)
+            pack.add(ctc_logits=logits.view(B, T, self.V))
+        return pack
+
+    def _cer(self, pred, gold):
+        """transformer_official.py:87-91.  Greedy ids by argmax (first index wins ties - the
+        reference's topk(1) tie order at exactly-zero padded rows is implementation-defined)."""
+        ids = pred.argmax(-1).cpu()
+        gold = gold.cpu()
+        hyp = [self.vocab.convert_id2str(r.tolist()) for r in ids]
+        ref = [self.vocab.convert_id2str(r.tolist()) for r in gold]
+        return sum(calculate_cer(h, r) for h, r in zip(hyp, ref)) * 100 / len(hyp)
+
+    def cal_metrics(self, output, input):
+        """transformer_official.py:83-94 on a forward() output (evaluation path)."""
+        pack = Pack()
+        row_nll = nll = n_valid = None
+        if self.use_decoder:
+            pred, gold = output.pred, output.gold
+            B, To, V = pred.shape
+            n_valid = (gold != PAD_ID).sum().float().reshape(1)
+            row_nll, _ = K.xent_fwd_bwd(pred.reshape(B * To, V).contiguous(), gold.reshape(-1).int(), n_valid, PAD_ID, want_grad=False)
+        if self.use_ctc:
+            prep = K.dec_preprocess(input.tgt_for_input.contiguous(), SOS_ID, EOS_ID)
+            nll, _ = K.ctc_fwd_bwd(output.ctc_logits.contiguous(), input.wave_len.to(torch.int32), prep[2], prep[4], self._engine.ws, want_grad=False)
+        lam = self.ctc_weight
+        loss = K.loss_combine(row_nll, n_valid, nll, 1.0 - lam if self.use_ctc else 1.0, lam)
+        assert not torch.isinf(loss[0])
+        pack.add(loss=loss[0])
+        if self.use_decoder:
+            pack.add(cer=torch.Tensor([self._cer(output.pred, output.gold)]))
+        return pack
+
+    def train_step(self, input, loss_scale=1.0, n_valid_override=None, ctc_batch=None):
+        """Forward + backward into the flat gradient buffer (no optimizer).  Returns the metrics
+        tensor [loss, ce, ctc] (device) and, for CER, (pred, gold) or None."""
+        eng, x, wave_len, prep = self._prepare(input)
+        B, T, _ = x.shape
+        lam = self.ctc_weight
+        enc, ecache = eng.encoder_fwd(x, wave_len, self.attn_window)
+        ys_in, ys_out, labels32, dec_len, lab_len, n_valid = prep
+        if n_valid_override is not None:
+            n_valid = n_valid_override(n_valid)
+        row_nll = nll = None
+        d_enc = None
+        pg = None
+        if self.use_decoder:
+            cross_len = input.tgt_len.to(torch.int32) if self.cross_mask == "ref_compat" else wave_len
+            pred, dcache = eng.decoder_fwd(prep, enc, cross_len, B, T)
+            if self.cer_in_iterate:
+                pg = (pred.view(B, -1, self.V).argmax(-1), ys_out)
+            w_ce = (1.0 - lam) if self.use_ctc else 1.0
+            row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, grad_scale=w_ce * loss_scale, dlogits=pred)
+        if self.use_ctc:
+            nb = float(ctc_batch if ctc_batch is not None else B)
+            nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale=lam * loss_scale / nb)
+        if self.use_decoder:
+            if d_enc is None:
+                d_enc = torch.zeros_like(enc)
+            eng.decoder_bwd(dcache, dpred, d_enc)
+        eng.encoder_bwd(ecache, d_enc)
+        loss = K.loss_combine(row_nll, n_valid, nll, (1.0 - lam) if self.use_ctc else 1.0, lam)
+        return loss, pg
+
+    def iterate(self, input, optimizer=None, is_train=True):
+        """transformer_official.py:96-104: forward, metrics, and - when training - zero_grad,
+        backward, clip_grad_norm_(5.0), optimizer.step()."""
+        if optimizer is None or not is_train:
+            with torch.no_grad():
+                output = self.forward(input)
+                return self.cal_metrics(output, input), None
+        self._ensure_engine(input.wave.device)
+        optimizer.zero_grad()
+        self.zero_flat_grads()
+        loss, pg = self.train_step(input)
+        fused = getattr(optimizer, "fused_step", None)
+        if fused is not None:
+            fused(self._flat, CLIP_NORM)                      # sumsq + clip + Noam + Adam, 3 launches
+        else:                                                 # any torch.optim-style optimizer
+            torch.nn.utils.clip_grad_norm_(self.parameters(), CLIP_NORM)
+            optimizer.step()
+            self._flat.refresh_lowp()
+        metrics = Pack()
+        metrics.add(loss=loss[0])
+        if self.use_decoder and self.use_ctc:
+            metrics.add(ce=loss[1], ctc=loss[2])
+        if pg is not None:
+            ids, gold = pg[0].cpu(), pg[1].cpu()
+            hyp = [self.vocab.convert_id2str(r.tolist()) for r in ids]
+            ref = [self.vocab.convert_id2str(r.tolist()) for r in gold]
+            metrics.add(cer=torch.Tensor([sum(calculate_cer(h, r) for h, r in zip(hyp, ref)) * 100 / len(hyp)]))
+        return metrics, None
+
+    def greedy_search(self):
+        pass
+
+    def beam_search(self):
+        pass
+
+    @classmethod
+    def get_default_config(cls):
+        class ModelConfig(BaseConfig):      # transformer_official.py:115-122 (+ the additions above)
+            d_model = 512
+            hidden_size = 64
+            ff_size = 1024
+            num_head = 8
+            dropout = 0.1
+            layer_num = 6
+            share_weight = False
+            ctc_weight = 0.0
+            cross_mask = "ref_compat"
+            dtype = "bf16"
+            attn_window = -1
+
+        return ModelConfig
+
+
+class TransformerOffical(_SpeechTransformer):
+    """Encoder-decoder with CE (and CTC when config.ctc_weight > 0)."""
+    USE_DECODER = True
+
+
+class TransformerCTC(_SpeechTransformer):
+    """Encoder + CTC head only (BASELINE.json config 2)."""
+    USE_DECODER = False

@@ -8,6 +8,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 
+# torch must be imported BEFORE the extension is dlopen'ed: libasr_hip.so then binds to the HIP
+# runtime instance torch has already loaded, so stream handles and device pointers are shared.
+# (Loaded the other way round the process ends up with two runtimes and every launch fails.)
+import torch  # noqa: F401  (side effect: loads libamdhip64)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libasr_hip.so")
 

@@ -1,0 +1,4 @@
+from .vocab import Vocab
+from .padder import Padder
+from .batch import collat, synthetic_pack, DataConfigAiShell1
+from .processor import AudioParser, build_LFR_features

@@ -1,0 +1,139 @@
+"""Data parallelism: one process per GPU, RCCL all-reduce of the flat gradient buffer over xGMI.
+
+The reference's only multi-GPU mechanism is an unused single-process torch.nn.DataParallel
+wrapper (Predictor/Bases/base_model.py:9-21, call site commented out at main.py:80).  Utterances
+are independent (every mask is per utterance, LayerNorm is per frame), so the path shards by
+minibatch with ONE exchange step per iteration: a sum all-reduce of the gradients.
+
+MI355X-first design:
+  * gradients already live in one flat fp32 buffer laid out in forward order; backward finishes
+    them from the END of the buffer towards the start, so buckets are contiguous slices - no
+    gather/scatter copies, no per-parameter hooks;
+  * the engine reports progress ("gradients at offsets >= o are final"); every bucket that lies
+    wholly above the mark is all-reduced on a high-priority side stream while backward continues;
+  * xGMI is point-to-point (7 links per GPU): a few large buckets (default 32 MB) keep each
+    transfer bandwidth-bound rather than latency-bound;
+  * the loss normalisers are made global BEFORE backward (token count all-reduced, CTC divided by
+    the global batch), so the summed gradients equal a single-process run on the concatenated
+    batch - no post-scaling pass over the gradients;
+  * the clip norm is computed on the reduced gradients, identical on every rank.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).
+    backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def make_buckets(block_ranges, numel, bucket_elems):
+    """Contiguous (start, end) slices of a flat buffer, built from the END backwards (the order in
+    which backward completes gradients), cut only at block starts.  Covers [0, numel) exactly."""
+    starts = sorted({s for s, _ in block_ranges} | {0})
+    buckets, end = [], numel
+    cur = numel
+    for s in reversed(starts):
+        if end - s >= bucket_elems or s == 0:
+            buckets.append((s, end))
+            end = s
+    assert buckets and buckets[-1][0] == 0 and sum(e - s for s, e in buckets) == numel
+    return buckets  # first bucket = highest offsets = ready first
+
+
+class GradBucketer:
+    """All-reduces `flat_g` bucket by bucket as `ready(offset)` marks move down."""
+
+    def __init__(self, flat_g, block_ranges, bucket_bytes=32 << 20, group=None):
+        self.g = flat_g
+        self.group = group
+        self.buckets = make_buckets(block_ranges, flat_g.numel(), max(1, bucket_bytes // flat_g.element_size()))
+        self.cuda = flat_g.is_cuda
+        self.comm_stream = torch.cuda.Stream(priority=-1) if self.cuda else None
+        self.next = 0
+        self.works = []
+
+    def begin(self):
+        self.next = 0
+        self.works = []
+
+    def _launch(self, i):
+        s, e = self.buckets[i]
+        view = self.g[s:e]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, offset):
+        """Gradients at flat offsets >= offset are final: launch every bucket fully above it."""
+        while self.next < len(self.buckets) and self.buckets[self.next][0] >= offset:
+            self._launch(self.next)
+            self.next += 1
+
+    def finish(self):
+        """Launch what is left and make the current stream wait for every bucket."""
+        self.ready(0)
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+class DataParallel:
+    """Wraps a model built on engine.FlatParams; `iterate` has the reference's signature."""
+
+    def __init__(self, model, device, bucket_bytes=32 << 20):
+        self.model = model
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        eng = model._ensure_engine(device)
+        flat = model._flat
+        dist.broadcast(flat.p, src=0)          # identical replicas
+        flat.refresh_lowp()
+        self.bucketer = GradBucketer(flat.g, flat.block_range, bucket_bytes)
+        eng.grad_ready = self.bucketer.ready
+
+    def _global_count(self, n_valid):
+        dist.all_reduce(n_valid, op=dist.ReduceOp.SUM)
+        return n_valid
+
+    def iterate(self, input, optimizer=None, is_train=True):
+        model = self.model
+        if optimizer is None or not is_train:
+            return model.iterate(input, optimizer, is_train)
+        from .Models.transformer_official import CLIP_NORM
+        from .Utils import Pack
+        model.zero_flat_grads()
+        self.bucketer.begin()
+        B = input.wave.shape[0]
+        loss, _ = model.train_step(input, n_valid_override=self._global_count, ctc_batch=B * self.world)
+        self.bucketer.finish()
+        optimizer.fused_step(model._flat, CLIP_NORM)
+        # CE was normalised by the GLOBAL token count (sum over ranks = global CE); the CTC term
+        # reported by the kernel is per local batch (mean over ranks = global CTC)
+        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+        lam = model.ctc_weight
+        ce, ctc = loss[1], loss[2] / self.world
+        total = ((1.0 - lam) * ce if model.use_ctc else ce) if model.use_decoder else 0.0
+        if model.use_ctc:
+            total = total + lam * ctc
+        metrics = Pack()
+        metrics.add(loss=total)
+        return metrics, None

@@ -1,0 +1,378 @@
+"""Explicit forward / backward engine of the Speech-Transformer over flat HBM buffers.
+
+No autograd and no tracing compiler: the step is a fixed sequence of C-ABI kernel launches
+(asr_chinese_e2e_amd.kernels) plus dense projections, written out by hand so that
+  * every parameter lives in ONE flat fp32 buffer (+ one flat fp32 gradient buffer, + Adam m/v,
+    + a bf16 shadow copy of the parameters that the MFMA GEMMs read); nn.Parameters are views,
+  * the flat order is the reverse of the order in which backward finishes gradients, so
+    data-parallel buckets are contiguous slices that can be all-reduced while backward is still
+    running (dist.py),
+  * fused projections (Q|K|V, cross-attention K|V) are plain views of adjacent parameters.
+
+Reference call stack this replaces: TransformerOffical.forward -> Encoder/Decoder ->
+MultiHeadAttention / PositionwiseFeedForwardUseConv -> cal_performance -> loss.backward()
+(Predictor/Models/transformer_official.py:68-104 and what it calls).
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from ._lib import ACT_NONE, ACT_RELU
+
+ALIGN = 64  # elements; keeps every block 256-byte (fp32) / 128-byte (bf16) aligned
+
+
+def positional_encoding(max_len, d_model):
+    """PositionalEncoding buffer, Predictor/Models/module.py:16-24."""
+    pe = torch.zeros(max_len, d_model)
+    pos = torch.arange(0, max_len).unsqueeze(1).float()
+    w = torch.exp(torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(pos * w)
+    pe[:, 1::2] = torch.cos(pos * w)
+    return pe.unsqueeze(0)
+
+
+class FlatParams:
+    """Flat fp32 parameter / gradient / Adam-state buffers with named views.
+
+    `blocks` is a list of lists of (name, shape): the tensors of one block are laid out
+    back-to-back (no padding inside a block, so e.g. w_qs|w_ks|w_vs form one (3*H*dk, d) matrix);
+    every block starts at a multiple of ALIGN elements."""
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+        self.index = {}       # name -> (offset, shape)
+        self.block_range = []  # (start, end) per block
+        off = 0
+        for blk in blocks:
+            start = off
+            for name, shape in blk:
+                n = 1
+                for s in shape:
+                    n *= s
+                self.index[name] = (off, tuple(shape))
+                off += n
+            self.block_range.append((start, off))
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.device = None
+        self.p = self.g = self.m = self.v = self.lp = None
+
+    def allocate(self, device, lowp):
+        self.device = torch.device(device)
+        z = lambda dt: torch.zeros(self.numel, dtype=dt, device=self.device)
+        self.p, self.g, self.m, self.v = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
+        self.lp = z(torch.bfloat16) if lowp else None
+
+    def view(self, buf, name):
+        off, shape = self.index[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[off:off + n].view(shape)
+
+    def span(self, buf, first, last, shape):
+        """One view over the adjacent tensors first..last (must be consecutive in a block)."""
+        o0, _ = self.index[first]
+        o1, s1 = self.index[last]
+        n1 = 1
+        for s in s1:
+            n1 *= s
+        n = 1
+        for s in shape:
+            n *= s
+        assert o1 + n1 - o0 == n, f"{first}..{last} is not contiguous ({o1 + n1 - o0} != {n})"
+        return buf[o0:o0 + n].view(shape)
+
+    def refresh_lowp(self):
+        if self.lp is not None:
+            K.cast(self.p, self.lp)
+
+
+class Linear:
+    """y = x W^T + b with W (N,K) a view of the flat buffers.  bf16: hand-written MFMA kernels
+    (asr_gemm_nt_bf16 forward, asr_gemm_tn_bf16 weight gradient); shapes the kernels do not take
+    (K or leading dims not multiples of 8) and fp32 mode go to the hipBLASLt/rocBLAS library GEMM
+    through torch.matmul - a plain library GEMM, never a CPU fallback."""
+
+    def __init__(self, flat, w_names, b_names, N, Kdim):
+        self.flat, self.N, self.K = flat, N, Kdim
+        self.w32 = flat.span(flat.p, w_names[0], w_names[-1], (N, Kdim))
+        self.gw = flat.span(flat.g, w_names[0], w_names[-1], (N, Kdim))
+        self.wlp = flat.span(flat.lp, w_names[0], w_names[-1], (N, Kdim)) if flat.lp is not None else None
+        if b_names:
+            self.b32 = flat.span(flat.p, b_names[0], b_names[-1], (N,))
+            self.gb = flat.span(flat.g, b_names[0], b_names[-1], (N,))
+        else:
+            self.b32 = self.gb = None
+
+    def rows(self, lo, hi):
+        """A Linear over output rows [lo, hi) of this one (e.g. the K|V part of Q|K|V)."""
+        sub = object.__new__(Linear)
+        sub.flat, sub.N, sub.K = self.flat, hi - lo, self.K
+        sub.w32, sub.gw = self.w32[lo:hi], self.gw[lo:hi]
+        sub.wlp = self.wlp[lo:hi] if self.wlp is not None else None
+        sub.b32 = self.b32[lo:hi] if self.b32 is not None else None
+        sub.gb = self.gb[lo:hi] if self.gb is not None else None
+        return sub
+
+    # ---- forward
+    def fwd(self, x, act=ACT_NONE, out=None):
+        M = x.shape[0]
+        out = torch.empty(M, self.N, dtype=x.dtype, device=x.device) if out is None else out
+        if x.dtype == torch.bfloat16 and K.gemm_nt_supported(M, self.N, self.K, x.stride(0), self.wlp.stride(0), out.stride(0)):
+            K.gemm_nt(x, self.wlp, self.b32, out, act)
+            return out
+        w = self.wlp if x.dtype == torch.bfloat16 else self.w32
+        if self.b32 is not None:
+            torch.addmm(self.b32.to(x.dtype), x, w.t(), out=out)
+        else:
+            torch.mm(x, w.t(), out=out)
+        if act == ACT_RELU:
+            K.relu_(out)
+        return out
+
+    # ---- backward pieces
+    def dgrad(self, dy, out=None, accumulate=False):
+        """dx = dy W, or out += dy W when accumulate."""
+        w = self.wlp if dy.dtype == torch.bfloat16 else self.w32
+        flops = 2.0 * dy.shape[0] * self.N * self.K
+        if accumulate:
+            return K.timed("lib_gemm_dgrad", flops, lambda: out.addmm_(dy, w))
+        if out is None:
+            return K.timed("lib_gemm_dgrad", flops, lambda: torch.mm(dy, w))
+        return K.timed("lib_gemm_dgrad", flops, lambda: torch.mm(dy, w, out=out))
+
+    def wgrad(self, dy, x):
+        """gw += dy^T x  (fp32 accumulation into the flat gradient buffer)."""
+        M = x.shape[0]
+        if dy.dtype == torch.bfloat16 and self.N % 8 == 0 and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
+            K.gemm_tn(dy, x, self.gw, accumulate=True)
+        elif dy.dtype == torch.bfloat16:
+            self.gw.add_(torch.mm(dy.t(), x).float())
+        else:
+            self.gw.addmm_(dy.t(), x)
+
+    def bgrad(self, dy, ws):
+        if self.gb is not None:
+            K.colsum(dy, self.gb, ws, accumulate=True)
+
+
+class LayerNormP:
+    def __init__(self, flat, prefix):
+        self.g = flat.view(flat.p, prefix + ".weight")
+        self.b = flat.view(flat.p, prefix + ".bias")
+        self.gg = flat.view(flat.g, prefix + ".weight")
+        self.gb = flat.view(flat.g, prefix + ".bias")
+
+
+class MHA:
+    """MultiHeadAttention of the reference (attention.py:6-62) over fused projections."""
+
+    def __init__(self, flat, pre, H, dk, d):
+        self.H, self.dk, self.d = H, dk, d
+        hd = H * dk
+        self.qkv = Linear(flat, [pre + "w_qs.weight", pre + "w_ks.weight", pre + "w_vs.weight"],
+                          [pre + "w_qs.bias", pre + "w_ks.bias", pre + "w_vs.bias"], 3 * hd, d)
+        self.q = self.qkv.rows(0, hd)
+        self.kv = self.qkv.rows(hd, 3 * hd)
+        self.fc = Linear(flat, [pre + "fc.weight"], [pre + "fc.bias"], d, hd)
+        self.ln = LayerNormP(flat, pre + "layer_norm")
+
+
+class FFN:
+    def __init__(self, flat, pre, d, ff):
+        self.w1 = Linear(flat, [pre + "w_1.weight"], [pre + "w_1.bias"], ff, d)
+        self.w2 = Linear(flat, [pre + "w_2.weight"], [pre + "w_2.bias"], d, ff)
+        self.ln = LayerNormP(flat, pre + "layer_norm")
+
+
+def mha_param_block(pre, H, dk, d):
+    hd = H * dk
+    return [[(pre + "w_qs.weight", (hd, d)), (pre + "w_ks.weight", (hd, d)), (pre + "w_vs.weight", (hd, d))],
+            [(pre + "w_qs.bias", (hd,)), (pre + "w_ks.bias", (hd,)), (pre + "w_vs.bias", (hd,))],
+            [(pre + "layer_norm.weight", (d,))], [(pre + "layer_norm.bias", (d,))],
+            [(pre + "fc.weight", (d, hd))], [(pre + "fc.bias", (d,))]]
+
+
+def ffn_param_block(pre, d, ff):
+    return [[(pre + "w_1.weight", (ff, d, 1))], [(pre + "w_1.bias", (ff,))],
+            [(pre + "w_2.weight", (d, ff, 1))], [(pre + "w_2.bias", (d,))],
+            [(pre + "layer_norm.weight", (d,))], [(pre + "layer_norm.bias", (d,))]]
+
+
+class Engine:
+    """Forward + backward of encoder (+ decoder) (+ CTC head) for one minibatch on one GPU."""
+
+    def __init__(self, flat, cfg, vocab_size, use_decoder, use_ctc, pe):
+        self.flat, self.cfg = flat, cfg
+        self.V = vocab_size
+        self.use_decoder, self.use_ctc = use_decoder, use_ctc
+        d, H, dk, ff = cfg.d_model, cfg.num_head, cfg.hidden_size, cfg.ff_size
+        self.d, self.H, self.dk, self.ff = d, H, dk, ff
+        self.d_in = cfg.n_mels * cfg.lfr_m
+        self.L = cfg.layer_num
+        self.dtype = torch.bfloat16 if flat.lp is not None else torch.float32
+        self.pe = pe  # (>=maxlen, d) f32 on device
+        self.ws = K.Workspace(flat.device)
+        self.lin_in = Linear(flat, ["encoder.linear_in.weight"], ["encoder.linear_in.bias"], d, self.d_in)
+        self.ln_in = LayerNormP(flat, "encoder.layer_norm_in")
+        self.enc = [(MHA(flat, f"encoder.layer_stack.{i}.slf_attn.", H, dk, d), FFN(flat, f"encoder.layer_stack.{i}.pos_ffn.", d, ff))
+                    for i in range(self.L)]
+        if use_decoder:
+            self.emb32 = flat.view(flat.p, "decoder.tgt_word_emb.weight")
+            self.gemb = flat.view(flat.g, "decoder.tgt_word_emb.weight")
+            self.prj = Linear(flat, ["decoder.tgt_word_emb.weight"], None, vocab_size, d)
+            self.dec = [(MHA(flat, f"decoder.layer_stack.{i}.slf_attn.", H, dk, d), MHA(flat, f"decoder.layer_stack.{i}.enc_attn.", H, dk, d),
+                         FFN(flat, f"decoder.layer_stack.{i}.pos_ffn.", d, ff)) for i in range(self.L)]
+        if use_ctc:
+            self.ctc_lo = Linear(flat, ["ctc_lo.weight"], ["ctc_lo.bias"], vocab_size, d)
+        self.grad_ready = None  # callback(offset): gradients at flat offsets >= offset are final
+
+    # ------------------------------------------------------------------ helpers
+    def _ready(self, name):
+        if self.grad_ready is not None:
+            self.grad_ready(self.flat.index[name][0])
+
+    def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross):
+        """x: (B*Tq, d) queries + residual; kv_src: (B*Tk, d).  Returns output and cache."""
+        H, dk, hd = self.H, self.dk, self.H * self.dk
+        c = {}
+        if not cross:
+            qkv = m.qkv.fwd(x)
+            q, k, v = qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:]
+            c["qkv"] = qkv
+        else:
+            q = m.q.fwd(x)
+            kv = m.kv.fwd(kv_src)
+            k, v = kv[:, :hd], kv[:, hd:]
+            c["q"], c["kv"] = q, kv
+        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window)
+        a = m.fc.fwd(ctx)
+        y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a)
+        c.update(x=x, kv_src=kv_src, ctx=ctx, lse=lse, xhat=xhat, rstd=rstd, k_len=k_len, q_lens=q_lens, dims=(B, Tq, Tk), causal=causal,
+                 window=window, cross=cross)
+        return y, c
+
+    def _attn_block_bwd(self, m, c, dy, dy2, d_kv_src=None):
+        """Returns (dx_proj, dz): gradient wrt the block input through the projections, and the
+        residual-path gradient dz (to be added by the consumer).  For cross attention the
+        key/value-source gradient is accumulated into d_kv_src in place."""
+        H, dk, hd = self.H, self.dk, self.H * self.dk
+        B, Tq, Tk = c["dims"]
+        dz = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], m.ln.g, c["q_lens"], m.ln.gg, m.ln.gb, m.fc.gb, B, Tq, self.ws)
+        m.fc.wgrad(dz, c["ctx"])
+        dctx = m.fc.dgrad(dz)
+        if not c["cross"]:
+            qkv = c["qkv"]
+            dqkv = torch.empty_like(qkv)
+            K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
+                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"])
+            m.qkv.bgrad(dqkv, self.ws)
+            m.qkv.wgrad(dqkv, c["x"])
+            dx = m.qkv.dgrad(dqkv)
+        else:
+            q, kv = c["q"], c["kv"]
+            dq = torch.empty_like(q)
+            dkv = torch.empty_like(kv)
+            K.sdpa_bwd(q, kv[:, :hd], kv[:, hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk, dq, dkv[:, :hd], dkv[:, hd:],
+                       c["causal"], c["window"])
+            m.q.bgrad(dq, self.ws)
+            m.kv.bgrad(dkv, self.ws)
+            m.q.wgrad(dq, c["x"])
+            m.kv.wgrad(dkv, c["kv_src"])
+            dx = m.q.dgrad(dq)
+            m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
+        return dx, dz
+
+    def _ffn_block_fwd(self, f, x, B, T, lens):
+        h = f.w1.fwd(x, act=ACT_RELU)
+        o = f.w2.fwd(h)
+        y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o)
+        return y, dict(x=x, h=h, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T))
+
+    def _ffn_block_bwd(self, f, c, dy, dy2):
+        B, T = c["dims"]
+        dz = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], f.ln.g, c["lens"], f.ln.gg, f.ln.gb, f.w2.gb, B, T, self.ws)
+        f.w2.wgrad(dz, c["h"])
+        dh = f.w2.dgrad(dz)
+        K.relu_bwd_(dh, c["h"], f.w1.gb, self.ws)
+        f.w1.wgrad(dh, c["x"])
+        dx = f.w1.dgrad(dh)
+        return dx, dz
+
+    # ------------------------------------------------------------------ encoder
+    def encoder_fwd(self, wave, wave_len, window=-1):
+        """wave (B,T,F) in the compute dtype, wave_len (B) int32.  transformer_official.py:158-189."""
+        B, T, F = wave.shape
+        x_in = wave.reshape(B * T, F)
+        e0 = self.lin_in.fwd(x_in)
+        h, xhat, rstd = K.add_ln_fwd(e0, None, self.ln_in.g, self.ln_in.b, self.pe, None, B, T, xhat=e0)
+        cache = dict(x_in=x_in, xhat_in=xhat, rstd_in=rstd, B=B, T=T, layers=[])
+        for mha, ffn in self.enc:
+            h1, c1 = self._attn_block_fwd(mha, h, h, B, T, T, wave_len, wave_len, False, window, False)
+            h, c2 = self._ffn_block_fwd(ffn, h1, B, T, wave_len)
+            cache["layers"].append((c1, c2))
+        return h, cache
+
+    def encoder_bwd(self, cache, d_enc):
+        B, T = cache["B"], cache["T"]
+        dy, dy2 = d_enc, None
+        for i in reversed(range(self.L)):
+            mha, ffn = self.enc[i]
+            c1, c2 = cache["layers"][i]
+            dx, dz = self._ffn_block_bwd(ffn, c2, dy, dy2)
+            dx, dz = self._attn_block_bwd(mha, c1, dx, dz)
+            dy, dy2 = dx, dz
+            self._ready(f"encoder.layer_stack.{i}.slf_attn.w_qs.weight")
+        dz = K.add_ln_bwd(dy, dy2, cache["xhat_in"], cache["rstd_in"], self.ln_in.g, None, self.ln_in.gg, self.ln_in.gb, self.lin_in.gb, B, T, self.ws)
+        self.lin_in.wgrad(dz, cache["x_in"])
+        self._ready("encoder.linear_in.weight")
+
+    # ------------------------------------------------------------------ CTC head
+    def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True):
+        """Returns (nll (B,), d_enc contribution or None)."""
+        logits = self.ctc_lo.fwd(enc)
+        nll, dl = K.ctc_fwd_bwd(logits.view(B, T, self.V), wave_len, labels32, lab_len, self.ws, blank=0, grad_scale=grad_scale,
+                                dlogits=logits.view(B, T, self.V) if want_grad else None, want_grad=want_grad)
+        if not want_grad:
+            return nll, None
+        dl = dl.view(B * T, self.V)
+        self.ctc_lo.bgrad(dl, self.ws)
+        self.ctc_lo.wgrad(dl, enc)
+        d_enc = self.ctc_lo.dgrad(dl)
+        self._ready("ctc_lo.weight")
+        return nll, d_enc
+
+    # ------------------------------------------------------------------ decoder
+    def decoder_fwd(self, prep, enc, cross_len, B, T):
+        """prep = kernels.dec_preprocess(tgt).  transformer_official.py:277-328."""
+        ys_in, ys_out, labels32, dec_len, lab_len, n_valid = prep
+        To = ys_in.shape[1]
+        x = K.embed_pe_fwd(ys_in.reshape(-1), self.emb32, self.pe, self.d ** -0.5, B, To, self.dtype)
+        cache = dict(B=B, T=T, To=To, ys_in=ys_in, layers=[])
+        for slf, cross, ffn in self.dec:
+            x1, c1 = self._attn_block_fwd(slf, x, x, B, To, To, dec_len, dec_len, True, -1, False)
+            x2, c2 = self._attn_block_fwd(cross, x1, enc, B, To, T, cross_len, dec_len, False, -1, True)
+            x, c3 = self._ffn_block_fwd(ffn, x2, B, To, dec_len)
+            cache["layers"].append((c1, c2, c3))
+        pred = self.prj.fwd(x)
+        cache["x_last"] = x
+        return pred, cache
+
+    def decoder_bwd(self, cache, dpred, d_enc):
+        """dpred (B*To, V); accumulates the encoder-output gradient into d_enc (B*T, d) in place."""
+        self.prj.wgrad(dpred, cache["x_last"])
+        dy, dy2 = self.prj.dgrad(dpred), None
+        for i in reversed(range(self.L)):
+            slf, cross, ffn = self.dec[i]
+            c1, c2, c3 = cache["layers"][i]
+            dx, dz = self._ffn_block_bwd(ffn, c3, dy, dy2)
+            dx, dz = self._attn_block_bwd(cross, c2, dx, dz, d_kv_src=d_enc)
+            dx, dz = self._attn_block_bwd(slf, c1, dx, dz)
+            dy, dy2 = dx, dz
+            self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
+        dx = dy + dy2  # gradient wrt the embedding output
+        K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5)
+        self._ready("decoder.tgt_word_emb.weight")

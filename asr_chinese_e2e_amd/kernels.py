@@ -43,6 +43,44 @@ def _chk_i32(*ts):
             raise ValueError("expected a contiguous int32 tensor")
 
 
+class LaunchTimer:
+    """HIP-event timing of selected launches on the stream they are issued on (bench.py's
+    roofline leg).  `work` is the algorithmic flop (or byte) count of the launch."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.rec = {n: [] for n in names}
+
+    def run(self, name, work, fn):
+        if name not in self.names:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.rec[name].append((e0, e1, work))
+        return out
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_us, work_per_s) (call after a device sync)."""
+        out = {}
+        for n, r in self.rec.items():
+            if not r:
+                continue
+            ms = [a.elapsed_time(b) for a, b, _ in r]
+            tot, work = sum(ms), sum(w for _, _, w in r)
+            out[n] = dict(launches=len(r), total_ms=tot, avg_us=1e3 * tot / len(r), work_per_s=work / (tot * 1e-3) if tot > 0 else 0.0,
+                          work_per_launch=work / len(r))
+        return out
+
+
+TIMER = None   # set to a LaunchTimer by bench.py
+
+
+def timed(name, work, fn):
+    return fn() if TIMER is None else TIMER.run(name, work, fn)
+
+
 class Workspace:
     """Grow-only scratch buffer (never shrinks, so pointers stay valid under graph replay once
     the high-water mark has been reached during warm-up)."""
@@ -289,8 +327,9 @@ def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None):
     _chk_f32(bias)
     if res is not None:
         assert res.dtype == torch.bfloat16 and res.shape == out.shape and res.stride() == out.stride()
-    check(lib.asr_gemm_nt_bf16(_p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0),
-                               out.stride(0), int(act), _stream()), "asr_gemm_nt_bf16")
+    timed("gemm_nt", 2.0 * M * N * K, lambda: check(
+        lib.asr_gemm_nt_bf16(_p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), int(act),
+                             _stream()), "asr_gemm_nt_bf16"))
     return out
 
 
@@ -300,8 +339,9 @@ def gemm_tn(dy, x, dw, accumulate=True):
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dw.shape == (N, K) and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
-    check(lib.asr_gemm_tn_bf16(_p(dy), _p(x), _p(dw), M, N, K, dy.stride(0), x.stride(0), dw.stride(0),
-                               int(accumulate), None, 0, _stream()), "asr_gemm_tn_bf16")
+    timed("gemm_tn", 2.0 * M * N * K, lambda: check(
+        lib.asr_gemm_tn_bf16(_p(dy), _p(x), _p(dw), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), None, 0,
+                             _stream()), "asr_gemm_tn_bf16"))
     return dw
 
 

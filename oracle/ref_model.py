@@ -343,7 +343,9 @@ def init_state_dict(cfg, vocab_size, seed=0, dtype=torch.float32):
         mha(f"encoder.layer_stack.{i}.slf_attn.")
         ffn(f"encoder.layer_stack.{i}.pos_ffn.")
     if cfg.use_decoder:
-        sd["decoder.tgt_word_emb.weight"] = xavier(vocab_size, d)
+        # nn.Embedding default N(0,1); the tied projection's own xavier init is discarded when the
+        # weights are shared (transformer_official.py:250-256)
+        sd["decoder.tgt_word_emb.weight"] = normal((vocab_size, d), 1.0)
         sd["decoder.positional_encoding.pe"] = positional_encoding(5000, d, dtype).unsqueeze(0)
         for i in range(cfg.layer_num):
             mha(f"decoder.layer_stack.{i}.slf_attn.")
