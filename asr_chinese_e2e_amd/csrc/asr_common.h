@@ -119,27 +119,29 @@ __device__ __forceinline__ float log_add(float a, float b) {
     return m + __logf(__expf(a - m) + __expf(b - m));
 }
 
-// out[c] (+)= sum_p part[p*pstride + c], c < ncols.  32 columns x 8 partial groups per block.
-static __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int P,
-                                                              size_t pstride, int ncols,
-                                                              float* __restrict__ out,
-                                                              int accumulate) {
-    __shared__ float red[8][33];
+// Second stage of every column reduction: out_k[c] (+)= sum_p part[p*pstride + k*d + c] for the
+// up-to-three vectors k packed side by side in a partial row.  32 columns x 32 partial groups per
+// 1024-thread workgroup: each thread sums P/32 partials, so the pass is a few microseconds.
+static __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int P, size_t pstride, int ncols, int d,
+                                                                      float* __restrict__ out0, float* __restrict__ out1,
+                                                                      float* __restrict__ out2, int accumulate) {
+    __shared__ float red[32][33];
     const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cg;
     float s = 0.f;
     if (col < ncols)
-        for (int p = pg; p < P; p += 8) s += part[(size_t)p * pstride + col];
+        for (int p = pg; p < P; p += 32) s += part[(size_t)p * pstride + col];
     red[pg][cg] = s;
     __syncthreads();
     if (pg == 0 && col < ncols) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += red[i][cg];
-        out[col] = accumulate ? out[col] + t : t;
+        for (int i = 0; i < 32; ++i) t += red[i][cg];
+        const int k = col / d, c = col - k * d;
+        float* out = k == 0 ? out0 : (k == 1 ? out1 : out2);
+        out[c] = accumulate ? out[c] + t : t;
     }
 }
-
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

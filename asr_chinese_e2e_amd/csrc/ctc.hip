@@ -118,6 +118,15 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------- kernel 2
+// whole-wave shifts by one lane through DPP (no LDS round trip as ds_bpermute would need): the
+// lane that has no source keeps -inf.
+__device__ __forceinline__ float wave_shr1(float v) {   // lane i <- lane i-1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(NEG_INF), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v) {   // lane i <- lane i+1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(NEG_INF), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 // NS = states per lane (S <= 64*NS).  dir = 0: alpha (wave 0), 1: beta (wave 1).
 template <int NS>
 __device__ __forceinline__ float ctc_recursion(const float* __restrict__ lp, float* __restrict__ out, const int32_t* __restrict__ lab,
@@ -185,10 +194,11 @@ __device__ __forceinline__ float ctc_recursion(const float* __restrict__ lp, flo
                 if (!backward) {
 #pragma unroll
                     for (int j = 0; j < NS; ++j) {
-                        float u1 = __shfl_up(a[j], 1, 64), u2 = __shfl_up(a[j], 2, 64);
+                        float u1 = wave_shr1(a[j]);
+                        float u2 = wave_shr1(u1);
                         // lanes 0/1 take their predecessors from the previous register's top lanes
-                        const float p1 = j > 0 ? __shfl(a[j > 0 ? j - 1 : 0], 63, 64) : NEG_INF;
-                        const float p2a = j > 0 ? __shfl(a[j > 0 ? j - 1 : 0], 62, 64) : NEG_INF;
+                        const float p1 = j > 0 ? lane_bcast(a[j > 0 ? j - 1 : 0], 63) : NEG_INF;
+                        const float p2a = j > 0 ? lane_bcast(a[j > 0 ? j - 1 : 0], 62) : NEG_INF;
                         if (lane == 0) { u1 = p1; u2 = p2a; }
                         if (lane == 1) { u2 = p1; }
                         n1[j] = u1;
@@ -197,9 +207,10 @@ __device__ __forceinline__ float ctc_recursion(const float* __restrict__ lp, flo
                 } else {
 #pragma unroll
                     for (int j = 0; j < NS; ++j) {
-                        float u1 = __shfl_down(a[j], 1, 64), u2 = __shfl_down(a[j], 2, 64);
-                        const float p1 = j + 1 < NS ? __shfl(a[j + 1 < NS ? j + 1 : j], 0, 64) : NEG_INF;
-                        const float p2a = j + 1 < NS ? __shfl(a[j + 1 < NS ? j + 1 : j], 1, 64) : NEG_INF;
+                        float u1 = wave_shl1(a[j]);
+                        float u2 = wave_shl1(u1);
+                        const float p1 = j + 1 < NS ? lane_bcast(a[j + 1 < NS ? j + 1 : j], 0) : NEG_INF;
+                        const float p2a = j + 1 < NS ? lane_bcast(a[j + 1 < NS ? j + 1 : j], 1) : NEG_INF;
                         if (lane == 63) { u1 = p1; u2 = p2a; }
                         if (lane == 62) { u2 = p1; }
                         n1[j] = u1;
@@ -210,7 +221,9 @@ __device__ __forceinline__ float ctc_recursion(const float* __restrict__ lp, flo
                 for (int j = 0; j < NS; ++j) {
                     const float m = fmaxf(fmaxf(a[j], n1[j]), n2[j]);
                     float r = NEG_INF;
-                    if (m != NEG_INF) r = m + logf(expf(a[j] - m) + expf(n1[j] - m) + expf(n2[j] - m)) + cur[k][j];
+                    // hardware exp2/log2 (1 ulp): the recursion is renormalised every 8 steps, so the
+                    // absolute log-domain error stays ~1e-6 per step
+                    if (m != NEG_INF) r = m + __logf(__expf(a[j] - m) + __expf(n1[j] - m) + __expf(n2[j] - m)) + cur[k][j];
                     a[j] = live[j] ? r : NEG_INF;
                 }
             }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
     }
 }
 
-// partial column sums land in ws as [wave_slot][3][d] f32 (slot = blockIdx*LN_WAVES + wave)
+// partial column sums land in ws as [blockIdx][3][d] f32 (the 4 waves are combined through LDS)
 template <typename T, int N, bool VEC8>
 __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ xhat,
@@ -154,10 +154,15 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
         }
         RS::store(dz + (size_t)row * d, d, lane, o);
     }
-    float* slot = ws + (size_t)(blockIdx.x * LN_WAVES + w) * 3 * d;
-    RS::storef(slot, d, lane, acc_g);
-    RS::storef(slot + d, d, lane, acc_b);
-    RS::storef(slot + 2 * d, d, lane, acc_z);
+    __shared__ __attribute__((aligned(16))) float sred[LN_WAVES][2048];
+    float* slot = ws + (size_t)blockIdx.x * 3 * d;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        RS::storef(sred[w], d, lane, k == 0 ? acc_g : (k == 1 ? acc_b : acc_z));
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += LN_WAVES * WAVE) slot[k * d + c] = sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c];
+        __syncthreads();
+    }
 }
 
 }  // namespace
@@ -168,7 +173,7 @@ static int ln_grid(int rows) {
 }
 
 extern "C" size_t asr_add_ln_bwd_workspace_bytes(int rows, int d) {
-    return (size_t)ln_grid(rows) * LN_WAVES * 3 * d * sizeof(float);
+    return (size_t)ln_grid(rows) * 3 * d * sizeof(float);
 }
 
 template <typename T>
@@ -251,11 +256,9 @@ extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat,
     if (dtype == ASR_F32) launch_ln_bwd<float>(dy, dy2, xhat, rstd, gamma, lens, dz, (float*)ws, rows, T, d, st);
     else if (dtype == ASR_BF16) launch_ln_bwd<bf16_t>(dy, dy2, xhat, rstd, gamma, lens, dz, (float*)ws, rows, T, d, st);
     else ASR_FAIL(ASR_EDTYPE, "asr_add_ln_bwd: dtype %d", dtype);
-    const int P = ln_grid(rows) * LN_WAVES;
-    const int fgrid = ceil_div(d, 32);
-    colsum_finalize_kernel<<<fgrid, 256, 0, st>>>((const float*)ws, P, (size_t)3 * d, d, dgamma, 1);
-    colsum_finalize_kernel<<<fgrid, 256, 0, st>>>((const float*)ws + d, P, (size_t)3 * d, d, dbeta, 1);
-    if (dbias) colsum_finalize_kernel<<<fgrid, 256, 0, st>>>((const float*)ws + 2 * d, P, (size_t)3 * d, d, dbias, 1);
+    const int P = ln_grid(rows);
+    const int ncols = dbias ? 3 * d : 2 * d;
+    colsum_finalize_kernel<<<ceil_div(ncols, 32), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
     ASR_CHECK_LAUNCH("asr_add_ln_bwd");
     return ASR_OK;
 }

@@ -93,10 +93,11 @@ __global__ __launch_bounds__(CS_WAVES* WAVE) void colsum_partial_kernel(T* __res
                 }
         }
     }
-    float* slot = ws + (size_t)(blockIdx.y * CS_WAVES + w) * cols;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (c0 + j < cols) slot[c0 + j] = acc[j];
+    __shared__ __attribute__((aligned(16))) float sred[CS_WAVES][256];
+    *(f32x4*)&sred[w][lane * 4] = acc;
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) ws[(size_t)blockIdx.y * cols + c] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
 }
 
 static int cs_row_slots(int rows, int cols) {
@@ -297,7 +298,7 @@ extern "C" int asr_cast(const void* src, void* dst, size_t n, int sd, int dd, vo
 }
 
 extern "C" size_t asr_colsum_workspace_bytes(int rows, int cols) {
-    return (size_t)cs_row_slots(rows, cols) * CS_WAVES * cols * sizeof(float);
+    return (size_t)cs_row_slots(rows, cols) * cols * sizeof(float);
 }
 
 template <bool RELU_BWD>
@@ -314,7 +315,7 @@ static int colsum_impl(void* x, const void* a, float* out, void* ws, size_t ws_b
     if (dtype == ASR_F32) colsum_partial_kernel<float, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((float*)x, (const float*)a, (float*)ws, rows, cols, ld, slots);
     else if (dtype == ASR_BF16) colsum_partial_kernel<bf16_t, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((bf16_t*)x, (const bf16_t*)a, (float*)ws, rows, cols, ld, slots);
     else ASR_FAIL(ASR_EDTYPE, "%s: dtype %d", name, dtype);
-    if (want_sum) colsum_finalize_kernel<<<ceil_div(cols, 32), 256, 0, st>>>((const float*)ws, slots * CS_WAVES, (size_t)cols, cols, out, accumulate);
+    if (want_sum) colsum_finalize_kernel<<<ceil_div(cols, 32), 1024, 0, st>>>((const float*)ws, slots, (size_t)cols, cols, cols, out, nullptr, nullptr, accumulate);
     ASR_CHECK_LAUNCH(name);
     return ASR_OK;
 }

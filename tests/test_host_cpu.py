@@ -1,0 +1,220 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/asr_hip.h
+declares, and the host logic that mirrors the reference's plugin interface (config merge, vocab
+ids, padder, Pack, Noam schedule, LFR, CER convention, state_dict key names, flat layout, DP
+bucketing over gloo)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import ROOT, golden_model_case, load_npz
+
+
+# ------------------------------------------------------------------------------------ C ABI
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "asr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(asr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from asr_chinese_e2e_amd import _lib
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in include/asr_hip.h but not exported by libasr_hip.so"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert _lib.lib.asr_abi_version() == 1
+    # argument counts of the binding match the header declarations
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "asr_hip.h")).read(), flags=re.S)
+    for n in names:
+        m = re.search(r"\b" + n + r"\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+        args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        assert len(args) == len(_lib.SIGNATURES[n][1]), n
+
+
+def test_library_is_gfx950_only_and_has_no_torch_types():
+    so = os.path.join(ROOT, "asr_chinese_e2e_amd", "libasr_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert all(not ("torch" in s or "c10" in s or "at::" in s) for s in exported)
+    assert set(header_functions()) <= set(exported)
+
+
+def test_error_reporting_without_gpu():
+    """Argument validation happens on the host before any launch: callable without a GPU."""
+    from asr_chinese_e2e_amd import _lib
+    rc = _lib.lib.asr_add_ln_fwd(None, None, None, None, None, None, None, None, None, 1, 1, 8, 0, None)
+    assert rc == -1 and "null pointer" in _lib.last_error()
+    rc = _lib.lib.asr_ctc_workspace_bytes(32, 500, 22)
+    assert rc == (3 * 32 * 500 * 48 + 32 * 500 + 32) * 4
+    with pytest.raises(_lib.AsrHipError):
+        _lib.check(-1, "x")
+
+
+def test_no_cpu_fallback_in_product_path():
+    from asr_chinese_e2e_amd import kernels as K
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        K.relu_(torch.zeros(8))
+    src = ""
+    for dp, _, fs in os.walk(os.path.join(ROOT, "asr_chinese_e2e_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src += open(os.path.join(dp, f)).read()
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+# ------------------------------------------------------------------------------------ host logic
+def test_config_merge_semantics():
+    from asr_chinese_e2e_amd.Bases import BaseConfig
+    z = load_npz("ops.npz")
+
+    class C(BaseConfig):
+        a = 1
+        b = 2
+
+    class D(BaseConfig):
+        b = 5
+        c = 7
+
+    c = C()
+    c.fn_build({"a": 3, "zzz": 9})      # unknown keys are ADDED (base_config.py:7-15)
+    c.fn_combine(D())
+    assert [c.a, c.b, c.c, c.zzz] == list(z["config/abc_zzz"])
+
+
+def test_vocab_padder_pack():
+    from asr_chinese_e2e_amd.data_handler import Padder, Vocab
+    from asr_chinese_e2e_amd.Utils import Pack
+    z = load_npz("ops.npz")
+    v = Vocab()
+    v.consume_sentance_list(["你好你", "好的"])
+    v.build()
+    assert v.vocab_size == int(z["vocab/size"])
+    assert v.convert_str("你好吗", use_bos=False, use_eos=False) == list(z["vocab/ids_plain"])
+    assert v.convert_str("你好吗") == list(z["vocab/ids_boseos"])
+    assert v.convert_id2str([4, 0, 5, 0]) == "你 好"
+    o2, l2 = Padder.pad_two([[4, 5, 6], [7], [8, 9]], 0)
+    assert np.array_equal(o2.numpy(), z["pad/two"]) and l2 == list(z["pad/two_len"])
+    o3, l3 = Padder.pad_tri([torch.ones(3, 2), 2 * torch.ones(1, 2), 3 * torch.ones(2, 2)], 0)
+    assert np.array_equal(o3.numpy(), z["pad/tri"]) and l3 == list(z["pad/tri_len"])
+    p = Pack()
+    p.add(a=1)
+    assert p.a == 1 and p.missing is None          # pack.py:7-8
+
+
+def test_noam_cer_lfr_against_reference_goldens():
+    from asr_chinese_e2e_amd.Trainer import NoamOpt
+    from asr_chinese_e2e_amd.Utils import calculate_cer
+    from asr_chinese_e2e_amd.data_handler import Vocab, build_LFR_features
+    z = load_npz("ops.npz")
+    no = NoamOpt(512, 1, 4000, None)
+    assert np.allclose([no.rate(int(s)) for s in z["noam/steps"]], z["noam/rate_512_4000"], rtol=1e-13)
+    no = NoamOpt(32, 2.0, 25, None)
+    assert np.allclose([no.rate(int(s)) for s in z["noam/steps"]], z["noam/rate_32_25_f2"], rtol=1e-13)
+    vocab = Vocab.synthetic(12)
+    vals = [calculate_cer(vocab.convert_id2str(h), vocab.convert_id2str(g)) for h, g in zip(z["cer/hyp"], z["cer/ref"])]
+    assert np.allclose(vals, z["cer/vals"])
+    for T in (1, 2, 3, 4, 7, 10, 11, 12):
+        x = np.arange(T * 3, dtype=np.float32).reshape(T, 3) + 0.5
+        assert np.array_equal(build_LFR_features(x, 4, 3), z[f"lfr/T{T}_m4n3"])
+
+
+def test_model_state_dict_matches_reference_keys_and_shapes():
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import Vocab
+    for case in ("model_small_ragged.npz", "model_small_full.npz"):
+        cfg, sd, batch, z = golden_model_case(case)
+        M = Models.TransformerOffical
+        mc = M.get_default_config()()
+        mc.fn_build({k: v for k, v in vars(cfg).items() if k != "use_decoder"})
+        model = M(mc, Vocab.synthetic(int(z["cfg/V"])))
+        mine = model.state_dict()
+        assert list(mine) == [k[3:] if k.startswith("sd/") else k[8:] for k in z.files if k.startswith(("sd/", "pe_head/"))]
+        for k, v in sd.items():
+            assert tuple(mine[k].shape) == tuple(v.shape), k
+        assert mine["decoder.tgt_word_prj.weight"].data_ptr() == mine["decoder.tgt_word_emb.weight"].data_ptr()
+        model.load_state_dict(sd)
+        assert torch.equal(model.state_dict()["encoder.linear_in.weight"], sd["encoder.linear_in.weight"])
+        assert np.allclose(mine["encoder.positional_encoding.pe"][:, :64].numpy(), z["pe_head/encoder.positional_encoding.pe"], atol=1e-6)
+
+
+def test_default_config_and_dropout_guard():
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import Vocab
+    C = Models.TransformerOffical.get_default_config()
+    c = C()
+    assert (c.d_model, c.hidden_size, c.ff_size, c.num_head, c.layer_num, c.dropout) == (512, 64, 1024, 8, 6, 0.1)
+    c.fn_build(dict(n_mels=80, lfr_m=4))
+    with pytest.raises(NotImplementedError):
+        Models.TransformerOffical(c, Vocab.synthetic(20))     # dropout 0.1 is not silently ignored
+    assert getattr(Models, "TransformerOffical") and getattr(Models, "TransformerCTC")
+
+
+def test_flat_layout_and_buckets():
+    from asr_chinese_e2e_amd import engine as E
+    from asr_chinese_e2e_amd.dist import make_buckets
+    blocks = E.mha_param_block("a.", 4, 8, 32) + E.ffn_param_block("f.", 32, 64) + [[("emb", (30, 32))]]
+    f = E.FlatParams(blocks)
+    assert all(off % E.ALIGN == 0 for off, _ in (f.index[b[0][0]] for b in blocks))
+    f.p = torch.arange(f.numel, dtype=torch.float32)
+    qkv = f.span(f.p, "a.w_qs.weight", "a.w_vs.weight", (96, 32))
+    assert torch.equal(qkv[32:64].reshape(-1), f.view(f.p, "a.w_ks.weight").reshape(-1))
+    bias = f.span(f.p, "a.w_qs.bias", "a.w_vs.bias", (96,))
+    assert bias.numel() == 96
+    for nbytes in (1, 4096, 1 << 30):
+        bk = make_buckets(f.block_range, f.numel, max(1, nbytes // 4))
+        assert bk[-1][0] == 0 and bk[0][1] == f.numel
+        assert all(bk[i][0] == bk[i + 1][1] for i in range(len(bk) - 1))      # contiguous, descending
+
+
+# ------------------------------------------------------------------------------------ DP over gloo
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from asr_chinese_e2e_amd import dist as D
+from asr_chinese_e2e_amd import engine as E
+rank, world = D.init("gloo")
+blocks = E.mha_param_block("l0.", 2, 4, 16) + E.ffn_param_block("l0f.", 16, 32) + E.mha_param_block("l1.", 2, 4, 16)
+f = E.FlatParams(blocks)
+g = torch.Generator().manual_seed(100 + rank)
+flat_g = torch.randn(f.numel, generator=g)
+mine = flat_g.clone()
+b = D.GradBucketer(flat_g, f.block_range, bucket_bytes=2048)
+assert len(b.buckets) > 2
+b.begin()
+# backward finishes gradients from the end of the buffer: report progress in that order
+marks = sorted({s for s, _ in f.block_range}, reverse=True)
+launched = []
+for m in marks[::3]:
+    b.ready(m)
+    launched.append(b.next)
+b.finish()
+assert b.next == len(b.buckets) and launched == sorted(launched)
+others = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(others, mine)
+want = sum(others)
+assert torch.allclose(flat_g, want, atol=1e-6), (flat_g - want).abs().max()
+# second iteration reuses the bucketer
+flat_g.copy_(mine); b.begin(); b.finish()
+assert torch.allclose(flat_g, want, atol=1e-6)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_grad_bucketer_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
