@@ -14,6 +14,8 @@
 //       (4 consecutive rows land on disjoint bank quarters).  The M range is split across
 //       workgroups (grid.y); partial tiles are added with fp32 atomics (full-rate shape: every
 //       wave-instruction adds two 128-byte row segments).
+#include <stdlib.h>
+
 #include "asr_common.h"
 
 namespace {
@@ -130,6 +132,161 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
                 }
             }
     }
+}
+
+
+// ------------------------------------------------------------------------- NT, LDS-DMA version
+// The projection GEMMs of this model are SHORT (K = 512 or 1024, M = 16000): one tile is a few
+// microseconds of MFMA work while a tile's fixed costs (launch, first-tile HBM latency, the store
+// tail) are of the same order, so the kernel is built to overlap them:
+//   * BM x 128 x 64 tiles (BM = 128 or 256), 4 waves (2 x 2), wave tile (BM/2) x 64 of MFMA 32x32x16;
+//   * operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging and no
+//     ds_write - the register-staged kernel above spends as many LDS cycles writing as the MFMAs
+//     take) in whole 128-byte lines (64-byte segments halve the request efficiency: measured),
+//     RING-stage ring, ONE raw s_barrier per k-step, a counted vmcnt keeps RING-2 tiles of DMA in
+//     flight across the barrier (RING = 2 relies on a second resident workgroup instead);
+//   * an LDS-DMA wave-instruction writes 1 KiB lane-linearly (8 rows of 128 B), so the bank
+//     swizzle goes on the per-lane SOURCE address (16-byte chunk c of row R lands in slot
+//     c ^ (R & 7)) and is undone on the fragment read (guide 5.4 rule 21);
+//   * fragments of k-step ks+1 are read from LDS while the MFMAs of ks issue (register double
+//     buffer: with one or two waves per SIMD nothing else hides the ds_read latency);
+//   * epilogue through LDS: bias / ReLU in registers, tile written as bf16 with a 272-byte row
+//     stride, then whole 256-byte rows stored 16 B per lane (the C^T accumulator stored straight
+//     from registers costs 32 scattered 8-byte stores per lane: more than the whole main loop);
+//   * XCD-aware tile order so the tiles that share an A row-panel run on one XCD's L2.
+// Rows past M / N are clamped on load (their results are never stored).
+constexpr int DBN = 128, DBK = 64;
+constexpr int DEPS = 272;                        // epilogue row stride (bytes)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+template <int BM_, int RING_> struct DmaCfg {
+    static constexpr int STAGE = (BM_ + DBN) * 128;                       // bytes per ring stage
+    static constexpr int EPI = BM_ * DEPS;
+    static constexpr int LDS = RING_ * STAGE > EPI ? RING_ * STAGE : EPI;
+    static constexpr int GROUPS = (BM_ + DBN) / 8;                        // 1-KiB DMA pieces per stage
+    static constexpr int PER_WAVE = GROUPS / 4;
+};
+
+template <int ACT, int BM_, int RING_, int DBG = 0>   // DBG (timing experiments only): 1 = DMA without MFMA, 2 = MFMA without DMA refills
+__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                          bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int tiles_n) {
+    using Cfg = DmaCfg<BM_, RING_>;
+    constexpr int MI = BM_ / 64;   // 32-row MFMA tiles per wave along M
+    constexpr int PW = Cfg::PER_WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem_dma[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;   // bijective XCD remap
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int m0 = tm * BM_, n0 = tn * DBN;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    // staging: GROUPS pieces of 8 rows per stage (A rows first, then W rows), PW per wave
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const bf16_t* src[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int g = w * PW + j;
+        src[j] = g < BM_ / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
+                             : W + (size_t)min(n0 + 8 * (g - BM_ / 8) + srow, N - 1) * ldb + schunk * 8;
+    }
+    auto stage = [&](int slot, int k0) {
+        char* base = smem_dma + slot * Cfg::STAGE + (w * PW) * 1024;
+#pragma unroll
+        for (int j = 0; j < PW; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + k0), (lds_void_t*)(base + j * 1024), 16, 0, 0);
+    };
+    f32x16 acc[2][MI];  // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int sw = r & 7;
+    const int a_row = (wm * (BM_ / 2) + r) * 128;            // + mi*32*128
+    const int w_row = BM_ * 128 + (wn * 64 + r) * 128;       // + ni*32*128
+    const int nk = K / DBK;
+    stage(0, 0);
+    if (RING_ > 2 && nk > 1) stage(1, DBK);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (RING_ > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's part of tile kt landed; the slot refilled next is no longer read
+        if (DBG != 2 && kt + RING_ - 1 < nk) stage(cur >= 1 ? cur - 1 : RING_ - 1, (kt + RING_ - 1) * DBK);
+        const char* sb = smem_dma + cur * Cfg::STAGE;
+        cur = cur == RING_ - 1 ? 0 : cur + 1;
+        if (DBG == 1) continue;
+        bf16x8 af[2][MI], wf[2][2];
+        auto load_frags = [&](int buf, int ks) {
+            const int coff = ((2 * ks + hh) ^ sw) << 4;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[buf][mi] = *(const bf16x8*)(sb + a_row + mi * 32 * 128 + coff);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int nl = wn * 64 + ni * 32 + 8 * g4 + 4 * hh;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b4[e] = (n0 + nl + e < N) ? bias[n0 + nl + e] : 0.f;
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * (BM_ / 2) + mi * 32 + r;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[ni][mi][4 * g4 + e] + b4[e];
+                    if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
+                    o[e] = x;
+                }
+                store4<bf16_t>((bf16_t*)(smem_dma + ml * DEPS + nl * 2), o);
+            }
+        }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < BM_ / 16; ++it) {
+        const int row = it * 16 + (tid >> 4), ch = tid & 15;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (m >= M || n >= N) continue;
+        const u32x4 v = *(const u32x4*)(smem_dma + row * DEPS + ch * 16);
+        if (n + 7 < N) {
+            *(u32x4*)(C + (size_t)m * ldc + n) = v;
+        } else {
+            const bf16_t* pv = (const bf16_t*)&v;
+            for (int e = 0; e < 8 && n + e < N; ++e) C[(size_t)m * ldc + n + e] = pv[e];
+        }
+    }
+}
+
+template <int ACT, int BM_, int RING_, int DBG>
+static void launch_nt_dma(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st) {
+    using Cfg = DmaCfg<BM_, RING_>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<ACT, BM_, RING_, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        attr = true;
+    }
+    const int t_n = ceil_div(N, DBN), t_m = ceil_div(M, BM_);
+    gemm_nt_dma_kernel<ACT, BM_, RING_, DBG><<<t_n * t_m, 256, Cfg::LDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n);
 }
 
 // ---------------------------------------------------------------------------------------- TN
@@ -249,8 +406,31 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     if (M <= 0 || N <= 0 || K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     if (K % 8 || lda % 8 || ldb % 8 || ldc % 4 || lda < K || ldb < K || ldc < N) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: K, lda, ldb must be multiples of 8 and ldc of 4 (K=%d lda=%d ldb=%d ldc=%d)", K, lda, ldb, ldc);
     if ((((uintptr_t)A | (uintptr_t)W) % 16) || ((uintptr_t)C % 8) || (res && (uintptr_t)res % 8) || (bias && (uintptr_t)bias % 16)) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: misaligned pointer");
-    const int tiles_n = ceil_div(N, BN), tiles_m = ceil_div(M, BM);
     hipStream_t st = (hipStream_t)stream;
+    if (act != ASR_ACT_RELU && act != ASR_ACT_NONE) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
+    if (K % DBK == 0 && !res && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {   // LDS-DMA kernel: whole 64-wide k-tiles, 16-B row stores
+        static const int dbg = getenv("ASR_GEMM_DBG") ? atoi(getenv("ASR_GEMM_DBG")) : 0;
+        static const int cfg = getenv("ASR_GEMM_CFG") ? atoi(getenv("ASR_GEMM_CFG")) : 0;   // tuning experiments
+        const bf16_t *a = (const bf16_t*)A, *wp = (const bf16_t*)W;
+        bf16_t* c = (bf16_t*)C;
+#define NT_DMA(BM_, RING_)                                                                                                  \
+    do {                                                                                                                     \
+        if (dbg == 1) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 1>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);                \
+        else if (dbg == 2) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 2>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);           \
+        else if (act == ASR_ACT_RELU) launch_nt_dma<ASR_ACT_RELU, BM_, RING_, 0>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st); \
+        else launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 0>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);                         \
+    } while (0)
+        // measured on config-2 shapes (tools/gemm_bench.py): 128 x 128, ring 2, two workgroups per
+        // CU is the fastest or within 3 % of it everywhere (535 / 437 / 527 / 634 / 545 TF/s)
+        if (cfg == 1) NT_DMA(256, 3);
+        else if (cfg == 2) NT_DMA(128, 3);
+        else if (cfg == 3) NT_DMA(256, 2);
+        else NT_DMA(128, 2);
+#undef NT_DMA
+        ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
+        return ASR_OK;
+    }
+    const int tiles_n = ceil_div(N, BN), tiles_m = ceil_div(M, BM);
     if (act == ASR_ACT_RELU)
         gemm_nt_kernel<ASR_ACT_RELU><<<tiles_n * tiles_m, 256, 0, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldb, ldc, tiles_n);
     else if (act == ASR_ACT_NONE)

@@ -156,26 +156,37 @@ __global__ __launch_bounds__(256) void sdpa_fwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sub, ks, lane), qf[ks], st[sub], 0, 0, 0);
         }
+        // The kernel is VALU-bound (dk = 64: 16 MFMAs vs ~32 softmax elements per lane and tile), so
+        // the per-element work is kept to max / fma / exp2 / add: tiles that lie wholly inside every
+        // mask skip the visibility test (wave-uniform branch), the 1/sqrt(dk)*log2(e) scale is folded
+        // into one fma with the running maximum, and exp2 is the bare v_exp_f32.
+        const bool need_mask = (k0 + TILE > klen) || (causal && k0 + TILE - 1 > q0) ||
+                               (window >= 0 && (k0 + TILE - 1 - q0 > window || q0 + 31 - k0 > window));
+        if (need_mask) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kj = k0 + 32 * sub + acc_row(i, lane);
+                    if (!visible(qi, kj, klen, causal, window)) st[sub][i] = -INFINITY;
+                }
+        }
         float tmax = M_INIT;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kj = k0 + 32 * sub + acc_row(i, lane);
-                const float s2 = visible(qi, kj, klen, causal, window) ? st[sub][i] * sc2 : -INFINITY;
-                st[sub][i] = s2;
-                tmax = fmaxf(tmax, s2);
-            }
+            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, st[sub][i]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mn);
+        const float mn = fmaxf(m, tmax);                       // running maximum in raw-score units
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * sc2);
         m = mn;
+        const float mc = mn * sc2;
         float psum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = exp2f(st[sub][i] - mn);
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[sub][i], sc2, -mc));
                 st[sub][i] = p;
                 psum += p;
             }
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256) void sdpa_fwd_bf16_kernel(const bf16_t* __rest
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.f / l : 0.f;
     store_rows_T(oacc, inv, o + (size_t)b * Tq * ldo + h * DK, ldo, q0, Tq, lane);
-    if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m + log2f(l)) * LN2 : -INFINITY;
+    if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m * sc2 + log2f(l)) * LN2 : -INFINITY;
 }
 
 // delta[b,h,q] = sum_d dO * O   (one wave per 8 rows x 8 lanes... simple: one thread-group of 8 lanes per (row, head))
@@ -267,10 +278,16 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __r
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Kt, 32 * sub, ks, lane), qf[ks], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Vt, 32 * sub, ks, lane), dof[ks], dp, 0, 0, 0);
             }
+            const int ks0 = k0 + 32 * sub;
+            const bool need_mask = (ks0 + 32 > klen) || (causal && ks0 + 31 > q0) || (window >= 0 && (ks0 + 31 - q0 > window || q0 + 31 - ks0 > window));
+            if (need_mask) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (!visible(qi, ks0 + acc_row(i, lane), klen, causal, window)) st[i] = -INFINITY;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int kj = k0 + 32 * sub + acc_row(i, lane);
-                const float p = visible(qi, kj, klen, causal, window) ? exp2f(st[i] * sc2 - lse2) : 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[i], sc2, -lse2));
                 st[i] = p * (dp[i] - dl) * scale;  // dS^T
             }
 #pragma unroll
@@ -346,6 +363,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Dt, 32 * sub, ks, lane), vf[ks], dp, 0, 0, 0);
             }
             f32x16 ds;
+            const int qs0 = q0 + 32 * sub;   // wave-uniform: does this 32x32 sub-tile touch any mask edge?
+            const bool need_mask = (kk0 + 32 > klen) || (causal && kk0 + 31 > qs0) || (window >= 0 && (kk0 + 31 - qs0 > window || qs0 + 31 - kk0 > window));
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int r0 = 32 * sub + 8 * g4 + 4 * (lane >> 5);
@@ -354,8 +373,9 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g4 + e;
-                    const int qi = q0 + r0 + e;
-                    const float p = visible(qi, kj, klen, causal, window) ? exp2f(st[i] * sc2 - l4[e]) : 0.f;
+                    float sv = st[i];
+                    if (need_mask && !visible(q0 + r0 + e, kj, klen, causal, window)) sv = -INFINITY;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sv, sc2, -l4[e]));
                     st[i] = p;
                     ds[i] = p * (dp[i] - d4[e]) * scale;
                 }

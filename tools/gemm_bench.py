@@ -1,0 +1,51 @@
+"""Micro-benchmark of the hand-written MFMA GEMMs against the library GEMM on the config-2 shapes.
+python tools/gemm_bench.py [nt|tn|nn|all]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from asr_chinese_e2e_amd import kernels as K
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+M = 16000
+SHAPES = [(1536, 512, "qkv"), (512, 512, "fc"), (1024, 512, "w1"), (512, 1024, "w2"), (4232, 512, "ctc_lo")]
+
+
+def timeit(fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+torch.manual_seed(0)
+for N, Kd, name in SHAPES:
+    x = torch.randn(M, Kd, device="cuda").bfloat16()
+    w = (torch.randn(N, Kd, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda")
+    dy = torch.randn(M, N, device="cuda").bfloat16()
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    dw = torch.zeros(N, Kd, device="cuda")
+    dx = torch.empty(M, Kd, device="cuda", dtype=torch.bfloat16)
+    fl = 2.0 * M * N * Kd
+    line = f"{name:7s} N={N:5d} K={Kd:5d}"
+    if which in ("nt", "all"):
+        t = timeit(lambda: K.gemm_nt(x, w, b, out))
+        tl = timeit(lambda: torch.addmm(b.bfloat16(), x, w.t(), out=out))
+        line += f" | NT mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s  lib {tl:7.1f} us {fl / tl / 1e6:6.0f} TF/s"
+    if which in ("tn", "all"):
+        t = timeit(lambda: K.gemm_tn(dy, x, dw, accumulate=True))
+        tl = timeit(lambda: torch.mm(dy.t(), x))
+        line += f" | TN mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s  lib {tl:7.1f} us {fl / tl / 1e6:6.0f} TF/s"
+    if which in ("nn", "all"):
+        tl = timeit(lambda: torch.mm(dy, w, out=dx))
+        line += f" | NN lib {tl:7.1f} us {fl / tl / 1e6:6.0f} TF/s"
+        if hasattr(K, "gemm_nn"):
+            t = timeit(lambda: K.gemm_nn(dy, w, dx))
+            line += f"  mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s"
+    print(line, flush=True)
