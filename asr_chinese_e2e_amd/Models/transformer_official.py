@@ -148,6 +148,8 @@ class _SpeechTransformer(BaseModel):
         """(Re)build the flat HBM buffers when the parameters are not views of them (first call,
         after .cuda()/.to(), after load_state_dict on a fresh module)."""
         device = torch.device(device)
+        if device.type == "cuda" and device.index is None:   # "cuda" and "cuda:0" must compare equal below
+            device = torch.device("cuda", torch.cuda.current_device())
         if device.type != "cuda":
             raise RuntimeError("the HIP engine runs on an MI355X only: move the model and batch to 'cuda' "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
@@ -162,7 +164,11 @@ class _SpeechTransformer(BaseModel):
         if ok:
             return self._engine
         old = {name: p.detach().to(device=device, dtype=torch.float32) for name, p in self._named_flat_params()}
+        old_mv = (f.m.to(device), f.v.to(device)) if f.m is not None else None   # keep Adam state across a device move
         f.allocate(device, self.lowp)
+        if old_mv is not None:
+            f.m.copy_(old_mv[0])
+            f.v.copy_(old_mv[1])
         for name, p in self._named_flat_params():
             view = f.view(f.p, name)
             view.copy_(old[name].view(view.shape))

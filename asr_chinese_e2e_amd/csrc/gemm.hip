@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int rows, int c
 
 static int tn_splits(int M, int N, int K) {
     const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
-    int s = ceil_div(512, tiles);            // aim at ~512 workgroups
+    int s = ceil_div(256, tiles);            // ~one workgroup per CU: every extra split adds N*K*4 B of atomics
     const int max_s = ceil_div(M, 4 * TM);   // at least 4 reduction tiles per workgroup
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;

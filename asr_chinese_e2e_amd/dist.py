@@ -10,8 +10,8 @@ MI355X-first design:
     them from the END of the buffer towards the start, so buckets are contiguous slices - no
     gather/scatter copies, no per-parameter hooks;
   * the engine reports progress ("gradients at offsets >= o are final"); every bucket that lies
-    wholly above the mark is all-reduced on a high-priority side stream while backward continues;
-  * xGMI is point-to-point (7 links per GPU): a few large buckets (default 32 MB) keep each
+    wholly above the mark is all-reduced on a separate communication stream while backward continues;
+  * xGMI is point-to-point (7 links per GPU): a few large buckets (default 16 MB) keep each
     transfer bandwidth-bound rather than latency-bound;
   * the loss normalisers are made global BEFORE backward (token count all-reduced, CTC divided by
     the global batch), so the summed gradients equal a single-process run on the concatenated
@@ -63,7 +63,10 @@ class GradBucketer:
         self.group = group
         self.buckets = make_buckets(block_ranges, flat_g.numel(), max(1, bucket_bytes // flat_g.element_size()))
         self.cuda = flat_g.is_cuda
-        self.comm_stream = torch.cuda.Stream(priority=-1) if self.cuda else None
+        # NORMAL priority: a high-priority HIP stream (priority=-1) next to the two compute streams
+        # doubled the step time on MI355X / ROCm 7 (11.0 vs 5.2 ms, measured with one rank)
+        prio = int(os.environ.get("ASR_COMM_PRIORITY", "0"))
+        self.comm_stream = torch.cuda.Stream(priority=prio) if self.cuda else None
         self.next = 0
         self.works = []
 
@@ -71,22 +74,24 @@ class GradBucketer:
         self.next = 0
         self.works = []
 
-    def _launch(self, i):
+    def _launch(self, i, streams=None):
         s, e = self.buckets[i]
         view = self.g[s:e]
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
+            for st in (streams or [torch.cuda.current_stream()]):   # producers of these gradients
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def ready(self, offset):
-        """Gradients at flat offsets >= offset are final: launch every bucket fully above it."""
+    def ready(self, offset, streams=None):
+        """Gradients at flat offsets >= offset are final (after the work already queued on
+        `streams`): launch every bucket that lies fully above the mark."""
         while self.next < len(self.buckets) and self.buckets[self.next][0] >= offset:
-            self._launch(self.next)
+            self._launch(self.next, streams)
             self.next += 1
 
     def finish(self):
@@ -100,8 +105,9 @@ class GradBucketer:
 class DataParallel:
     """Wraps a model built on engine.FlatParams; `iterate` has the reference's signature."""
 
-    def __init__(self, model, device, bucket_bytes=32 << 20):
+    def __init__(self, model, device, bucket_bytes=16 << 20, reduce_loss=False):
         self.model = model
+        self.reduce_loss = reduce_loss
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         eng = model._ensure_engine(device)
         flat = model._flat
@@ -123,9 +129,15 @@ class DataParallel:
         model.zero_flat_grads()
         self.bucketer.begin()
         B = input.wave.shape[0]
-        loss, _ = model.train_step(input, n_valid_override=self._global_count, ctc_batch=B * self.world)
+        # the token count only normalises the CE term: the CTC-only model needs no count exchange
+        loss, _ = model.train_step(input, n_valid_override=self._global_count if model.use_decoder else None,
+                                   ctc_batch=B * self.world)
         self.bucketer.finish()
         optimizer.fused_step(model._flat, CLIP_NORM)
+        if not self.reduce_loss:      # rank-local loss estimate (no extra collective per step)
+            metrics = Pack()
+            metrics.add(loss=loss[0])
+            return metrics, None
         # CE was normalised by the GLOBAL token count (sum over ranks = global CE); the CTC term
         # reported by the kernel is per local batch (mean over ranks = global CTC)
         dist.all_reduce(loss, op=dist.ReduceOp.SUM)

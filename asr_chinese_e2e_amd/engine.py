@@ -216,6 +216,7 @@ class Engine:
         self.dtype = torch.bfloat16 if flat.lp is not None else torch.float32
         self.pe = pe  # (>=maxlen, d) f32 on device
         self.ws = K.Workspace(flat.device)
+        self.ws_side = K.Workspace(flat.device)   # scratch of the kernels issued on the side stream
         self.lin_in = Linear(flat, ["encoder.linear_in.weight"], ["encoder.linear_in.bias"], d, self.d_in)
         self.ln_in = LayerNormP(flat, "encoder.layer_norm_in")
         self.enc = [(MHA(flat, f"encoder.layer_stack.{i}.slf_attn.", H, dk, d), FFN(flat, f"encoder.layer_stack.{i}.pos_ffn.", d, ff))
@@ -229,11 +230,41 @@ class Engine:
         if use_ctc:
             self.ctc_lo = Linear(flat, ["ctc_lo.weight"], ["ctc_lo.bias"], vocab_size, d)
         self.grad_ready = None  # callback(offset): gradients at flat offsets >= offset are final
+        # Weight/bias gradients are off the critical path (only the optimizer reads them): they run
+        # on a side stream, concurrently with the dgrad chain on the main stream, so the short,
+        # latency-bound kernels of both chains fill each other's idle CUs.
+        self.side = torch.cuda.Stream(device=flat.device)
+        self.overlap_wgrad = True
 
     # ------------------------------------------------------------------ helpers
     def _ready(self, name):
+        """Gradients at flat offsets >= this tensor's offset are final once the work queued so far
+        on BOTH streams has run: the consumer (dist.GradBucketer) waits on events of the two."""
         if self.grad_ready is not None:
-            self.grad_ready(self.flat.index[name][0])
+            streams = [torch.cuda.current_stream()] + ([self.side] if self.overlap_wgrad else [])
+            self.grad_ready(self.flat.index[name][0], streams)
+
+    def join_side(self):
+        """Main stream waits for every weight-gradient kernel issued so far."""
+        if self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def _wgrad(self, lin, dy, x, bias_from=None):
+        """lin.gw += dy^T x (and lin.gb += colsum(bias_from)) on the side stream."""
+        if not self.overlap_wgrad:
+            if bias_from is not None:
+                lin.bgrad(bias_from, self.ws_side)
+            lin.wgrad(dy, x)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            if bias_from is not None:
+                lin.bgrad(bias_from, self.ws_side)
+            lin.wgrad(dy, x)
+        for t in (dy, x):
+            t.record_stream(self.side)
 
     def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross):
         """x: (B*Tq, d) queries + residual; kv_src: (B*Tk, d).  Returns output and cache."""
@@ -262,15 +293,14 @@ class Engine:
         H, dk, hd = self.H, self.dk, self.H * self.dk
         B, Tq, Tk = c["dims"]
         dz = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], m.ln.g, c["q_lens"], m.ln.gg, m.ln.gb, m.fc.gb, B, Tq, self.ws)
-        m.fc.wgrad(dz, c["ctx"])
+        self._wgrad(m.fc, dz, c["ctx"])
         dctx = m.fc.dgrad(dz)
         if not c["cross"]:
             qkv = c["qkv"]
             dqkv = torch.empty_like(qkv)
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
                        dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"])
-            m.qkv.bgrad(dqkv, self.ws)
-            m.qkv.wgrad(dqkv, c["x"])
+            self._wgrad(m.qkv, dqkv, c["x"], bias_from=dqkv)
             dx = m.qkv.dgrad(dqkv)
         else:
             q, kv = c["q"], c["kv"]
@@ -278,10 +308,8 @@ class Engine:
             dkv = torch.empty_like(kv)
             K.sdpa_bwd(q, kv[:, :hd], kv[:, hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk, dq, dkv[:, :hd], dkv[:, hd:],
                        c["causal"], c["window"])
-            m.q.bgrad(dq, self.ws)
-            m.kv.bgrad(dkv, self.ws)
-            m.q.wgrad(dq, c["x"])
-            m.kv.wgrad(dkv, c["kv_src"])
+            self._wgrad(m.q, dq, c["x"], bias_from=dq)
+            self._wgrad(m.kv, dkv, c["kv_src"], bias_from=dkv)
             dx = m.q.dgrad(dq)
             m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
         return dx, dz
@@ -295,10 +323,10 @@ class Engine:
     def _ffn_block_bwd(self, f, c, dy, dy2):
         B, T = c["dims"]
         dz = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], f.ln.g, c["lens"], f.ln.gg, f.ln.gb, f.w2.gb, B, T, self.ws)
-        f.w2.wgrad(dz, c["h"])
+        self._wgrad(f.w2, dz, c["h"])
         dh = f.w2.dgrad(dz)
         K.relu_bwd_(dh, c["h"], f.w1.gb, self.ws)
-        f.w1.wgrad(dh, c["x"])
+        self._wgrad(f.w1, dh, c["x"])
         dx = f.w1.dgrad(dh)
         return dx, dz
 
@@ -327,7 +355,8 @@ class Engine:
             dy, dy2 = dx, dz
             self._ready(f"encoder.layer_stack.{i}.slf_attn.w_qs.weight")
         dz = K.add_ln_bwd(dy, dy2, cache["xhat_in"], cache["rstd_in"], self.ln_in.g, None, self.ln_in.gg, self.ln_in.gb, self.lin_in.gb, B, T, self.ws)
-        self.lin_in.wgrad(dz, cache["x_in"])
+        self._wgrad(self.lin_in, dz, cache["x_in"])
+        self.join_side()
         self._ready("encoder.linear_in.weight")
 
     # ------------------------------------------------------------------ CTC head
@@ -339,8 +368,7 @@ class Engine:
         if not want_grad:
             return nll, None
         dl = dl.view(B * T, self.V)
-        self.ctc_lo.bgrad(dl, self.ws)
-        self.ctc_lo.wgrad(dl, enc)
+        self._wgrad(self.ctc_lo, dl, enc, bias_from=dl)
         d_enc = self.ctc_lo.dgrad(dl)
         self._ready("ctc_lo.weight")
         return nll, d_enc
@@ -363,7 +391,7 @@ class Engine:
 
     def decoder_bwd(self, cache, dpred, d_enc):
         """dpred (B*To, V); accumulates the encoder-output gradient into d_enc (B*T, d) in place."""
-        self.prj.wgrad(dpred, cache["x_last"])
+        self._wgrad(self.prj, dpred, cache["x_last"])
         dy, dy2 = self.prj.dgrad(dpred), None
         for i in reversed(range(self.L)):
             slf, cross, ffn = self.dec[i]

@@ -1,0 +1,132 @@
+"""Trainer loop, checkpoint round trip, evaluation path and the RCCL data-parallel wrapper (one
+rank) on the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from tests.helpers import ROOT  # noqa: E402
+
+
+def small_model(ctc_weight=0.3, cls="TransformerOffical", seed=0):
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import Vocab
+    torch.manual_seed(seed)
+    M = getattr(Models, cls)
+    cfg = M.get_default_config()()
+    cfg.fn_build(dict(n_mels=16, lfr_m=1, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=2, dropout=0.0,
+                      ctc_weight=ctc_weight, dtype="fp32", num_epoch=2, warm_up=10))
+    return M(cfg, Vocab.synthetic(40)), cfg
+
+
+def batches(n, seed=0):
+    from asr_chinese_e2e_amd.data_handler import synthetic_pack
+    return [synthetic_pack(4, 24, 16, 40, seed=seed + i, ragged=True, Lmin=2, Lmax=6, device="cuda") for i in range(n)]
+
+
+def test_trainer_checkpoint_and_eval(tmp_path):
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt, Trainer11
+    model, cfg = small_model()
+    model = model.cuda()
+    opt = NoamOpt(cfg.d_model, 1, cfg.warm_up, FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+    data = batches(3)
+    tr = Trainer11(opt, model, data, dev_iter=data[:1], test_iter=data[:1], ckpt_root=str(tmp_path), exp_name="exp", log_every_iter=1,
+                   eval_every_iter=2, save_every_iter=3)
+    tr.train()                                   # 2 epochs x 3 steps
+    assert tr.global_step == 6 and opt._step == 6
+    tags = {h["tag"] for h in tr.history}
+    assert {"lr", "train/loss", "dev/loss", "test/loss", "train/utt_per_s"} <= tags
+    losses = [h["value"] for h in tr.history if h["tag"] == "train/loss"]
+    assert all(np.isfinite(losses))
+    # files named like the reference (trainer11.py:93-99)
+    assert os.path.isfile(tmp_path / "exp" / "e1_s6.model") and os.path.isfile(tmp_path / "exp" / "e1_s6.opt")
+    # resume: a fresh model + optimizer loaded from the checkpoint continues identically
+    m2, _ = small_model(seed=1)
+    m2 = m2.cuda()
+    o2 = NoamOpt(cfg.d_model, 1, cfg.warm_up, FusedAdam(m2.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+    m2._ensure_engine("cuda")
+    t2 = Trainer11(o2, m2, data, ckpt_root=str(tmp_path), exp_name="exp2")
+    t2.ckpt_root = str(tmp_path)
+    t2.load_from_ckpt("exp", 1, 6)
+    assert o2._step == 6 and abs(o2._rate - opt._rate) < 1e-15
+    for (n, a), (_, b) in zip(model.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), n
+    ma, _ = model.iterate(data[0], optimizer=opt)
+    mb, _ = m2.iterate(data[0], optimizer=o2)
+    assert abs(float(ma.loss) - float(mb.loss)) < 1e-6 * abs(float(ma.loss))
+    # float atomics (embedding scatter-add) make the last bits run-dependent, and Adam turns the
+    # round-off of ~zero gradients into +-lr: bound by a few lr, and require the bulk to agree
+    for (n, a), (_, b) in zip(model.named_parameters(), m2.named_parameters()):
+        d = (a - b).abs()
+        assert float(d.max()) <= 3 * opt._rate, n
+        assert float((d > 1e-6 + 1e-5 * b.abs()).float().mean()) < 0.05, n
+    # evaluation path returns loss and cer without touching the weights
+    before = model._flat.p.clone()
+    ev, _ = model.iterate(data[1], is_train=False)
+    assert np.isfinite(float(ev.loss)) and 0 <= float(ev.cer)
+    assert torch.equal(before, model._flat.p)
+
+
+def test_any_torch_optimizer_still_works():
+    """The model also drives a stock torch.optim.Adam under the reference's NoamOpt semantics."""
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+    data = batches(1)[0]
+    ref_model, cfg = small_model(seed=3)
+    ref_model = ref_model.cuda()
+    ref_model._ensure_engine("cuda")
+    sd = {k: v.clone() for k, v in ref_model.state_dict().items()}
+    o1 = NoamOpt(cfg.d_model, 1, 10, FusedAdam(ref_model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+    ref_model.iterate(data, optimizer=o1)
+    m2, _ = small_model(seed=4)
+    m2 = m2.cuda()
+    m2.load_state_dict(sd)
+    o2 = NoamOpt(cfg.d_model, 1, 10, torch.optim.Adam(m2.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+    m2.iterate(data, optimizer=o2)
+    for (n, a), (_, b) in zip(ref_model.named_parameters(), m2.named_parameters()):
+        if not n.endswith("w_ks.bias"):
+            assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), n
+
+
+DP_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from asr_chinese_e2e_amd import Models, dist as D
+from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+rank, world = D.init("nccl")
+def build():
+    torch.manual_seed(0)
+    M = Models.TransformerOffical
+    cfg = M.get_default_config()()
+    cfg.fn_build(dict(n_mels=16, lfr_m=1, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=2, dropout=0.0, ctc_weight=0.3, dtype="fp32"))
+    m = M(cfg, Vocab.synthetic(40)).cuda()
+    return m, NoamOpt(64, 1, 10, FusedAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+pack = synthetic_pack(4, 24, 16, 40, seed=5, ragged=True, Lmin=2, Lmax=6, device="cuda")
+m1, o1 = build()
+m2, o2 = build()
+dp = D.DataParallel(m2, "cuda", bucket_bytes=64 << 10, reduce_loss=True)
+assert len(dp.bucketer.buckets) > 3
+for _ in range(3):
+    a, _ = m1.iterate(pack, optimizer=o1)
+    b, _ = dp.iterate(pack, optimizer=o2)
+    assert abs(float(a.loss) - float(b.loss)) < 1e-5 * abs(float(a.loss)), (float(a.loss), float(b.loss))
+for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+    assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), n
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+print("dp ok")
+"""
+
+
+def test_data_parallel_wrapper_one_rank_rccl(tmp_path):
+    """world_size 1 over the nccl (= RCCL) backend: the bucketed all-reduce path, global loss
+    normalisers and fused step give the same trajectory as the plain model."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "dp ok" in p.stdout
