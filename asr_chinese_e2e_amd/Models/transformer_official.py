@@ -60,10 +60,7 @@ class _SpeechTransformer(BaseModel):
         self.lowp = str(getattr(c, "dtype", "bf16")).lower() in ("bf16", "bfloat16")
         self.attn_window = int(getattr(c, "attn_window", -1))
         self.cer_in_iterate = bool(getattr(c, "cer_in_iterate", True))
-        if float(getattr(c, "dropout", 0.0)) != 0.0 and not getattr(c, "allow_dropout_ignored", False):
-            # dropout sites of the reference: transformer_official.py:175, 306; attention.py:59, 83; module.py:73
-            raise NotImplementedError("dropout > 0 is not implemented in the HIP engine yet: pass dropout=0.0 "
-                                      "(or allow_dropout_ignored=True to run without it)")
+        self._step_seed = int(getattr(c, "seed", 0))   # advanced once per training step (dropout masks)
         d, H, dk, ff = c.d_model, c.num_head, c.hidden_size, c.ff_size
         d_in = c.n_mels * c.lfr_m
         V = vocab.vocab_size
@@ -197,9 +194,13 @@ class _SpeechTransformer(BaseModel):
                 p.grad = f.view(f.g, name)
 
     # ------------------------------------------------------------------ reference API
-    def _prepare(self, input):
+    def _prepare(self, input, training=False):
         wave = input.wave
         eng = self._ensure_engine(wave.device)
+        eng.training = bool(training)
+        if training:
+            self._step_seed = (self._step_seed + 1) & 0x7FFFFFFF
+            eng.step_seed = self._step_seed
         x = wave if wave.dtype == eng.dtype else wave.to(eng.dtype)
         x = x.contiguous()
         wave_len = input.wave_len.to(torch.int32)
@@ -255,7 +256,7 @@ class _SpeechTransformer(BaseModel):
     def train_step(self, input, loss_scale=1.0, n_valid_override=None, ctc_batch=None):
         """Forward + backward into the flat gradient buffer (no optimizer).  Returns the metrics
         tensor [loss, ce, ctc] (device) and, for CER, (pred, gold) or None."""
-        eng, x, wave_len, prep = self._prepare(input)
+        eng, x, wave_len, prep = self._prepare(input, training=self.training)
         B, T, _ = x.shape
         lam = self.ctc_weight
         enc, ecache = eng.encoder_fwd(x, wave_len, self.attn_window)

@@ -6,7 +6,7 @@ import of the product path fails loudly.  Build it with
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p
 
 # torch must be imported BEFORE the extension is dlopen'ed: libasr_hip.so then binds to the HIP
 # runtime instance torch has already loaded, so stream handles and device pointers are shared.
@@ -18,25 +18,28 @@ LIB_PATH = os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
+DROP_PRE, DROP_POST = 1, 2
 
-P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
 
 # name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
 SIGNATURES = {
     "asr_abi_version": (I, []),
     "asr_last_error": (I, [c_char_p, Z]),
-    "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, U, I, I, P]),
     "asr_add_ln_bwd_workspace_bytes": (Z, [I, I]),
-    "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, I, P]),
-    "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
-    "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
+    "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, F, U, I, I, P]),
+    "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
+    "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
+    "asr_dropout_mask": (I, [P, I, I, F, U, P]),
+    "asr_sdpa_dropout_mask": (I, [P, I, I, I, I, F, U, P]),
     "asr_ctc_workspace_bytes": (Z, [I, I, I]),
     "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, P, Z, I, P]),
     "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),
     "asr_dec_preprocess": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
-    "asr_embed_pe_fwd": (I, [P, P, P, P, F, I, I, I, I, I, P]),
-    "asr_embed_bwd": (I, [P, P, P, F, I, I, I, I, P]),
+    "asr_embed_pe_fwd": (I, [P, P, P, P, F, I, I, I, I, F, U, I, P]),
+    "asr_embed_bwd": (I, [P, P, P, F, I, I, I, F, U, I, P]),
     "asr_relu_fwd": (I, [P, Z, I, P]),
     "asr_relu_bwd": (I, [P, P, P, P, Z, I, I, I, P]),
     "asr_colsum_workspace_bytes": (Z, [I, I]),

@@ -143,5 +143,30 @@ static __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const floa
     }
 }
 
+// ---- dropout: counter-based keep mask ---------------------------------------------------------
+// One 32-bit hash per PAIR of adjacent elements (low / high 16 bits), keyed by (pair index, seed):
+// forward and backward regenerate identical masks, nothing is stored.  keep <=> 16 bits >= p*65536.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t pair, uint32_t seed) {
+    uint32_t h = pair * 0x9E3779B1u ^ seed;
+    h ^= h >> 15; h *= 0x85EBCA77u;
+    h ^= h >> 13; h *= 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t h, int half, uint32_t thr16) { return ((h >> (16 * half)) & 0xffffu) >= thr16; }
+__device__ __forceinline__ bool drop_keep_at(uint32_t elem, uint32_t seed, uint32_t thr16) {
+    return drop_keep(drop_hash(elem >> 1, seed), elem & 1, thr16);
+}
+static inline uint32_t drop_thr16(float p) { return p <= 0.f ? 0u : (uint32_t)(p * 65536.f + 0.5f); }
+
+// XCD-aware workgroup order (guide T1).  Workgroups are dealt round-robin over the 8 XCDs (each
+// with a private L2), so consecutive linear ids land on different L2s.  This maps the hardware id
+// to a virtual id such that each XCD owns a contiguous run of virtual ids: workgroups that share
+// operand panels are given consecutive virtual ids and then hit one L2.  Bijective for any size.
+__device__ __forceinline__ int xcd_virtual_id(int id, int nwg) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7, idx = id >> 3;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

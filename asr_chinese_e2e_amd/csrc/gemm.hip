@@ -319,14 +319,19 @@ __device__ __forceinline__ bf16x8 tn_frag(const bf16_t* tile, int col0, int s, i
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N, int K,
-                                                      int ldy, int ldx, int ldw, int tiles_k, int rows_per_split, int use_atomic) {
+                                                      int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split, int use_atomic) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TM * TSW];
     bf16_t* Ys = smem;
     bf16_t* Xs = smem + TM * TSW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tk = blockIdx.x % tiles_k, tn = blockIdx.x / tiles_k;
+    // 1-D grid, XCD-aware: all output tiles of one M-split read the same dY / X rows, so a split's
+    // tiles get consecutive virtual ids (one XCD's L2 then serves the re-reads)
+    const int ntiles = tiles_k * tiles_n;
+    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    const int split = vid / ntiles, tile = vid - split * ntiles;
+    const int tk = tile % tiles_k, tn = tile / tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
-    const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
     const int wn = w >> 1, wk = w & 1;
     f32x16 acc[2][2];  // [ni][ki]
 #pragma unroll
@@ -464,8 +469,7 @@ extern "C" int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M,
         int g = (int)((total + 255) / 256);
         zero_f32_kernel<<<g < 1024 ? g : 1024, 256, 0, st>>>(dW, N, K, ldw);
     }
-    dim3 grid(tiles_n * tiles_k, nsplit);
-    gemm_tn_kernel<<<grid, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, rows_per_split, use_atomic);
+    gemm_tn_kernel<<<tiles_n * tiles_k * nsplit, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic);
     ASR_CHECK_LAUNCH("asr_gemm_tn_bf16");
     return ASR_OK;
 }

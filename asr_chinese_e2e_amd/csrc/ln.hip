@@ -24,6 +24,15 @@ template <typename T, int N, bool VEC8> struct RowSlice {
             }
         }
     }
+    static __device__ __forceinline__ int col(int i, int lane) {
+        if constexpr (VEC8) return (i >> 3) * 512 + lane * 8 + (i & 7);
+        else return i * 64 + lane;
+    }
+    // v[i] = keep(row, col) ? v[i] * scale : 0   (dropout mask regenerated from the counter hash)
+    static __device__ __forceinline__ void dropout(float (&v)[N], uint32_t row_base, int lane, uint32_t seed, uint32_t thr, float scale) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = drop_keep_at(row_base + (uint32_t)col(i, lane), seed, thr) ? v[i] * scale : 0.f;
+    }
     static __device__ __forceinline__ void loadf(const float* p, int d, int lane, float (&v)[N]) {
         RowSlice<float, N, VEC8>::load(p, d, lane, v);
     }
@@ -44,11 +53,14 @@ template <typename T, int N, bool VEC8> struct RowSlice {
     }
 };
 
-template <typename T, int N, bool VEC8>
+// DROP: 0 = none, 1 = dropout on x before the residual add (attention.py:59, module.py:73),
+//       2 = dropout on the output after the PE add (transformer_official.py:175-177)
+template <typename T, int N, bool VEC8, int DROP>
 __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ pe, const int32_t* __restrict__ lens,
-    T* __restrict__ y, T* __restrict__ xhat, float* __restrict__ rstd_out, int rows, int T_, int d) {
+    T* __restrict__ y, T* __restrict__ xhat, float* __restrict__ rstd_out, int rows, int T_, int d,
+    uint32_t seed, uint32_t thr, float dscale) {
     using RS = RowSlice<T, N, VEC8>;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float g[N], bt[N];
@@ -59,6 +71,7 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
         const int b = row / T_, t = row - b * T_;
         float z[N];
         RS::load(x + (size_t)row * d, d, lane, z);
+        if constexpr (DROP == 1) RS::dropout(z, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
         if (res) {
             float r[N];
             RS::load(res + (size_t)row * d, d, lane, r);
@@ -92,6 +105,7 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < N; ++i) out[i] += p[i];
         }
+        if constexpr (DROP == 2) RS::dropout(out, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
         if (!keep) {
 #pragma unroll
             for (int i = 0; i < N; ++i) out[i] = 0.f;
@@ -103,12 +117,12 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
 }
 
 // partial column sums land in ws as [blockIdx][3][d] f32 (the 4 waves are combined through LDS)
-template <typename T, int N, bool VEC8>
+template <typename T, int N, bool VEC8, int DROP>
 __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ xhat,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-    const int32_t* __restrict__ lens, T* __restrict__ dz, float* __restrict__ ws, int rows, int T_,
-    int d) {
+    const int32_t* __restrict__ lens, T* __restrict__ dz, T* __restrict__ dx, float* __restrict__ ws, int rows, int T_,
+    int d, uint32_t seed, uint32_t thr, float dscale) {
     using RS = RowSlice<T, N, VEC8>;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float g[N], acc_g[N], acc_b[N], acc_z[N];
@@ -129,6 +143,7 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
 #pragma unroll
                 for (int i = 0; i < N; ++i) gy[i] += e[i];
             }
+            if constexpr (DROP == 2) RS::dropout(gy, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
             RS::load(xhat + (size_t)row * d, d, lane, xh);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -146,13 +161,19 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
             for (int i = 0; i < N; ++i) {
                 o[i] = rstd * (gy[i] - s1 - xh[i] * s2);
                 if constexpr (!VEC8) o[i] = (i * 64 + lane < d) ? o[i] : 0.f;
-                acc_z[i] += o[i];
+                if constexpr (DROP != 1) acc_z[i] += o[i];
             }
         } else {
 #pragma unroll
             for (int i = 0; i < N; ++i) o[i] = 0.f;
         }
         RS::store(dz + (size_t)row * d, d, lane, o);
+        if constexpr (DROP == 1) {   // gradient wrt the pre-dropout GEMM output (and its bias)
+            RS::dropout(o, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc_z[i] += o[i];
+            RS::store(dx + (size_t)row * d, d, lane, o);
+        }
     }
     __shared__ __attribute__((aligned(16))) float sred[LN_WAVES][2048];
     float* slot = ws + (size_t)blockIdx.x * 3 * d;
@@ -176,14 +197,14 @@ extern "C" size_t asr_add_ln_bwd_workspace_bytes(int rows, int d) {
     return (size_t)ln_grid(rows) * 3 * d * sizeof(float);
 }
 
-template <typename T>
+template <typename T, int DROP>
 static int launch_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                          const float* pe, const int32_t* lens, void* y, void* xhat, float* rstd,
-                         int rows, int T_, int d, hipStream_t st) {
+                         int rows, int T_, int d, uint32_t seed, uint32_t thr, float dscale, hipStream_t st) {
     const int grid = ln_grid(rows);
 #define LN_FWD(N, V)                                                                              \
-    add_ln_fwd_kernel<T, N, V><<<grid, LN_WAVES * WAVE, 0, st>>>(                                  \
-        (const T*)x, (const T*)res, gamma, beta, pe, lens, (T*)y, (T*)xhat, rstd, rows, T_, d)
+    add_ln_fwd_kernel<T, N, V, DROP><<<grid, LN_WAVES * WAVE, 0, st>>>(                            \
+        (const T*)x, (const T*)res, gamma, beta, pe, lens, (T*)y, (T*)xhat, rstd, rows, T_, d, seed, thr, dscale)
     if (d % 512 == 0 && d <= 2048) {
         switch (d / 512) {
             case 1: LN_FWD(8, true); break;
@@ -206,25 +227,33 @@ static int launch_ln_fwd(const void* x, const void* res, const float* gamma, con
 
 extern "C" int asr_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                               const float* pe, const int32_t* lens, void* y, void* xhat,
-                              float* rstd, int B, int T, int d, int dtype, void* stream) {
+                              float* rstd, int B, int T, int d, float drop_p, uint32_t drop_seed, int drop_mode,
+                              int dtype, void* stream) {
     if (!x || !gamma || !beta || !y || !xhat || !rstd) ASR_FAIL(ASR_EINVAL, "asr_add_ln_fwd: null pointer");
     if (B <= 0 || T <= 0 || d <= 0 || d > 2048) ASR_FAIL(ASR_EINVAL, "asr_add_ln_fwd: bad shape B=%d T=%d d=%d", B, T, d);
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && drop_mode != 1 && drop_mode != 2) || (drop_p > 0.f && (d & 1)))
+        ASR_FAIL(ASR_EINVAL, "asr_add_ln_fwd: bad dropout p=%f mode=%d (d must be even)", drop_p, drop_mode);
+    if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_add_ln_fwd: dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ASR_F32) launch_ln_fwd<float>(x, res, gamma, beta, pe, lens, y, xhat, rstd, B * T, T, d, st);
-    else if (dtype == ASR_BF16) launch_ln_fwd<bf16_t>(x, res, gamma, beta, pe, lens, y, xhat, rstd, B * T, T, d, st);
-    else ASR_FAIL(ASR_EDTYPE, "asr_add_ln_fwd: dtype %d", dtype);
+    const int mode = drop_p > 0.f ? drop_mode : 0;
+    const uint32_t thr = drop_thr16(drop_p);
+    const float ds = 1.f / (1.f - drop_p);
+#define LN_FWD_D(TT, MODE) launch_ln_fwd<TT, MODE>(x, res, gamma, beta, pe, lens, y, xhat, rstd, B * T, T, d, drop_seed, thr, ds, st)
+    if (dtype == ASR_F32) { if (mode == 0) LN_FWD_D(float, 0); else if (mode == 1) LN_FWD_D(float, 1); else LN_FWD_D(float, 2); }
+    else { if (mode == 0) LN_FWD_D(bf16_t, 0); else if (mode == 1) LN_FWD_D(bf16_t, 1); else LN_FWD_D(bf16_t, 2); }
+#undef LN_FWD_D
     ASR_CHECK_LAUNCH("asr_add_ln_fwd");
     return ASR_OK;
 }
 
-template <typename T>
+template <typename T, int DROP>
 static void launch_ln_bwd(const void* dy, const void* dy2, const void* xhat, const float* rstd,
-                          const float* gamma, const int32_t* lens, void* dz, float* ws, int rows,
-                          int T_, int d, hipStream_t st) {
+                          const float* gamma, const int32_t* lens, void* dz, void* dx, float* ws, int rows,
+                          int T_, int d, uint32_t seed, uint32_t thr, float dscale, hipStream_t st) {
     const int grid = ln_grid(rows);
 #define LN_BWD(N, V)                                                                      \
-    add_ln_bwd_kernel<T, N, V><<<grid, LN_WAVES * WAVE, 0, st>>>(                          \
-        (const T*)dy, (const T*)dy2, (const T*)xhat, rstd, gamma, lens, (T*)dz, ws, rows, T_, d)
+    add_ln_bwd_kernel<T, N, V, DROP><<<grid, LN_WAVES * WAVE, 0, st>>>(                    \
+        (const T*)dy, (const T*)dy2, (const T*)xhat, rstd, gamma, lens, (T*)dz, (T*)dx, ws, rows, T_, d, seed, thr, dscale)
     if (d % 512 == 0 && d <= 2048) {
         switch (d / 512) {
             case 1: LN_BWD(8, true); break;
@@ -245,17 +274,25 @@ static void launch_ln_bwd(const void* dy, const void* dy2, const void* xhat, con
 }
 
 extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat, const float* rstd,
-                              const float* gamma, const int32_t* lens, void* dz, float* dgamma,
+                              const float* gamma, const int32_t* lens, void* dz, void* dx, float* dgamma,
                               float* dbeta, float* dbias, void* ws, size_t ws_bytes, int B, int T,
-                              int d, int dtype, void* stream) {
+                              int d, float drop_p, uint32_t drop_seed, int drop_mode, int dtype, void* stream) {
     if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !ws) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: null pointer");
     if (B <= 0 || T <= 0 || d <= 0 || d > 2048) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: bad shape B=%d T=%d d=%d", B, T, d);
     const int rows = B * T;
     if (ws_bytes < asr_add_ln_bwd_workspace_bytes(rows, d)) ASR_FAIL(ASR_EWORKSPACE, "asr_add_ln_bwd: workspace %zu < %zu", ws_bytes, asr_add_ln_bwd_workspace_bytes(rows, d));
+    if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_add_ln_bwd: dtype %d", dtype);
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && drop_mode != 1 && drop_mode != 2) || (drop_p > 0.f && (d & 1)))
+        ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: bad dropout p=%f mode=%d", drop_p, drop_mode);
+    const int mode = drop_p > 0.f ? drop_mode : 0;
+    if (mode == 1 && !dx) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: pre-residual dropout needs the dx output");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ASR_F32) launch_ln_bwd<float>(dy, dy2, xhat, rstd, gamma, lens, dz, (float*)ws, rows, T, d, st);
-    else if (dtype == ASR_BF16) launch_ln_bwd<bf16_t>(dy, dy2, xhat, rstd, gamma, lens, dz, (float*)ws, rows, T, d, st);
-    else ASR_FAIL(ASR_EDTYPE, "asr_add_ln_bwd: dtype %d", dtype);
+    const uint32_t thr = drop_thr16(drop_p);
+    const float ds = 1.f / (1.f - drop_p);
+#define LN_BWD_D(TT, MODE) launch_ln_bwd<TT, MODE>(dy, dy2, xhat, rstd, gamma, lens, dz, dx, (float*)ws, rows, T, d, drop_seed, thr, ds, st)
+    if (dtype == ASR_F32) { if (mode == 0) LN_BWD_D(float, 0); else if (mode == 1) LN_BWD_D(float, 1); else LN_BWD_D(float, 2); }
+    else { if (mode == 0) LN_BWD_D(bf16_t, 0); else if (mode == 1) LN_BWD_D(bf16_t, 1); else LN_BWD_D(bf16_t, 2); }
+#undef LN_BWD_D
     const int P = ln_grid(rows);
     const int ncols = dbias ? 3 * d : 2 * d;
     colsum_finalize_kernel<<<ceil_div(ncols, 32), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);

@@ -152,22 +152,40 @@ __global__ void dec_preprocess_kernel(const int64_t* __restrict__ tgt, int32_t* 
 template <typename T, typename W>
 __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int32_t* __restrict__ ids, const W* __restrict__ emb,
                                                            const float* __restrict__ pe, T* __restrict__ y, float scale,
-                                                           int rows, int To, int d, int V) {
+                                                           int rows, int To, int d, int V, uint32_t seed, uint32_t thr, float dscale) {
     const int row = blockIdx.x;
     int id = ids[row];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
     const int t = row % To;
-    for (int c = threadIdx.x; c < d; c += blockDim.x)
-        y[(size_t)row * d + c] = from_f32<T>(to_f32<W>(emb[(size_t)id * d + c]) * scale + pe[(size_t)t * d + c]);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float v = to_f32<W>(emb[(size_t)id * d + c]) * scale + pe[(size_t)t * d + c];
+        if (thr) v = drop_keep_at((uint32_t)row * (uint32_t)d + c, seed, thr) ? v * dscale : 0.f;
+        y[(size_t)row * d + c] = from_f32<T>(v);
+    }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dy,
-                                                        float* __restrict__ demb, float scale, int d, int V) {
+                                                        float* __restrict__ demb, float scale, int d, int V, uint32_t seed, uint32_t thr,
+                                                        float dscale) {
     const int row = blockIdx.x;
     const int id = ids[row];
     if (id < 0 || id >= V) return;
-    for (int c = threadIdx.x; c < d; c += blockDim.x)
-        atomicAdd(&demb[(size_t)id * d + c], to_f32<T>(dy[(size_t)row * d + c]) * scale);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float g = to_f32<T>(dy[(size_t)row * d + c]) * scale;
+        if (thr) g = drop_keep_at((uint32_t)row * (uint32_t)d + c, seed, thr) ? g * dscale : 0.f;
+        if (g != 0.f) atomicAdd(&demb[(size_t)id * d + c], g);
+    }
+}
+
+// mask[r][c] for c < cols, element counter r * cols_pad + c (cols_pad = cols rounded up to even)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, size_t rows, int cols, uint32_t seed, uint32_t thr) {
+    const size_t n = rows * (size_t)cols;
+    const uint32_t cp = (uint32_t)((cols + 1) & ~1);
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / cols;
+        const uint32_t c = (uint32_t)(i - r * cols);
+        mask[i] = drop_keep_at((uint32_t)r * cp + c, seed, thr) ? 1 : 0;
+    }
 }
 
 // ---- optimizer -------------------------------------------------------------------------------
@@ -342,27 +360,49 @@ extern "C" int asr_dec_preprocess(const int64_t* tgt, int32_t* ys_in, int32_t* y
 }
 
 extern "C" int asr_embed_pe_fwd(const int32_t* ids, const void* emb, const float* pe, void* y, float scale, int B, int To, int d,
-                                int V, int dtype, void* stream) {
+                                int V, float drop_p, uint32_t drop_seed, int dtype, void* stream) {
     if (!ids || !emb || !pe || !y) ASR_FAIL(ASR_EINVAL, "asr_embed_pe_fwd: null pointer");
     if (B <= 0 || To <= 0 || d <= 0 || V <= 0) ASR_FAIL(ASR_EINVAL, "asr_embed_pe_fwd: bad shape");
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (d & 1))) ASR_FAIL(ASR_EINVAL, "asr_embed_pe_fwd: bad dropout p=%f", drop_p);
     hipStream_t st = (hipStream_t)stream;
+    const uint32_t thr = drop_thr16(drop_p);
+    const float ds = 1.f / (1.f - drop_p);
     // the gather always reads the fp32 master embedding (exact), whatever the activation dtype
-    if (dtype == ASR_F32) embed_pe_fwd_kernel<float, float><<<B * To, 256, 0, st>>>(ids, (const float*)emb, pe, (float*)y, scale, B * To, To, d, V);
-    else if (dtype == ASR_BF16) embed_pe_fwd_kernel<bf16_t, float><<<B * To, 256, 0, st>>>(ids, (const float*)emb, pe, (bf16_t*)y, scale, B * To, To, d, V);
+    if (dtype == ASR_F32) embed_pe_fwd_kernel<float, float><<<B * To, 256, 0, st>>>(ids, (const float*)emb, pe, (float*)y, scale, B * To, To, d, V, drop_seed, thr, ds);
+    else if (dtype == ASR_BF16) embed_pe_fwd_kernel<bf16_t, float><<<B * To, 256, 0, st>>>(ids, (const float*)emb, pe, (bf16_t*)y, scale, B * To, To, d, V, drop_seed, thr, ds);
     else ASR_FAIL(ASR_EDTYPE, "asr_embed_pe_fwd: dtype %d", dtype);
     ASR_CHECK_LAUNCH("asr_embed_pe_fwd");
     return ASR_OK;
 }
 
-extern "C" int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, float scale, int rows, int d, int V, int dtype,
-                             void* stream) {
+extern "C" int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, float scale, int rows, int d, int V, float drop_p,
+                             uint32_t drop_seed, int dtype, void* stream) {
     if (!ids || !dy || !demb) ASR_FAIL(ASR_EINVAL, "asr_embed_bwd: null pointer");
     if (rows <= 0 || d <= 0) ASR_FAIL(ASR_EINVAL, "asr_embed_bwd: bad shape");
+    if (drop_p < 0.f || drop_p >= 1.f) ASR_FAIL(ASR_EINVAL, "asr_embed_bwd: bad dropout p=%f", drop_p);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ASR_F32) embed_bwd_kernel<float><<<rows, 256, 0, st>>>(ids, (const float*)dy, demb, scale, d, V);
-    else if (dtype == ASR_BF16) embed_bwd_kernel<bf16_t><<<rows, 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, d, V);
+    const uint32_t thr = drop_thr16(drop_p);
+    const float ds = 1.f / (1.f - drop_p);
+    if (dtype == ASR_F32) embed_bwd_kernel<float><<<rows, 256, 0, st>>>(ids, (const float*)dy, demb, scale, d, V, drop_seed, thr, ds);
+    else if (dtype == ASR_BF16) embed_bwd_kernel<bf16_t><<<rows, 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, d, V, drop_seed, thr, ds);
     else ASR_FAIL(ASR_EDTYPE, "asr_embed_bwd: dtype %d", dtype);
     ASR_CHECK_LAUNCH("asr_embed_bwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_dropout_mask(uint8_t* mask, int rows, int cols, float drop_p, uint32_t drop_seed, void* stream) {
+    if (!mask || rows <= 0 || cols <= 0 || (cols & 1)) ASR_FAIL(ASR_EINVAL, "asr_dropout_mask: bad arguments (cols must be even)");
+    const size_t n = (size_t)rows * cols;
+    dropout_mask_kernel<<<(int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(mask, (size_t)rows, cols, drop_seed, drop_thr16(drop_p));
+    ASR_CHECK_LAUNCH("asr_dropout_mask");
+    return ASR_OK;
+}
+
+extern "C" int asr_sdpa_dropout_mask(uint8_t* mask, int B, int H, int Tq, int Tk, float drop_p, uint32_t drop_seed, void* stream) {
+    if (!mask || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) ASR_FAIL(ASR_EINVAL, "asr_sdpa_dropout_mask: bad arguments");
+    const size_t n = (size_t)B * H * Tq * Tk;   // element index ((b*H+h)*Tq+q)*Tk+k is the linear index
+    dropout_mask_kernel<<<(int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), 256, 0, (hipStream_t)stream>>>(mask, (size_t)B * H * Tq, Tk, drop_seed, drop_thr16(drop_p));
+    ASR_CHECK_LAUNCH("asr_sdpa_dropout_mask");
     return ASR_OK;
 }
 

@@ -117,14 +117,19 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&acc)[2], float mul, 
 }
 
 // ---------------------------------------------------------------- forward
+template <bool DROP>
 __global__ __launch_bounds__(256) void sdpa_fwd_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                             bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
-                                                            int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale) {
+                                                            int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
+                                                            uint32_t dseed, uint32_t dthr, float dscale) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TILE_ELEMS];
     bf16_t* Kt = smem;
     bf16_t* Vt = smem + TILE_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x * 128, q0 = qblk + 32 * w;
+    // 1-D grid, XCD-aware: the query blocks of one (b, h) - which all stream the same K/V - get
+    // consecutive virtual ids and so share one XCD's L2 (K/V otherwise re-fetched per query block)
+    const int nqb = (Tq + 127) >> 7, vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    const int bh = vid / nqb, b = bh / H, h = bh - b * H, qblk = (vid - bh * nqb) * 128, q0 = qblk + 32 * w;
     const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
     const bf16_t* kb = k + (size_t)b * Tk * ldk + h * DK;
     const bf16_t* vb = v + (size_t)b * Tk * ldv + h * DK;
@@ -191,6 +196,17 @@ __global__ __launch_bounds__(256) void sdpa_fwd_bf16_kernel(const bf16_t* __rest
                 psum += p;
             }
         l = l * alpha + psum;
+        if constexpr (DROP) {   // attention.py:83: dropout on the probabilities (the normaliser l stays undropped)
+            const uint32_t rowbase = (((uint32_t)(b * H + h)) * Tq + min(qi, Tq - 1)) * ((Tk + 1) & ~1);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const uint32_t hsh = drop_hash((rowbase + k0 + 32 * sub + acc_row(i, lane)) >> 1, dseed);
+                    st[sub][i] = drop_keep(hsh, 0, dthr) ? st[sub][i] * dscale : 0.f;
+                    st[sub][i + 1] = drop_keep(hsh, 1, dthr) ? st[sub][i + 1] * dscale : 0.f;
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
 #pragma unroll
@@ -232,15 +248,18 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o
 }
 
 // ---------------------------------------------------------------- backward: dQ
+template <bool DROP>
 __global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dq, const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq,
-                                                               int ldk, int ldv, int ldo, int causal, int window, float scale) {
+                                                               int ldk, int ldv, int ldo, int causal, int window, float scale, uint32_t dseed, uint32_t dthr,
+                                                               float dscale) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TILE_ELEMS];
     bf16_t* Kt = smem;
     bf16_t* Vt = smem + TILE_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x * 128, q0 = qblk + 32 * w;
+    const int nqb = (Tq + 127) >> 7, vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    const int bh = vid / nqb, b = bh / H, h = bh - b * H, qblk = (vid - bh * nqb) * 128, q0 = qblk + 32 * w;
     const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
     const bf16_t* dob = d_o + (size_t)b * Tq * ldo + h * DK;
     const bf16_t* kb = k + (size_t)b * Tk * ldk + h * DK;
@@ -285,6 +304,15 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __r
                 for (int i = 0; i < 16; ++i)
                     if (!visible(qi, ks0 + acc_row(i, lane), klen, causal, window)) st[i] = -INFINITY;
             }
+            if constexpr (DROP) {   // dP = (dO V^T) o keep / (1-p)
+                const uint32_t rowbase = (((uint32_t)(b * H + h)) * Tq + min(qi, Tq - 1)) * ((Tk + 1) & ~1);
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const uint32_t hsh = drop_hash((rowbase + ks0 + acc_row(i, lane)) >> 1, dseed);
+                    dp[i] = drop_keep(hsh, 0, dthr) ? dp[i] * dscale : 0.f;
+                    dp[i + 1] = drop_keep(hsh, 1, dthr) ? dp[i + 1] * dscale : 0.f;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(st[i], sc2, -lse2));
@@ -303,10 +331,12 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------- backward: dK, dV
+template <bool DROP>
 __global__ __launch_bounds__(256) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                 const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dk_, bf16_t* __restrict__ dv, const int32_t* __restrict__ k_len, int H,
-                                                                int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale) {
+                                                                int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
+                                                                uint32_t dseed, uint32_t dthr, float dscale) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TILE_ELEMS];
     __shared__ __attribute__((aligned(16))) float stats[2 * TILE];
     bf16_t* Qt = smem;
@@ -314,7 +344,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __
     float* s_lse = stats;
     float* s_del = stats + TILE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x * 128, kk0 = kblk + 32 * w;
+    const int nkb = (Tk + 127) >> 7, vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    const int bh = vid / nkb, b = bh / H, h = bh - b * H, kblk = (vid - bh * nkb) * 128, kk0 = kblk + 32 * w;
     const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
     const bf16_t* dob = d_o + (size_t)b * Tq * ldo + h * DK;
     const bf16_t* kb = k + (size_t)b * Tk * ldk + h * DK;
@@ -376,8 +407,13 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __
                     float sv = st[i];
                     if (need_mask && !visible(q0 + r0 + e, kj, klen, causal, window)) sv = -INFINITY;
                     const float p = __builtin_amdgcn_exp2f(fmaf(sv, sc2, -l4[e]));
-                    st[i] = p;
-                    ds[i] = p * (dp[i] - d4[e]) * scale;
+                    float keepf = 1.f;
+                    if constexpr (DROP) {
+                        const uint32_t el = (((uint32_t)(b * H + h)) * Tq + min(q0 + r0 + e, Tq - 1)) * ((Tk + 1) & ~1) + min(kj, Tk - 1);
+                        keepf = drop_keep_at(el, dseed, dthr) ? dscale : 0.f;
+                    }
+                    st[i] = p * keepf;                               // dropped probabilities feed dV
+                    ds[i] = p * (dp[i] * keepf - d4[e]) * scale;
                 }
             }
 #pragma unroll
@@ -403,7 +439,8 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __
 template <typename T>
 __global__ __launch_bounds__(64) void sdpa_fwd_generic_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ o,
                                                               float* __restrict__ lse, const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int dk,
-                                                              int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale) {
+                                                              int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale, uint32_t dseed,
+                                                              uint32_t dthr, float dscale) {
     extern __shared__ float sc[];  // Tk scores, then dk floats of the query row
     float* qrow = sc + Tk;
     const int lane = threadIdx.x;
@@ -434,6 +471,11 @@ __global__ __launch_bounds__(64) void sdpa_fwd_generic_kernel(const T* __restric
     l = wave_sum(l);
     __syncthreads();
     const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (dthr) {   // dropout on the probabilities; l (the normaliser) is already summed
+        const uint32_t rowbase = (((uint32_t)(b * H + h)) * Tq + qi) * ((Tk + 1) & ~1);
+        for (int j = lane; j < Tk; j += 64) sc[j] = drop_keep_at(rowbase + j, dseed, dthr) ? sc[j] * dscale : 0.f;
+        __syncthreads();
+    }
     T* op = o + ((size_t)b * Tq + qi) * ldo + (size_t)h * dk;
     for (int c = lane; c < dk; c += 64) {
         float a = 0.f;
@@ -451,7 +493,8 @@ template <typename T>
 __global__ __launch_bounds__(64) void sdpa_bwd_dq_generic_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                                  const T* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                  T* __restrict__ dq, const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int dk, int ldq,
-                                                                 int ldk, int ldv, int ldo, int causal, int window, float scale) {
+                                                                 int ldk, int ldv, int ldo, int causal, int window, float scale, uint32_t dseed, uint32_t dthr,
+                                                                 float dscale) {
     extern __shared__ float sc[];  // Tk dS values, then q row (dk) and dO row (dk)
     float* qrow = sc + Tk;
     float* dorow = qrow + dk;
@@ -471,6 +514,7 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dq_generic_kernel(const T* __rest
             const T* vp = v + ((size_t)b * Tk + j) * ldv + (size_t)h * dk;
             float a = 0.f, dp = 0.f;
             for (int c = 0; c < dk; ++c) { a += qrow[c] * to_f32<T>(kp[c]); dp += dorow[c] * to_f32<T>(vp[c]); }
+            if (dthr) dp = drop_keep_at((((uint32_t)(b * H + h)) * Tq + qi) * ((Tk + 1) & ~1) + j, dseed, dthr) ? dp * dscale : 0.f;
             ds = expf(a * scale - L) * (dp - dl) * scale;
         }
         sc[j] = ds;
@@ -492,7 +536,8 @@ template <typename T>
 __global__ __launch_bounds__(64) void sdpa_bwd_dkv_generic_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                                   const T* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                   T* __restrict__ dk_, T* __restrict__ dv, const int32_t* __restrict__ k_len, int H, int Tq, int Tk,
-                                                                  int dk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale) {
+                                                                  int dk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale, uint32_t dseed,
+                                                                  uint32_t dthr, float dscale) {
     extern __shared__ float sc[];  // Tq p values, Tq dS values, k row (dk), v row (dk)
     float* ps = sc;
     float* dss = sc + Tq;
@@ -514,7 +559,10 @@ __global__ __launch_bounds__(64) void sdpa_bwd_dkv_generic_kernel(const T* __res
             for (int c = 0; c < dk; ++c) { a += to_f32<T>(qp[c]) * krow[c]; dp += to_f32<T>(dop[c]) * vrow[c]; }
             const size_t st = ((size_t)b * H + h) * Tq + i;
             p = expf(a * scale - lse[st]);
-            ds = p * (dp - delta[st]) * scale;
+            float keepf = 1.f;
+            if (dthr) keepf = drop_keep_at((((uint32_t)(b * H + h)) * Tq + i) * ((Tk + 1) & ~1) + kj, dseed, dthr) ? dscale : 0.f;
+            ds = p * (dp * keepf - delta[st]) * scale;
+            p *= keepf;
         }
         ps[i] = p;
         dss[i] = ds;
@@ -551,20 +599,25 @@ static int check_common(const char* name, int B, int H, int Tq, int Tk, int dk, 
 }  // namespace
 
 extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* k_len, int B, int H, int Tq, int Tk, int dk,
-                            int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale, int dtype, void* stream) {
+                            int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale, float drop_p, uint32_t dseed, int dtype,
+                            void* stream) {
     if (!q || !k || !v || !o || !lse) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: null pointer");
     if (int rc = check_common("asr_sdpa_fwd", B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo)) return rc;
+    if (drop_p < 0.f || drop_p >= 1.f) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: bad dropout p=%f", drop_p);
+    if ((double)B * H * Tq * (Tk + 1) >= 4294967296.0) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: B*H*Tq*Tk exceeds the 32-bit dropout counter");
+    const uint32_t dthr = drop_thr16(drop_p);
+    const float dscale = 1.f / (1.f - drop_p);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o)) {
-        dim3 grid(ceil_div(Tq, 128), H, B);
-        sdpa_fwd_bf16_kernel<<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo,
-                                                    causal, window, scale);
+        const int grid = ceil_div(Tq, 128) * H * B;
+        if (dthr) sdpa_fwd_bf16_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
+        else sdpa_fwd_bf16_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
     } else {
         dim3 grid(Tq, H, B);
         const size_t lds = (size_t)(Tk + dk) * sizeof(float);
         if (lds > 64 * 1024) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: generic path needs Tk+dk <= 16384");
-        if (dtype == ASR_F32) sdpa_fwd_generic_kernel<float><<<grid, 64, lds, st>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, lse, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale);
-        else if (dtype == ASR_BF16) sdpa_fwd_generic_kernel<bf16_t><<<grid, 64, lds, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale);
+        if (dtype == ASR_F32) sdpa_fwd_generic_kernel<float><<<grid, 64, lds, st>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, lse, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
+        else if (dtype == ASR_BF16) sdpa_fwd_generic_kernel<bf16_t><<<grid, 64, lds, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
         else ASR_FAIL(ASR_EDTYPE, "asr_sdpa_fwd: dtype %d", dtype);
     }
     ASR_CHECK_LAUNCH("asr_sdpa_fwd");
@@ -573,30 +626,39 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
 
 extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, void* dq, void* dk_,
                             void* dv, const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk, int ldv, int ldo, int causal, int window,
-                            float scale, int dtype, void* stream) {
+                            float scale, float drop_p, uint32_t dseed, int dtype, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk_ || !dv) ASR_FAIL(ASR_EINVAL, "asr_sdpa_bwd: null pointer");
     if (int rc = check_common("asr_sdpa_bwd", B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo)) return rc;
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_sdpa_bwd: dtype %d", dtype);
+    if (drop_p < 0.f || drop_p >= 1.f) ASR_FAIL(ASR_EINVAL, "asr_sdpa_bwd: bad dropout p=%f", drop_p);
+    const uint32_t dthr = drop_thr16(drop_p);
+    const float dscale = 1.f / (1.f - drop_p);
     hipStream_t st = (hipStream_t)stream;
     const int ngroups = B * Tq * H;
     if (dtype == ASR_F32) sdpa_delta_kernel<float><<<ceil_div(ngroups, 32), 256, 0, st>>>((const float*)o, (const float*)d_o, delta, B, H, Tq, dk, ldo);
     else sdpa_delta_kernel<bf16_t><<<ceil_div(ngroups, 32), 256, 0, st>>>((const bf16_t*)o, (const bf16_t*)d_o, delta, B, H, Tq, dk, ldo);
     if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, d_o) && mfma_ok(dk, ldq, ldk, ldv, ldo, dq, dk_, dv, o)) {
-        dim3 gq(ceil_div(Tq, 128), H, B), gk(ceil_div(Tk, 128), H, B);
-        sdpa_bwd_dq_bf16_kernel<<<gq, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, k_len, H, Tq, Tk,
-                                                     ldq, ldk, ldv, ldo, causal, window, scale);
-        sdpa_bwd_dkv_bf16_kernel<<<gk, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk_, (bf16_t*)dv, k_len, H,
-                                                      Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale);
+        const int gq = ceil_div(Tq, 128) * H * B, gk = ceil_div(Tk, 128) * H * B;
+#define SDPA_BWD(D)                                                                                                                                        \
+    do {                                                                                                                                                   \
+        sdpa_bwd_dq_bf16_kernel<D><<<gq, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq,   \
+                                                        k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);                  \
+        sdpa_bwd_dkv_bf16_kernel<D><<<gk, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk_, \
+                                                         (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);    \
+    } while (0)
+        if (dthr) SDPA_BWD(true);
+        else SDPA_BWD(false);
+#undef SDPA_BWD
     } else {
         dim3 gq(Tq, H, B), gk(Tk, H, B);
         const size_t l1 = (size_t)(Tk + 2 * dk) * sizeof(float), l2 = (size_t)(2 * Tq + 2 * dk) * sizeof(float);
         if (l1 > 64 * 1024 || l2 > 64 * 1024) ASR_FAIL(ASR_EINVAL, "asr_sdpa_bwd: generic path sequence too long for LDS");
         if (dtype == ASR_F32) {
-            sdpa_bwd_dq_generic_kernel<float><<<gq, 64, l1, st>>>((const float*)q, (const float*)k, (const float*)v, (const float*)d_o, lse, delta, (float*)dq, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale);
-            sdpa_bwd_dkv_generic_kernel<float><<<gk, 64, l2, st>>>((const float*)q, (const float*)k, (const float*)v, (const float*)d_o, lse, delta, (float*)dk_, (float*)dv, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale);
+            sdpa_bwd_dq_generic_kernel<float><<<gq, 64, l1, st>>>((const float*)q, (const float*)k, (const float*)v, (const float*)d_o, lse, delta, (float*)dq, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
+            sdpa_bwd_dkv_generic_kernel<float><<<gk, 64, l2, st>>>((const float*)q, (const float*)k, (const float*)v, (const float*)d_o, lse, delta, (float*)dk_, (float*)dv, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
         } else {
-            sdpa_bwd_dq_generic_kernel<bf16_t><<<gq, 64, l1, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale);
-            sdpa_bwd_dkv_generic_kernel<bf16_t><<<gk, 64, l2, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale);
+            sdpa_bwd_dq_generic_kernel<bf16_t><<<gq, 64, l1, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
+            sdpa_bwd_dkv_generic_kernel<bf16_t><<<gk, 64, l2, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
         }
     }
     ASR_CHECK_LAUNCH("asr_sdpa_bwd");

@@ -235,8 +235,19 @@ class Engine:
         # latency-bound kernels of both chains fill each other's idle CUs.
         self.side = torch.cuda.Stream(device=flat.device)
         self.overlap_wgrad = True
+        # dropout (reference default 0.1; sites: transformer_official.py:175, 306; attention.py:59, 83;
+        # module.py:73): masks are regenerated in backward from (step seed, site id), never stored
+        self.drop_p = float(getattr(cfg, "dropout", 0.0))
+        self.training = True
+        self.step_seed = 0
 
     # ------------------------------------------------------------------ helpers
+    def _drop(self, site):
+        """(p, seed) of a dropout site for the current step; p = 0 in eval mode."""
+        if not self.training or self.drop_p <= 0.0:
+            return 0.0, 0
+        return self.drop_p, (self.step_seed * 0x9E3779B1 + site * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF
+
     def _ready(self, name):
         """Gradients at flat offsets >= this tensor's offset are final once the work queued so far
         on BOTH streams has run: the consumer (dist.GradBucketer) waits on events of the two."""
@@ -266,7 +277,7 @@ class Engine:
         for t in (dy, x):
             t.record_stream(self.side)
 
-    def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross):
+    def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross, site):
         """x: (B*Tq, d) queries + residual; kv_src: (B*Tk, d).  Returns output and cache."""
         H, dk, hd = self.H, self.dk, self.H * self.dk
         c = {}
@@ -279,11 +290,13 @@ class Engine:
             kv = m.kv.fwd(kv_src)
             k, v = kv[:, :hd], kv[:, hd:]
             c["q"], c["kv"] = q, kv
-        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window)
+        pa, sa = self._drop(site)          # attention probabilities (attention.py:83)
+        pf, sf = self._drop(site + 1)      # after fc, before residual + LN (attention.py:59)
+        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa)
         a = m.fc.fwd(ctx)
-        y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a)
+        y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)
         c.update(x=x, kv_src=kv_src, ctx=ctx, lse=lse, xhat=xhat, rstd=rstd, k_len=k_len, q_lens=q_lens, dims=(B, Tq, Tk), causal=causal,
-                 window=window, cross=cross)
+                 window=window, cross=cross, drop=(pa, sa, pf, sf))
         return y, c
 
     def _attn_block_bwd(self, m, c, dy, dy2, d_kv_src=None):
@@ -292,14 +305,16 @@ class Engine:
         key/value-source gradient is accumulated into d_kv_src in place."""
         H, dk, hd = self.H, self.dk, self.H * self.dk
         B, Tq, Tk = c["dims"]
-        dz = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], m.ln.g, c["q_lens"], m.ln.gg, m.ln.gb, m.fc.gb, B, Tq, self.ws)
-        self._wgrad(m.fc, dz, c["ctx"])
-        dctx = m.fc.dgrad(dz)
+        pa, sa, pf, sf = c["drop"]
+        dz, dxg = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], m.ln.g, c["q_lens"], m.ln.gg, m.ln.gb, m.fc.gb, B, Tq, self.ws,
+                               drop_p=pf, drop_seed=sf, drop_mode=1)
+        self._wgrad(m.fc, dxg, c["ctx"])
+        dctx = m.fc.dgrad(dxg)
         if not c["cross"]:
             qkv = c["qkv"]
             dqkv = torch.empty_like(qkv)
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
-                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"])
+                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa)
             self._wgrad(m.qkv, dqkv, c["x"], bias_from=dqkv)
             dx = m.qkv.dgrad(dqkv)
         else:
@@ -307,24 +322,27 @@ class Engine:
             dq = torch.empty_like(q)
             dkv = torch.empty_like(kv)
             K.sdpa_bwd(q, kv[:, :hd], kv[:, hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk, dq, dkv[:, :hd], dkv[:, hd:],
-                       c["causal"], c["window"])
+                       c["causal"], c["window"], drop_p=pa, drop_seed=sa)
             self._wgrad(m.q, dq, c["x"], bias_from=dq)
             self._wgrad(m.kv, dkv, c["kv_src"], bias_from=dkv)
             dx = m.q.dgrad(dq)
             m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
         return dx, dz
 
-    def _ffn_block_fwd(self, f, x, B, T, lens):
+    def _ffn_block_fwd(self, f, x, B, T, lens, site):
         h = f.w1.fwd(x, act=ACT_RELU)
         o = f.w2.fwd(h)
-        y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o)
-        return y, dict(x=x, h=h, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T))
+        pf, sf = self._drop(site)          # after w_2, before residual + LN (module.py:73)
+        y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o, drop_p=pf, drop_seed=sf, drop_mode=1)
+        return y, dict(x=x, h=h, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T), drop=(pf, sf))
 
     def _ffn_block_bwd(self, f, c, dy, dy2):
         B, T = c["dims"]
-        dz = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], f.ln.g, c["lens"], f.ln.gg, f.ln.gb, f.w2.gb, B, T, self.ws)
-        self._wgrad(f.w2, dz, c["h"])
-        dh = f.w2.dgrad(dz)
+        pf, sf = c["drop"]
+        dz, dxg = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], f.ln.g, c["lens"], f.ln.gg, f.ln.gb, f.w2.gb, B, T, self.ws,
+                               drop_p=pf, drop_seed=sf, drop_mode=1)
+        self._wgrad(f.w2, dxg, c["h"])
+        dh = f.w2.dgrad(dxg)
         K.relu_bwd_(dh, c["h"], f.w1.gb, self.ws)
         self._wgrad(f.w1, dh, c["x"])
         dx = f.w1.dgrad(dh)
@@ -336,11 +354,12 @@ class Engine:
         B, T, F = wave.shape
         x_in = wave.reshape(B * T, F)
         e0 = self.lin_in.fwd(x_in)
-        h, xhat, rstd = K.add_ln_fwd(e0, None, self.ln_in.g, self.ln_in.b, self.pe, None, B, T, xhat=e0)
-        cache = dict(x_in=x_in, xhat_in=xhat, rstd_in=rstd, B=B, T=T, layers=[])
-        for mha, ffn in self.enc:
-            h1, c1 = self._attn_block_fwd(mha, h, h, B, T, T, wave_len, wave_len, False, window, False)
-            h, c2 = self._ffn_block_fwd(ffn, h1, B, T, wave_len)
+        p0, s0 = self._drop(1)             # dropout(LN(linear_in(x)) + PE)  (transformer_official.py:175-177)
+        h, xhat, rstd = K.add_ln_fwd(e0, None, self.ln_in.g, self.ln_in.b, self.pe, None, B, T, xhat=e0, drop_p=p0, drop_seed=s0, drop_mode=2)
+        cache = dict(x_in=x_in, xhat_in=xhat, rstd_in=rstd, B=B, T=T, layers=[], drop=(p0, s0))
+        for i, (mha, ffn) in enumerate(self.enc):
+            h1, c1 = self._attn_block_fwd(mha, h, h, B, T, T, wave_len, wave_len, False, window, False, site=10 + 4 * i)
+            h, c2 = self._ffn_block_fwd(ffn, h1, B, T, wave_len, site=12 + 4 * i)
             cache["layers"].append((c1, c2))
         return h, cache
 
@@ -354,7 +373,9 @@ class Engine:
             dx, dz = self._attn_block_bwd(mha, c1, dx, dz)
             dy, dy2 = dx, dz
             self._ready(f"encoder.layer_stack.{i}.slf_attn.w_qs.weight")
-        dz = K.add_ln_bwd(dy, dy2, cache["xhat_in"], cache["rstd_in"], self.ln_in.g, None, self.ln_in.gg, self.ln_in.gb, self.lin_in.gb, B, T, self.ws)
+        p0, s0 = cache["drop"]
+        dz, _ = K.add_ln_bwd(dy, dy2, cache["xhat_in"], cache["rstd_in"], self.ln_in.g, None, self.ln_in.gg, self.ln_in.gb, self.lin_in.gb, B, T, self.ws,
+                             drop_p=p0, drop_seed=s0, drop_mode=2)
         self._wgrad(self.lin_in, dz, cache["x_in"])
         self.join_side()
         self._ready("encoder.linear_in.weight")
@@ -378,12 +399,13 @@ class Engine:
         """prep = kernels.dec_preprocess(tgt).  transformer_official.py:277-328."""
         ys_in, ys_out, labels32, dec_len, lab_len, n_valid = prep
         To = ys_in.shape[1]
-        x = K.embed_pe_fwd(ys_in.reshape(-1), self.emb32, self.pe, self.d ** -0.5, B, To, self.dtype)
-        cache = dict(B=B, T=T, To=To, ys_in=ys_in, layers=[])
-        for slf, cross, ffn in self.dec:
-            x1, c1 = self._attn_block_fwd(slf, x, x, B, To, To, dec_len, dec_len, True, -1, False)
-            x2, c2 = self._attn_block_fwd(cross, x1, enc, B, To, T, cross_len, dec_len, False, -1, True)
-            x, c3 = self._ffn_block_fwd(ffn, x2, B, To, dec_len)
+        pe_, se_ = self._drop(2)           # dropout(emb * scale + PE)  (transformer_official.py:306-307)
+        x = K.embed_pe_fwd(ys_in.reshape(-1), self.emb32, self.pe, self.d ** -0.5, B, To, self.dtype, drop_p=pe_, drop_seed=se_)
+        cache = dict(B=B, T=T, To=To, ys_in=ys_in, layers=[], drop=(pe_, se_))
+        for i, (slf, cross, ffn) in enumerate(self.dec):
+            x1, c1 = self._attn_block_fwd(slf, x, x, B, To, To, dec_len, dec_len, True, -1, False, site=100 + 8 * i)
+            x2, c2 = self._attn_block_fwd(cross, x1, enc, B, To, T, cross_len, dec_len, False, -1, True, site=102 + 8 * i)
+            x, c3 = self._ffn_block_fwd(ffn, x2, B, To, dec_len, site=104 + 8 * i)
             cache["layers"].append((c1, c2, c3))
         pred = self.prj.fwd(x)
         cache["x_last"] = x
@@ -402,5 +424,5 @@ class Engine:
             dy, dy2 = dx, dz
             self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
         dx = dy + dy2  # gradient wrt the embedding output
-        K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5)
+        K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1])
         self._ready("decoder.tgt_word_emb.weight")

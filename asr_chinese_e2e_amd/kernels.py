@@ -97,8 +97,9 @@ class Workspace:
 
 
 # --------------------------------------------------------------------------------- LayerNorm
-def add_ln_fwd(x, res, gamma, beta, pe, lens, B, T, y=None, xhat=None, rstd=None):
-    """y = LN(x + res) * gamma + beta (+ pe[t]), rows t >= lens[b] zeroed.  xhat may alias x."""
+def add_ln_fwd(x, res, gamma, beta, pe, lens, B, T, y=None, xhat=None, rstd=None, drop_p=0.0, drop_seed=0, drop_mode=0):
+    """y = LN(x + res) * gamma + beta (+ pe[t]), rows t >= lens[b] zeroed.  xhat may alias x.
+    drop_mode 1: dropout on x before the residual add; 2: dropout on the output."""
     d = x.shape[-1]
     assert x.is_contiguous() and x.numel() == B * T * d
     if res is not None:
@@ -114,11 +115,13 @@ def add_ln_fwd(x, res, gamma, beta, pe, lens, B, T, y=None, xhat=None, rstd=None
     xhat = torch.empty_like(x) if xhat is None else xhat
     rstd = torch.empty(B * T, dtype=torch.float32, device=x.device) if rstd is None else rstd
     check(lib.asr_add_ln_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(pe), _p(lens), _p(y), _p(xhat), _p(rstd),
-                             B, T, d, _dt(x), _stream()), "asr_add_ln_fwd")
+                             B, T, d, float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_mode), _dt(x), _stream()), "asr_add_ln_fwd")
     return y, xhat, rstd
 
 
-def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws, dz=None):
+def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws, dz=None, drop_p=0.0, drop_seed=0, drop_mode=0):
+    """Returns (dz, dx): dz = gradient wrt the residual input; dx = gradient wrt x (the same tensor
+    unless pre-residual dropout is active, then dz * keep / (1-p))."""
     d = dy.shape[-1]
     assert dy.is_contiguous() and xhat.is_contiguous() and dy.numel() == B * T * d == xhat.numel()
     assert xhat.dtype == dy.dtype and (dy2 is None or (dy2.dtype == dy.dtype and dy2.is_contiguous() and dy2.numel() == dy.numel()))
@@ -126,11 +129,13 @@ def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws,
     _chk_i32(lens)
     assert rstd.numel() == B * T and dgamma.numel() == d and dbeta.numel() == d and (dbias is None or dbias.numel() == d)
     dz = torch.empty_like(dy) if dz is None else dz
+    dx = torch.empty_like(dy) if (drop_p > 0 and drop_mode == 1) else None
     nbytes = lib.asr_add_ln_bwd_workspace_bytes(B * T, d)
     w = ws.get(nbytes)
-    check(lib.asr_add_ln_bwd(_p(dy), _p(dy2), _p(xhat), _p(rstd), _p(gamma), _p(lens), _p(dz), _p(dgamma), _p(dbeta),
-                             _p(dbias), _p(w), w.numel(), B, T, d, _dt(dy), _stream()), "asr_add_ln_bwd")
-    return dz
+    check(lib.asr_add_ln_bwd(_p(dy), _p(dy2), _p(xhat), _p(rstd), _p(gamma), _p(lens), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
+                             _p(dbias), _p(w), w.numel(), B, T, d, float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_mode),
+                             _dt(dy), _stream()), "asr_add_ln_bwd")
+    return dz, (dx if dx is not None else dz)
 
 
 # --------------------------------------------------------------------------------- attention
@@ -140,7 +145,7 @@ def _strided_rows(t, H, dk):
     return t.stride(0)
 
 
-def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None):
+def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None, drop_p=0.0, drop_seed=0):
     """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer)."""
     ldq, ldk, ldv = _strided_rows(q, H, dk), _strided_rows(k, H, dk), _strided_rows(v, H, dk)
     assert q.shape[0] == B * Tq and k.shape[0] == B * Tk and v.shape[0] == B * Tk
@@ -152,11 +157,12 @@ def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=No
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if lse is None else lse
     scale = float(dk) ** -0.5 if scale is None else float(scale)
     check(lib.asr_sdpa_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(k_len), B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo,
-                           int(causal), int(window), scale, _dt(q), _stream()), "asr_sdpa_fwd")
+                           int(causal), int(window), scale, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_fwd")
     return o, lse
 
 
-def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=False, window=-1, scale=None, delta=None):
+def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=False, window=-1, scale=None, delta=None,
+             drop_p=0.0, drop_seed=0):
     ldq, ldk, ldv, ldo = (_strided_rows(t, H, dk) for t in (q, k, v, o))
     assert _strided_rows(do, H, dk) == ldo and _strided_rows(dq, H, dk) == ldq
     assert _strided_rows(dk_, H, dk) == ldk and _strided_rows(dv, H, dk) == ldv
@@ -166,8 +172,8 @@ def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=F
     delta = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if delta is None else delta
     scale = float(dk) ** -0.5 if scale is None else float(scale)
     check(lib.asr_sdpa_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk_), _p(dv), _p(k_len),
-                           B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, int(causal), int(window), scale, _dt(q), _stream()),
-          "asr_sdpa_bwd")
+                           B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, int(causal), int(window), scale, float(drop_p),
+                           int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_bwd")
     return dq, dk_, dv
 
 
@@ -233,24 +239,37 @@ def dec_preprocess(tgt, sos=2, eos=3):
     return ys_in, ys_out, labels32, dec_len, lab_len, n_valid
 
 
-def embed_pe_fwd(ids, emb, pe, scale, B, To, dtype, y=None):
+def embed_pe_fwd(ids, emb, pe, scale, B, To, dtype, y=None, drop_p=0.0, drop_seed=0):
     V, d = emb.shape
     _chk_i32(ids)
     _chk_f32(emb, pe)
     assert ids.numel() == B * To and pe.shape[-1] == d and pe.shape[-2] >= To
     y = torch.empty(B * To, d, dtype=dtype, device=emb.device) if y is None else y
-    check(lib.asr_embed_pe_fwd(_p(ids), _p(emb), _p(pe), _p(y), float(scale), B, To, d, V, _dt(y), _stream()),
-          "asr_embed_pe_fwd")
+    check(lib.asr_embed_pe_fwd(_p(ids), _p(emb), _p(pe), _p(y), float(scale), B, To, d, V, float(drop_p),
+                               int(drop_seed) & 0xFFFFFFFF, _dt(y), _stream()), "asr_embed_pe_fwd")
     return y
 
 
-def embed_bwd(ids, dy, demb, scale):
+def embed_bwd(ids, dy, demb, scale, drop_p=0.0, drop_seed=0):
     V, d = demb.shape
     _chk_i32(ids)
     _chk_f32(demb)
     assert dy.is_contiguous() and dy.shape[-1] == d and dy.numel() == ids.numel() * d
-    check(lib.asr_embed_bwd(_p(ids), _p(dy), _p(demb), float(scale), ids.numel(), d, V, _dt(dy), _stream()),
-          "asr_embed_bwd")
+    check(lib.asr_embed_bwd(_p(ids), _p(dy), _p(demb), float(scale), ids.numel(), d, V, float(drop_p),
+                            int(drop_seed) & 0xFFFFFFFF, _dt(dy), _stream()), "asr_embed_bwd")
+
+
+def dropout_mask(rows, cols, drop_p, drop_seed, device="cuda"):
+    """(rows, cols) uint8 keep mask of the LayerNorm / embedding dropout sites (tests)."""
+    m = torch.empty(rows, cols, dtype=torch.uint8, device=device)
+    check(lib.asr_dropout_mask(_p(m), rows, cols, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream()), "asr_dropout_mask")
+    return m
+
+
+def sdpa_dropout_mask(B, H, Tq, Tk, drop_p, drop_seed, device="cuda"):
+    m = torch.empty(B, H, Tq, Tk, dtype=torch.uint8, device=device)
+    check(lib.asr_sdpa_dropout_mask(_p(m), B, H, Tq, Tk, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream()), "asr_sdpa_dropout_mask")
+    return m
 
 
 # --------------------------------------------------------------------------------- elementwise

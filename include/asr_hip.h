@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 1
+#define ASR_ABI_VERSION 2
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -60,24 +60,35 @@ int asr_last_error(char* buf, size_t n);
  *   z = x + res (res may be NULL);  xhat = (z - mean) * rstd  (eps 1e-5, biased variance)
  *   y = xhat * gamma + beta  (+ pe[t] if pe != NULL)   ;   y = 0 for rows t >= lens[b] if lens
  * x, res, y, xhat: (B*T, d) `dtype`; xhat may alias x.  gamma, beta: (d) f32; pe: (>=T, d) f32;
- * rstd: (B*T) f32; lens: (B) int32 or NULL.  d must be a multiple of 64 and <= 2048.
+ * rstd: (B*T) f32; lens: (B) int32 or NULL.  d <= 2048.
+ * Dropout (drop_p > 0; reference sites attention.py:59, module.py:73, transformer_official.py:175):
+ *   drop_mode ASR_DROP_PRE : x is dropped (x * keep / (1-p)) before the residual add;
+ *   drop_mode ASR_DROP_POST: the output (after the PE add, before pad zeroing) is dropped.
+ * The keep mask of element (row, col) is a counter hash of (row*d + col, drop_seed): forward and
+ * backward regenerate it, nothing is stored (asr_dropout_mask materialises it for tests).
  */
+#define ASR_DROP_PRE 1
+#define ASR_DROP_POST 2
 int asr_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                    const float* pe, const int32_t* lens, void* y, void* xhat, float* rstd,
-                   int B, int T, int d, int dtype, void* stream);
+                   int B, int T, int d, float drop_p, uint32_t drop_seed, int drop_mode, int dtype,
+                   void* stream);
 
 /* Backward of the above.  dy (+ dy2 if not NULL) is the gradient wrt y.
  *   g = (dy + dy2) * mask * gamma ;  dz = rstd * (g - mean(g) - xhat * mean(g * xhat))
  * dz: (B*T, d) `dtype` (gradient wrt x and wrt res).  Column sums over all rows are ACCUMULATED
  * (+=) into f32 vectors: dgamma += sum (dy*mask*xhat), dbeta += sum (dy*mask), and, if dbias is
  * not NULL, dbias += sum dz (bias gradient of the GEMM that produced x).
+ * With ASR_DROP_PRE dropout the gradient wrt x differs from the residual gradient: dz stays the
+ * residual gradient and dx (required then, (B*T, d) `dtype`) receives dz * keep / (1-p); dbias sums
+ * dx.  With ASR_DROP_POST the mask is applied to (dy + dy2) first.  dx may be NULL otherwise.
  * ws: asr_add_ln_bwd_workspace_bytes(B*T, d) bytes of scratch.
  */
 size_t asr_add_ln_bwd_workspace_bytes(int rows, int d);
 int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat, const float* rstd,
-                   const float* gamma, const int32_t* lens, void* dz, float* dgamma, float* dbeta,
-                   float* dbias, void* ws, size_t ws_bytes, int B, int T, int d, int dtype,
-                   void* stream);
+                   const float* gamma, const int32_t* lens, void* dz, void* dx, float* dgamma,
+                   float* dbeta, float* dbias, void* ws, size_t ws_bytes, int B, int T, int d,
+                   float drop_p, uint32_t drop_seed, int drop_mode, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked scaled-dot-product attention, flash style (scores never materialised).
@@ -90,17 +101,28 @@ int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat, const floa
  * Key j is visible to query i of utterance b iff  j < k_len[b]  and (!causal or j <= i)
  * and (window < 0 or |i - j| <= window).  lse: (B, H, Tq) f32 = log sum exp of scaled scores.
  * ASR_BF16 runs on MFMA (dk must be 64); ASR_F32 is an exact-fp32 VALU path (dk <= 128).
+ * drop_p > 0: dropout on the attention probabilities after the softmax (attention.py:83): the
+ * output uses p * keep / (1-p), the normaliser does not.  Mask of (b,h,q,k) = counter hash of
+ * (((b*H+h)*Tq+q)*Tk_even + k, drop_seed), Tk_even = Tk rounded up to even.
  */
 int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
-                 int ldv, int ldo, int causal, int window, float scale, int dtype, void* stream);
+                 int ldv, int ldo, int causal, int window, float scale, float drop_p,
+                 uint32_t drop_seed, int dtype, void* stream);
 
 /* Backward: given do (same layout as o) computes dq, dk, dv (layouts/strides of q, k, v).
  * delta: (B, H, Tq) f32 scratch (rowsum(do*o)), written by the call. */
 int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                  const float* lse, float* delta, void* dq, void* dk_, void* dv,
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
-                 int ldv, int ldo, int causal, int window, float scale, int dtype, void* stream);
+                 int ldv, int ldo, int causal, int window, float scale, float drop_p,
+                 uint32_t drop_seed, int dtype, void* stream);
+
+/* Test helpers: materialise the keep masks the kernels regenerate (1 = kept), uint8.
+ * asr_dropout_mask: (rows, cols) mask of the LayerNorm / embedding sites;
+ * asr_sdpa_dropout_mask: (B, H, Tq, Tk) mask of the attention-probability site. */
+int asr_dropout_mask(uint8_t* mask, int rows, int cols, float drop_p, uint32_t drop_seed, void* stream);
+int asr_sdpa_dropout_mask(uint8_t* mask, int B, int H, int Tq, int Tk, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CTC loss, forward-backward, fused with log-softmax over the vocabulary.
@@ -147,13 +169,14 @@ int asr_dec_preprocess(const int64_t* tgt, int32_t* ys_in, int32_t* ys_out, int3
 /* Embedding gather * scale + positional encoding.
  * Replaces:  tgt_word_emb(ys_in) * x_logit_scale + positional_encoding
  *              transformer_official.py:306-307
- * ids: (B*To) int32; emb: (V, d) `wdtype` storage of the embedding used for the gather;
- * pe: (>=To, d) f32; y: (B*To, d) `dtype`. */
+ * ids: (B*To) int32; emb: (V, d) f32 master embedding; pe: (>=To, d) f32; y: (B*To, d) `dtype`.
+ * drop_p > 0: dropout on the output (transformer_official.py:306), mask as in asr_dropout_mask. */
 int asr_embed_pe_fwd(const int32_t* ids, const void* emb, const float* pe, void* y, float scale,
-                     int B, int To, int d, int V, int dtype, void* stream);
-/* demb (V, d) f32 += scale * scatter-add over rows of dy ((B*To, d) `dtype`). */
+                     int B, int To, int d, int V, float drop_p, uint32_t drop_seed, int dtype,
+                     void* stream);
+/* demb (V, d) f32 += scale * scatter-add over rows of (dy * keep / (1-p)) ((B*To, d) `dtype`). */
 int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, float scale, int rows, int d,
-                  int V, int dtype, void* stream);
+                  int V, float drop_p, uint32_t drop_seed, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Elementwise / reductions used between GEMMs.

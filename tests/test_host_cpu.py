@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/asr_hip.h but not exported by libasr_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert _lib.lib.asr_abi_version() == 1
+    assert _lib.lib.asr_abi_version() == 2
     # argument counts of the binding match the header declarations
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "asr_hip.h")).read(), flags=re.S)
     for n in names:
@@ -48,7 +48,7 @@ def test_library_is_gfx950_only_and_has_no_torch_types():
 def test_error_reporting_without_gpu():
     """Argument validation happens on the host before any launch: callable without a GPU."""
     from asr_chinese_e2e_amd import _lib
-    rc = _lib.lib.asr_add_ln_fwd(None, None, None, None, None, None, None, None, None, 1, 1, 8, 0, None)
+    rc = _lib.lib.asr_add_ln_fwd(None, None, None, None, None, None, None, None, None, 1, 1, 8, 0.0, 0, 0, 0, None)
     assert rc == -1 and "null pointer" in _lib.last_error()
     rc = _lib.lib.asr_ctc_workspace_bytes(32, 500, 22)
     assert rc == (3 * 32 * 500 * 48 + 32 * 500 + 32) * 4
@@ -143,15 +143,15 @@ def test_model_state_dict_matches_reference_keys_and_shapes():
         assert np.allclose(mine["encoder.positional_encoding.pe"][:, :64].numpy(), z["pe_head/encoder.positional_encoding.pe"], atol=1e-6)
 
 
-def test_default_config_and_dropout_guard():
+def test_default_config():
     from asr_chinese_e2e_amd import Models
     from asr_chinese_e2e_amd.data_handler import Vocab
     C = Models.TransformerOffical.get_default_config()
     c = C()
     assert (c.d_model, c.hidden_size, c.ff_size, c.num_head, c.layer_num, c.dropout) == (512, 64, 1024, 8, 6, 0.1)
     c.fn_build(dict(n_mels=80, lfr_m=4))
-    with pytest.raises(NotImplementedError):
-        Models.TransformerOffical(c, Vocab.synthetic(20))     # dropout 0.1 is not silently ignored
+    m = Models.TransformerOffical(c, Vocab.synthetic(20))     # the reference default (dropout 0.1) constructs
+    assert m.config.dropout == 0.1
     assert getattr(Models, "TransformerOffical") and getattr(Models, "TransformerCTC")
 
 

@@ -77,7 +77,8 @@ def test_add_ln(K, ws, dtype, d, use_res, use_pe, use_len):
     close(y, yr, **TOL[dtype], what="ln fwd")
     dgamma, dbeta, dbias = (torch.zeros(d, device=DEV) for _ in range(3))
     dgamma += 1.0  # accumulate semantics
-    dz = K.add_ln_bwd(to(dy), to(dy2), xhat, rstd, to(gamma), to(lens), dgamma, dbeta, dbias, B, T, ws)
+    dz, dxg = K.add_ln_bwd(to(dy), to(dy2), xhat, rstd, to(gamma), to(lens), dgamma, dbeta, dbias, B, T, ws)
+    assert dxg is dz
     gt = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=6e-2)
     close(dz, xr.grad, **gt, what="ln dz")
     close(dgamma - 1.0, g64.grad, rtol=gt["rtol"], atol=gt["atol"] * 4, what="ln dgamma")
@@ -465,3 +466,101 @@ def test_logmel_lfr(K):
     z = load_npz("ops.npz")
     x9 = z["lfr/x9"]
     assert np.array_equal(logmel_ref.build_lfr(x9, 3, 1), z["lfr/x9_m3n1"])
+
+
+# ------------------------------------------------------------------------------------ dropout
+def test_dropout_mask_statistics(K):
+    for p in (0.1, 0.5):
+        m = K.dropout_mask(512, 1024, p, 1234).float()
+        assert abs(float(m.mean()) - (1 - p)) < 3e-3
+        assert abs(float(m[:, 0::2].mean()) - float(m[:, 1::2].mean())) < 5e-3          # both halves of the pair hash
+        m2 = K.dropout_mask(512, 1024, p, 1235).float()
+        assert 0.3 * p < float((m != m2).float().mean()) < 2.2 * p * (1 - p) + 0.05       # seeds decorrelate
+    assert float(K.dropout_mask(8, 64, 0.0, 7).float().mean()) == 1.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode,d", [(1, 512), (2, 512), (1, 48)])
+def test_add_ln_dropout(K, ws, dtype, mode, d):
+    """Forward/backward with the kernel's own (regenerated) mask fed explicitly to the oracle."""
+    torch.manual_seed(d + mode)
+    B, T, p, seed = 2, 19, 0.3, 4242
+    x = torch.randn(B * T, d).to(dtype)
+    res = torch.randn(B * T, d).to(dtype)
+    gamma, beta = 1 + 0.2 * torch.randn(d), 0.1 * torch.randn(d)
+    pe = R.positional_encoding(32, d) if mode == 2 else None
+    lens = torch.tensor([19, 11], dtype=torch.int32)
+    dy = torch.randn(B * T, d).to(dtype)
+    mask = K.dropout_mask(B * T, d, p, seed).cpu().double() / (1 - p)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    z = (xr * mask if mode == 1 else xr) + rr
+    yr = F.layer_norm(z, (d,), g64, b64, 1e-5)
+    if mode == 2:
+        yr = (yr + pe[:T].double().repeat(B, 1)) * mask
+    keep = (torch.arange(T).unsqueeze(0) < lens.view(-1, 1)).reshape(-1, 1).double()
+    yr = yr * keep
+    (yr * dy.double()).sum().backward()
+    to = lambda t: None if t is None else t.to(DEV)
+    y, xhat, rstd = K.add_ln_fwd(to(x), to(res), to(gamma), to(beta), to(pe), to(lens), B, T, drop_p=p, drop_seed=seed, drop_mode=mode)
+    close(y, yr, **TOL[dtype], what="ln dropout fwd")
+    dgamma, dbeta, dbias = (torch.zeros(d, device=DEV) for _ in range(3))
+    dz, dxg = K.add_ln_bwd(to(dy), None, xhat, rstd, to(gamma), to(lens), dgamma, dbeta, dbias, B, T, ws, drop_p=p, drop_seed=seed, drop_mode=mode)
+    gt = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=6e-2)
+    close(dz, rr.grad, **gt, what="ln dropout dres")
+    close(dxg, xr.grad, **gt, what="ln dropout dx")
+    close(dbias, xr.grad.sum(0), rtol=gt["rtol"], atol=gt["atol"] * 4, what="ln dropout dbias")
+    close(dgamma, g64.grad, rtol=gt["rtol"], atol=gt["atol"] * 4, what="ln dropout dgamma")
+
+
+@pytest.mark.parametrize("dtype,B,H,Tq,Tk,dk,causal", [(torch.float32, 2, 2, 9, 12, 16, False), (torch.bfloat16, 2, 2, 130, 130, 64, False),
+                                                     (torch.bfloat16, 1, 2, 70, 200, 64, False), (torch.bfloat16, 2, 2, 96, 96, 64, True)])
+def test_sdpa_dropout(K, dtype, B, H, Tq, Tk, dk, causal):
+    torch.manual_seed(Tq + Tk)
+    p, seed, d = 0.2, 99, H * dk
+    q = torch.randn(B * Tq, d).to(dtype)
+    kv = torch.randn(B * Tk, 2 * d).to(dtype)
+    do = torch.randn(B * Tq, d).to(dtype)
+    klen = torch.tensor([Tk, max(Tk // 2, 1)][:B], dtype=torch.int32)
+    scale = dk ** -0.5
+    mask = K.sdpa_dropout_mask(B, H, Tq, Tk, p, seed).cpu().double() / (1 - p)
+    qr = q.double().reshape(B, Tq, H, dk).clone().requires_grad_(True)
+    kr = kv[:, :d].double().reshape(B, Tk, H, dk).clone().requires_grad_(True)
+    vr = kv[:, d:].double().reshape(B, Tk, H, dk).clone().requires_grad_(True)
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * scale
+    vis = torch.arange(Tk).view(1, 1, 1, Tk) < klen.view(B, 1, 1, 1)
+    if causal:
+        vis = vis & (torch.arange(Tk).view(1, 1, 1, Tk) <= torch.arange(Tq).view(1, 1, Tq, 1))
+    pr = torch.softmax(s.masked_fill(~vis, float("-inf")), -1) * mask           # attention.py:82-83
+    o_ref = torch.einsum("bhqk,bkhd->bqhd", pr, vr)
+    (o_ref * do.double().reshape(B, Tq, H, dk)).sum().backward()
+    g = kv.to(DEV)
+    qd = q.to(DEV)
+    o, lse = K.sdpa_fwd(qd, g[:, :d], g[:, d:], klen.to(DEV), B, H, Tq, Tk, dk, causal, -1, scale, drop_p=p, drop_seed=seed)
+    ft = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    close(o.reshape(B, Tq, H, dk), o_ref, **ft, what="sdpa dropout o")
+    dq = torch.empty_like(qd)
+    dg = torch.empty_like(g)
+    K.sdpa_bwd(qd, g[:, :d], g[:, d:], o, do.to(DEV), lse, klen.to(DEV), B, H, Tq, Tk, dk, dq, dg[:, :d], dg[:, d:], causal, -1, scale,
+               drop_p=p, drop_seed=seed)
+    gt = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=5e-2)
+    close(dq.reshape(B, Tq, H, dk), qr.grad, **gt, what="sdpa dropout dq")
+    close(dg[:, :d].reshape(B, Tk, H, dk), kr.grad, **gt, what="sdpa dropout dk")
+    close(dg[:, d:].reshape(B, Tk, H, dk), vr.grad, **gt, what="sdpa dropout dv")
+
+
+def test_embed_dropout(K):
+    torch.manual_seed(0)
+    V, d, B, To, p, seed = 30, 48, 3, 6, 0.25, 5
+    emb = torch.randn(V, d)
+    ids = torch.randint(0, V, (B, To), dtype=torch.int32)
+    pe = R.positional_encoding(16, d)
+    mask = K.dropout_mask(B * To, d, p, seed).cpu().float() / (1 - p)
+    y = K.embed_pe_fwd(ids.to(DEV).reshape(-1), emb.to(DEV), pe.to(DEV), d ** -0.5, B, To, torch.float32, drop_p=p, drop_seed=seed)
+    ref = (emb[ids.long()] * d ** -0.5 + pe[:To].unsqueeze(0)).reshape(B * To, d) * mask
+    close(y, ref, rtol=1e-6, atol=1e-6, what="embed dropout fwd")
+    dy = torch.randn(B * To, d)
+    demb = torch.zeros(V, d, device=DEV)
+    K.embed_bwd(ids.to(DEV).reshape(-1), dy.to(DEV), demb, d ** -0.5, drop_p=p, drop_seed=seed)
+    refg = torch.zeros(V, d).index_add_(0, ids.long().reshape(-1), dy * mask * d ** -0.5)
+    close(demb, refg, rtol=1e-5, atol=1e-5, what="embed dropout bwd")

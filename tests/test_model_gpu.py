@@ -223,3 +223,39 @@ def test_no_cpu_fallback():
     model = build(cfg, 20)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model.forward(to_pack(batch, "cpu"))
+
+
+def test_dropout_training_and_eval_modes():
+    """Reference default dropout 0.1: eval mode ignores it (identical to a dropout-0 model), train
+    mode is reproducible for a given step seed, differs between steps, and still learns."""
+    from asr_chinese_e2e_amd.data_handler import synthetic_pack
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, ctc_weight=0.3)
+    cfg, sd, batch = oracle_case(4, 64, 80, 40, 8, over, seed=4, ragged=True)
+    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
+    sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    pack = to_pack(batch)
+    m0 = build(cfg, 40, dtype="bf16").cuda()
+    m0.load_state_dict(sd)
+    m1 = build(cfg, 40, dtype="bf16", dropout=0.1).cuda()
+    m1.load_state_dict(sd)
+    m0.eval(); m1.eval()
+    a, _ = m0.iterate(pack, is_train=False)
+    b, _ = m1.iterate(pack, is_train=False)
+    assert float(a.loss) == float(b.loss)
+    m1.train()
+    m1._ensure_engine(DEV)
+    losses = []
+    for seed in (7, 7, 8):
+        m1._step_seed = seed
+        m1.zero_flat_grads()
+        loss, _ = m1.train_step(pack)
+        losses.append((float(loss[0]), float(m1._flat.g.abs().sum())))
+    assert losses[0] == losses[1]                       # same seed -> same masks, bit-identical step
+    assert losses[0][0] != losses[2][0]                 # next step -> new masks
+    assert abs(losses[0][0] - float(a.loss)) < 0.25 * abs(float(a.loss))
+    opt = make_opt(m1, cfg, 10)
+    first = None
+    for i in range(12):
+        m, _ = m1.iterate(pack, optimizer=opt, is_train=True)
+        first = float(m.loss) if first is None else first
+    assert np.isfinite(float(m.loss)) and float(m.loss) < first
