@@ -274,8 +274,9 @@ class Engine:
             if bias_from is not None:
                 lin.bgrad(bias_from, self.ws_side)
             lin.wgrad(dy, x)
-        for t in (dy, x):
-            t.record_stream(self.side)
+        if not torch.cuda.is_current_stream_capturing():   # graph pools never recycle during capture
+            for t in (dy, x):
+                t.record_stream(self.side)
 
     def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross, site):
         """x: (B*Tq, d) queries + residual; kv_src: (B*Tk, d).  Returns output and cache."""

@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--vocab", type=int, default=4232)
     ap.add_argument("--window", type=int, default=-1)
+    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step instead of eager launches "
+                    "(measured SLOWER on MI355X/ROCm 7: 5.21 vs 4.88 ms CTC-only, 8.81 vs 8.42 ms joint - the step is GPU-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
@@ -120,7 +123,7 @@ def main():
     joint = args.config == "joint"
     Model = Models.TransformerOffical if joint else Models.TransformerCTC
     cfg = Model.get_default_config()()
-    cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=0.0, layer_num=args.layers, ctc_weight=0.3 if joint else 1.0, dtype="bf16",
+    cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=args.dropout, layer_num=args.layers, ctc_weight=0.3 if joint else 1.0, dtype="bf16",
                       attn_window=args.window, cer_in_iterate=False, warm_up=4000))
     torch.manual_seed(0)
     model = Model(cfg, Vocab.synthetic(args.vocab)).to(dev)
@@ -128,8 +131,13 @@ def main():
     opt = NoamOpt(cfg.d_model, 1, cfg.warm_up, adam)
     pack = synthetic_pack(args.batch, args.frames, 80, args.vocab, seed=1234 + rank, device=dev, dtype=torch.bfloat16)
     runner = model
+    graphed = False
     if use_dp:
         runner = D.DataParallel(model, dev)
+    elif args.graph and args.dropout == 0.0:
+        from asr_chinese_e2e_amd.graph import GraphedModel
+        runner = GraphedModel(model)          # whole step as one hipGraph (single process, no dropout)
+        graphed = True
 
     def barrier():
         if use_dp:
@@ -158,8 +166,9 @@ def main():
         K.TIMER = timer
         n_inst = min(args.steps, 10)
         model._engine.overlap_wgrad = False   # standalone kernel durations (concurrent streams inflate them)
+        inst_runner = model if graphed else runner          # events cannot be read back from a captured graph
         for _ in range(n_inst):
-            runner.iterate(pack, optimizer=opt, is_train=True)
+            inst_runner.iterate(pack, optimizer=opt, is_train=True)
         barrier()
         K.TIMER = None
         model._engine.overlap_wgrad = True
@@ -180,8 +189,8 @@ def main():
             "config": {"workload": ("configs[2]: joint CTC/attention (lambda=0.3) encoder-decoder" if joint else
                                     "configs[1]: 6-layer Transformer encoder + CTC-only") +
                                    f", bf16, per-GPU batch {args.batch}, T={args.frames}, F=80, V={args.vocab}, "
-                                   f"{args.layers} layers, d_model 512, 8x64 heads, ff 1024, dropout 0.0, "
-                                   "fwd+loss+bwd+clip+Noam/Adam per step",
+                                   f"{args.layers} layers, d_model 512, 8x64 heads, ff 1024, dropout {args.dropout}, "
+                                   "fwd+loss+bwd+clip+Noam/Adam per step" + (", one hipGraph per step" if graphed else ", eager launches"),
                        "global_batch": world * args.batch, "seq_len": args.frames, "parallelism": f"dp{world}"},
         }
         if timer is not None:
