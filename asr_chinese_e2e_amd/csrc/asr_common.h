@@ -129,8 +129,17 @@ static __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const floa
     const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cg;
     float s = 0.f;
-    if (col < ncols)
-        for (int p = pg; p < P; p += 32) s += part[(size_t)p * pstride + col];
+    if (col < ncols) {
+        int p = pg;
+        for (; p + 7 * 32 < P; p += 8 * 32) {   // 8 independent loads in flight (the pass is latency-bound)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u * 32) * pstride + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < P; p += 32) s += part[(size_t)p * pstride + col];
+    }
     red[pg][cg] = s;
     __syncthreads();
     if (pg == 0 && col < ncols) {

@@ -69,7 +69,28 @@ __global__ __launch_bounds__(CS_WAVES* WAVE) void colsum_partial_kernel(T* __res
     const int c0 = blockIdx.x * 256 + lane * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bool full = (c0 + 3 < cols) && (ld % 4 == 0);
-    for (int r = blockIdx.y * CS_WAVES + w; r < rows; r += row_slots * CS_WAVES) {
+    const int rstride = row_slots * CS_WAVES;
+    int r = blockIdx.y * CS_WAVES + w;
+    if (full) {   // 4 rows in flight per lane: the pass is latency-bound with one load per iteration
+        for (; r + 3 * rstride < rows; r += 4 * rstride) {
+            f32x4 v[4], av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = load4<T>(x + (size_t)(r + u * rstride) * ld + c0);
+                if constexpr (RELU_BWD) av[u] = load4<T>(a + (size_t)(r + u * rstride) * ld + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (RELU_BWD) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = av[u][j] > 0.f ? v[u][j] : 0.f;
+                    store4<T>(x + (size_t)(r + u * rstride) * ld + c0, v[u]);
+                }
+                acc += v[u];
+            }
+        }
+    }
+    for (; r < rows; r += rstride) {
         T* p = x + (size_t)r * ld + c0;
         if (full) {
             f32x4 v = load4<T>(p);

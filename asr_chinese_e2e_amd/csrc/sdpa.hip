@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o
 // ---------------------------------------------------------------- backward: dQ
 template <bool DROP>
 __global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                               const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               bf16_t* __restrict__ dq, const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq,
+                                                               const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                               float* __restrict__ delta, bf16_t* __restrict__ dq, const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq,
                                                                int ldk, int ldv, int ldo, int causal, int window, float scale, uint32_t dseed, uint32_t dthr,
                                                                float dscale) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TILE_ELEMS];
@@ -274,7 +274,20 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __r
     const int qi = q0 + (lane & 31);
     const size_t stat = ((size_t)b * H + h) * Tq + min(qi, Tq - 1);
     const float lse2 = lse[stat] * LOG2E;
-    const float dl = delta[stat];
+    // delta = rowsum(dO o O): this wave already holds its 32 dO rows as fragments, so the separate
+    // delta pass (one more read of O and dO, one more launch) is folded in here; the result is also
+    // written out for the dK/dV kernel that runs next on the stream.
+    float dl = 0.f;
+    {
+        bf16x8 of[4];
+        frags_from_global(of, o + (size_t)b * Tq * ldo + h * DK, ldo, q0, Tq, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
+        dl += __shfl_xor(dl, 32, 64);
+        if (lane < 32 && qi < Tq) delta[stat] = dl;
+    }
     const float sc2 = scale * LOG2E;
     f32x16 acc[2];
 #pragma unroll
@@ -635,13 +648,16 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
     const float dscale = 1.f / (1.f - drop_p);
     hipStream_t st = (hipStream_t)stream;
     const int ngroups = B * Tq * H;
-    if (dtype == ASR_F32) sdpa_delta_kernel<float><<<ceil_div(ngroups, 32), 256, 0, st>>>((const float*)o, (const float*)d_o, delta, B, H, Tq, dk, ldo);
-    else sdpa_delta_kernel<bf16_t><<<ceil_div(ngroups, 32), 256, 0, st>>>((const bf16_t*)o, (const bf16_t*)d_o, delta, B, H, Tq, dk, ldo);
-    if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, d_o) && mfma_ok(dk, ldq, ldk, ldv, ldo, dq, dk_, dv, o)) {
+    const bool mfma = dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, d_o) && mfma_ok(dk, ldq, ldk, ldv, ldo, dq, dk_, dv, o);
+    if (!mfma) {   // the MFMA dQ kernel computes delta itself
+        if (dtype == ASR_F32) sdpa_delta_kernel<float><<<ceil_div(ngroups, 32), 256, 0, st>>>((const float*)o, (const float*)d_o, delta, B, H, Tq, dk, ldo);
+        else sdpa_delta_kernel<bf16_t><<<ceil_div(ngroups, 32), 256, 0, st>>>((const bf16_t*)o, (const bf16_t*)d_o, delta, B, H, Tq, dk, ldo);
+    }
+    if (mfma) {
         const int gq = ceil_div(Tq, 128) * H * B, gk = ceil_div(Tk, 128) * H * B;
 #define SDPA_BWD(D)                                                                                                                                        \
     do {                                                                                                                                                   \
-        sdpa_bwd_dq_bf16_kernel<D><<<gq, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq,   \
+        sdpa_bwd_dq_bf16_kernel<D><<<gq, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, delta, (bf16_t*)dq, \
                                                         k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);                  \
         sdpa_bwd_dkv_bf16_kernel<D><<<gk, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk_, \
                                                          (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);    \
