@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o
 
 // ---------------------------------------------------------------- backward: dQ
 template <bool DROP>
-__global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+__global__ __launch_bounds__(256, 3) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16_t* __restrict__ dq, const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq,
                                                                int ldk, int ldv, int ldo, int causal, int window, float scale, uint32_t dseed, uint32_t dthr,
@@ -344,8 +344,10 @@ __global__ __launch_bounds__(256) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------- backward: dK, dV
+// launch bound 2 waves/SIMD: without it the kernel takes 176 arch + 96 accumulator registers = 272
+// of the unified 512-entry file, i.e. ONE workgroup per CU (measured: 134 us, 2.8 waves/CU average)
 template <bool DROP>
-__global__ __launch_bounds__(256) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+__global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                 const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
                                                                 bf16_t* __restrict__ dk_, bf16_t* __restrict__ dv, const int32_t* __restrict__ k_len, int H,
                                                                 int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
