@@ -7,10 +7,10 @@
 //      then gathers the S = 2L+1 lattice inputs lp[b,t,s] = x[l'_s] - lse (row is L1/L2-hot).
 //   2. ctc_alpha_beta : one workgroup of two waves per utterance.  Wave 0 runs the alpha
 //      recursion forward in time, wave 1 the beta recursion backward, state s on lane s%64
-//      (register j = s/64), predecessors via DPP/shuffle (no LDS in the recursion), lattice
+//      (register j = s/64), predecessors via DPP wave shifts (no LDS in the recursion), lattice
 //      inputs prefetched 2 x 8 timesteps ahead in registers so the serial chain never waits on
-//      memory.  Both are renormalised by their running maximum every 8 steps (offsets summed
-//      for the loss), so fp32 round-off does not grow with T.
+//      memory.  Linear domain, rescaled by the column maximum every 2 steps (logs of the scales
+//      summed for the loss): 5 VALU per step instead of 3 exp + 1 log.
 //   3. ctc_grad       : one workgroup per frame.  Wave 0 forms the frame's state posteriors
 //      softmax_s(alpha+beta-lp) (exact: the sum over s is p(l|x) at every t) and scatters them into an LDS
 //      table indexed by label (ds_add_f32), then one streaming pass: read logits, write
@@ -94,12 +94,21 @@ __device__ __forceinline__ float wave_row_lse(const T* __restrict__ x, int V, in
     return m + logf(s);
 }
 
+// ---------------------------------------------------------------------------------- lattice layout
+// The 2L+1 states of the blank-augmented label sequence are kept as two arrays per frame:
+//   blanks  Bk[i] = state 2i     (i = 0..L)        labels  Lb[i] = state 2i+1  (i = 0..L-1)
+// stored as one row of 2W doubles, [Bk 0..W) | Lb 0..W)], W = 32/64/128/256 >= L+1, zero beyond
+// the valid entries.  In this form the recursions need ONE lane shift per step instead of two:
+//   alpha: Bk'[i] = yB (Bk[i] + Lb[i-1])          Lb'[i] = yL[i] (Lb[i] + Bk[i]   + c[i]  Lb[i-1])
+//   beta : Bk'[i] = yB (Bk[i] + Lb[i])            Lb'[i] = yL[i] (Lb[i] + Bk[i+1] + c'[i] Lb[i+1])
+// with c[i] = lab[i] != lab[i-1], c'[i] = lab[i] != lab[i+1] (the skip transitions).
+
 // ---------------------------------------------------------------------------------- kernel 1
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict__ logits, const int32_t* __restrict__ in_len,
                                                              const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                             float* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int Lmax,
-                                                             int Smax, int blank) {
+                                                             double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int Lmax,
+                                                             int W, int blank) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
@@ -108,159 +117,228 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict
         const T* x = logits + (size_t)row * V;
         const float lse = wave_row_lse<T>(x, V, lane, nullptr);
         if (lane == 0) lse_out[row] = lse;
-        const int L = lab_len[b], S = 2 * L + 1;
-        float* out = lp + (size_t)row * Smax;
-        for (int s = lane; s < S; s += 64) {
-            const int c = (s & 1) ? labels[(size_t)b * Lmax + (s >> 1)] : blank;
-            out[s] = to_f32<T>(x[c]) - lse;
+        const int L = lab_len[b];
+        double* out = lp + (size_t)row * 2 * W;
+        const double yb = exp((double)(to_f32<T>(x[blank]) - lse));   // y_t(blank): linear domain, fp64
+        for (int i = lane; i < W; i += 64) {   // zero beyond the valid entries: the recursion runs unpredicated
+            out[i] = i <= L ? yb : 0.0;
+            const int c = labels[(size_t)b * Lmax + min(i, Lmax - 1)];
+            out[W + i] = i < L ? exp((double)(to_f32<T>(x[c]) - lse)) : 0.0;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------- kernel 2
-// whole-wave shifts by one lane through DPP (no LDS round trip as ds_bpermute would need): the
-// lane that has no source keeps -inf.
-__device__ __forceinline__ float wave_shr1(float v) {   // lane i <- lane i-1
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(NEG_INF), __float_as_int(v), 0x138, 0xf, 0xf, false));
+// The recursion runs in the LINEAR domain with rescaling (the classic scaled forward-backward) in
+// fp64 (alpha and beta of one frame can sit > 1e38 apart at the state where their PRODUCT peaks,
+// which fp32 cannot hold once a column is scaled to its maximum): one step is a lane shift, an
+// add, an fma and a multiply instead of 3 exp + 1 log, and the rescaling is an exact power of two
+// folded into a LATER frame's y so that the wave-wide max reduction is off the dependent chain.
+// The kernel is a pure dependent chain on B workgroups: instructions per step are what it costs.
+// log p(l|x) = ln2 * (sum of exponents taken out) + log of the final column; per-frame scale
+// factors cancel in the posterior (it is normalised over the states).
+// Whole-wave shifts by one lane through DPP (no LDS round trip as ds_bpermute would need): the
+// lane that has no source gets 0.
+__device__ __forceinline__ double wave_shr1(double v) {   // lane i <- lane i-1 (two 32-bit DPP moves)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float wave_shl1(float v) {   // lane i <- lane i+1
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(NEG_INF), __float_as_int(v), 0x130, 0xf, 0xf, false));
+__device__ __forceinline__ double wave_shl1(double v) {   // lane i <- lane i+1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
-// NS = states per lane (S <= 64*NS).  dir = 0: alpha (wave 0), 1: beta (wave 1).
-template <int NS>
-__device__ __forceinline__ float ctc_recursion(const float* __restrict__ lp, float* __restrict__ out, const int32_t* __restrict__ lab,
-                                               int Tb, int L, int Smax, int blank, int lane, bool backward) {
-    const int S = 2 * L + 1;
-    float off = 0.f;  // sum of the maxima removed so far: true log value = stored value + off
-    // transition permissions per owned state
-    bool can2[NS];   // alpha: s-2 -> s allowed ; beta: s+2 -> s allowed
-    bool live[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = lane + 64 * j;
-        live[j] = s < S;
-        bool c = false;
-        if (!backward) {
-            if (live[j] && (s & 1) && s >= 2) c = lab[s >> 1] != lab[(s >> 1) - 1];
-        } else {
-            if (s + 2 < S && (s & 1)) c = lab[s >> 1] != lab[(s >> 1) + 1];
-        }
-        can2[j] = c;
-    }
-    constexpr int CH = 8;  // timesteps per prefetch chunk
-    float a[NS];
-    float buf0[CH][NS], buf1[CH][NS];
-    auto fetch = [&](float (&dst)[CH][NS], int chunk) {
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int step = chunk * CH + k;
-            const int t = backward ? Tb - 1 - step : step;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const int s = lane + 64 * j;
-                dst[k][j] = (step < Tb && live[j]) ? lp[(size_t)t * Smax + s] : NEG_INF;
-            }
-        }
-    };
-    auto advance = [&](const float (&cur)[CH][NS], int chunk) {
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int step = chunk * CH + k;
-            if (step >= Tb) break;
-            const int t = backward ? Tb - 1 - step : step;
-            if (k == 0 && chunk > 0) {
-                // renormalise once per chunk: keeps |a| small, so fp32 round-off does not grow with T.
-                // Any per-timestep constant cancels in the posterior (it is normalised over s).
-                float mx = NEG_INF;
-#pragma unroll
-                for (int j = 0; j < NS; ++j) mx = fmaxf(mx, a[j]);
-                mx = wave_max(mx);
-                if (mx != NEG_INF) {
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) a[j] -= mx;
-                    off += mx;
-                }
-            }
-            if (step == 0) {
-#pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    const int s = lane + 64 * j;
-                    const bool init = backward ? (s == S - 1 || s == S - 2) : (s == 0 || s == 1);
-                    a[j] = (init && live[j]) ? cur[k][j] : NEG_INF;
-                }
-            } else {
-                float n1[NS], n2[NS];
-                if (!backward) {
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) {
-                        float u1 = wave_shr1(a[j]);
-                        float u2 = wave_shr1(u1);
-                        // lanes 0/1 take their predecessors from the previous register's top lanes
-                        const float p1 = j > 0 ? lane_bcast(a[j > 0 ? j - 1 : 0], 63) : NEG_INF;
-                        const float p2a = j > 0 ? lane_bcast(a[j > 0 ? j - 1 : 0], 62) : NEG_INF;
-                        if (lane == 0) { u1 = p1; u2 = p2a; }
-                        if (lane == 1) { u2 = p1; }
-                        n1[j] = u1;
-                        n2[j] = can2[j] ? u2 : NEG_INF;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) {
-                        float u1 = wave_shl1(a[j]);
-                        float u2 = wave_shl1(u1);
-                        const float p1 = j + 1 < NS ? lane_bcast(a[j + 1 < NS ? j + 1 : j], 0) : NEG_INF;
-                        const float p2a = j + 1 < NS ? lane_bcast(a[j + 1 < NS ? j + 1 : j], 1) : NEG_INF;
-                        if (lane == 63) { u1 = p1; u2 = p2a; }
-                        if (lane == 62) { u2 = p1; }
-                        n1[j] = u1;
-                        n2[j] = can2[j] ? u2 : NEG_INF;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    const float m = fmaxf(fmaxf(a[j], n1[j]), n2[j]);
-                    float r = NEG_INF;
-                    // hardware exp2/log2 (1 ulp): the recursion is renormalised every 8 steps, so the
-                    // absolute log-domain error stays ~1e-6 per step
-                    if (m != NEG_INF) r = m + __logf(__expf(a[j] - m) + __expf(n1[j] - m) + __expf(n2[j] - m)) + cur[k][j];
-                    a[j] = live[j] ? r : NEG_INF;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const int s = lane + 64 * j;
-                if (live[j]) out[(size_t)t * Smax + s] = a[j];
-            }
-        }
-    };
-    const int nchunks = (Tb + CH - 1) / CH;
-    fetch(buf0, 0);
-    for (int c = 0; c < nchunks; c += 2) {
-        fetch(buf1, c + 1);
-        advance(buf0, c);
-        fetch(buf0, c + 2);
-        advance(buf1, c + 1);
-    }
-    return off;
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// max over the 64 lanes of unsigned values, DPP only (prefix max inside each 16-lane row, then
+// row broadcasts); the result is uniform.  Used on the HIGH words of non-negative doubles, whose
+// bit patterns order like the values.
+// LAST = highest active lane (63, or 31 when only half the wave runs).
+template <int LAST>
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define DPP_MAX(ctrl, rmask)                                                                                   \
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
+    DPP_MAX(0x111, 0xf);   // row_shr:1
+    DPP_MAX(0x112, 0xf);   // row_shr:2
+    DPP_MAX(0x114, 0xf);   // row_shr:4
+    DPP_MAX(0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds the row maximum
+    DPP_MAX(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    if (LAST == 63) DPP_MAX(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave maximum
+#undef DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, LAST);
 }
 
-template <int NS>
-__global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __restrict__ lp, float* __restrict__ alpha, float* __restrict__ beta,
+// W = row half-width (compile time: 32, 64, 128, 256), NS = registers per lane per array (entry
+// i = lane + 64 j).  Every load and store of the steady-state loop is unconditional, at an
+// immediate offset from one running pointer, and the loop body is one basic block, so the
+// compiler counts outstanding memory operations (s_waitcnt vmcnt(N), N > 0) and the prefetched
+// chunk really overlaps the dependent chain.  (With predicated loads it fell back to vmcnt(0)
+// per chunk: ~1.5 us of exposed latency 60 times per utterance.)
+// Returns ln of the scale taken out (true value = stored value * exp(ret)), or -inf once every
+// state has become 0 (infeasible alignment).
+template <int W, bool BWD>
+__device__ __forceinline__ double ctc_recursion(const double* __restrict__ y, double* __restrict__ out, const int32_t* __restrict__ lab,
+                                                int Tb, int L, int lane) {
+    constexpr int NS = W <= 64 ? 1 : W / 64;
+    constexpr ptrdiff_t RW = 2 * W;             // row stride
+    constexpr ptrdiff_t DT = BWD ? -RW : RW;    // the frame of recursion step k is t = k (alpha) or Tb-1-k (beta)
+    int esum = 0;          // sum of the binary exponents scaled away so far
+    bool dead = false;     // every state reached 0
+    double skip[NS];       // 1.0 where the label-to-label skip transition into (alpha) / out of (beta) Lb[i] exists
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int i = lane + 64 * j;
+        bool c;
+        if (!BWD) c = i >= 1 && i < L && lab[i] != lab[i - 1];
+        else c = i + 1 < L && lab[i] != lab[i + 1];
+        skip[j] = c ? 1.0 : 0.0;
+    }
+    const double* yp = y + (BWD ? (size_t)(Tb - 1) * RW : 0) + lane;   // step 0
+    double* op = out + (BWD ? (size_t)(Tb - 1) * RW : 0) + lane;
+    double bk[NS], lb[NS];
+    // step 0: the two entry states (alpha: Bk[0], Lb[0]; beta: Bk[L], Lb[L-1])
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int i = lane + 64 * j;
+        bk[j] = (BWD ? i == L : i == 0) ? yp[64 * j] : 0.0;
+        lb[j] = (BWD ? i == L - 1 : i == 0) ? yp[W + 64 * j] : 0.0;
+        op[64 * j] = bk[j];
+        op[W + 64 * j] = lb[j];
+    }
+    constexpr int CH = 8;  // steps per prefetch chunk; chunk c covers steps 1 + c*CH .. c*CH + CH
+    const int nsteps = Tb - 1;            // recursion steps 1 .. Tb-1
+    struct Chunk { double b[CH][NS], l[CH][NS]; };
+    Chunk c0, c1;
+    auto fetch = [&](Chunk& d, const double* p) {   // p = row of the chunk's first step
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                d.b[k][j] = p[k * DT + 64 * j];
+                d.l[k][j] = p[k * DT + W + 64 * j];
+            }
+    };
+    auto fetch_clamped = [&](Chunk& d, int chunk) {   // rows past the last frame are clamped to it (never used)
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int step = min(1 + chunk * CH + k, nsteps);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                d.b[k][j] = yp[(ptrdiff_t)step * DT + 64 * j];
+                d.l[k][j] = yp[(ptrdiff_t)step * DT + W + 64 * j];
+            }
+        }
+    };
+    double sc = 1.0;   // power-of-two scale waiting to be applied
+    int e_pending = 0;
+    auto one_step = [&](const double (&ybk)[NS], const double (&ylk)[NS], double* o, int k) {
+        double yb[NS], yl[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { yb[j] = ybk[j]; yl[j] = ylk[j]; }
+        if ((k & 3) == 1) {   // apply the scale found two steps ago: off the chain, it multiplies y
+#pragma unroll
+            for (int j = 0; j < NS; ++j) { yb[j] *= sc; yl[j] *= sc; }
+            esum += e_pending;
+        }
+        double nb[NS], nl[NS];
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                double sh = wave_shr1(lb[j]);          // Lb[i-1]
+                if (j > 0) sh = lane == 0 ? lane_bcast(lb[j > 0 ? j - 1 : 0], 63) : sh;
+                nb[j] = yb[j] * (bk[j] + sh);
+                nl[j] = yl[j] * fma(skip[j], sh, lb[j] + bk[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                double sb = wave_shl1(bk[j]);          // Bk[i+1]
+                double sl = wave_shl1(lb[j]);          // Lb[i+1]
+                if (j + 1 < NS) {
+                    sb = lane == 63 ? lane_bcast(bk[j + 1 < NS ? j + 1 : j], 0) : sb;
+                    sl = lane == 63 ? lane_bcast(lb[j + 1 < NS ? j + 1 : j], 0) : sl;
+                }
+                nb[j] = yb[j] * (bk[j] + lb[j]);
+                nl[j] = yl[j] * fma(skip[j], sl, lb[j] + sb);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { bk[j] = nb[j]; lb[j] = nl[j]; }
+        if ((k & 3) == 3) {
+            // Every 4th step: binary exponent e of the column maximum (integer DPP max over the
+            // doubles' high words); 2^-e is applied two steps later.  No division, no log: the
+            // loss only needs the SUM of the exponents.  Six steps shrink the maximum by y^6, far
+            // inside the fp64 range for any y a softmax can produce.  Branch-free.
+            unsigned hi = 0u;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) hi = max(hi, max((unsigned)__double2hiint(bk[j]), (unsigned)__double2hiint(lb[j])));
+            hi = wave_max_u32<(W < 64 ? W : 64) - 1>(hi);
+            const bool zero = (hi >> 20) == 0u;            // all states 0 (or denormal: treated as dead)
+            e_pending = zero ? 0 : (int)(hi >> 20) - 1023;
+            sc = __hiloint2double((1023 - e_pending) << 20, 0);
+            dead |= zero;
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            o[64 * j] = bk[j];
+            o[W + 64 * j] = lb[j];
+        }
+    };
+    const int nfull = nsteps / CH;
+    int c = 0;
+    fetch_clamped(c0, 0);
+    const double* yq = yp + DT;   // row of step 1 + c*CH
+    double* oq = op + DT;
+    // steady state: chunks c+1 and c+2 are full, every access unconditional
+    for (; c + 3 <= nfull; c += 2) {
+        fetch(c1, yq + CH * DT);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) one_step(c0.b[k], c0.l[k], oq + k * DT, k);
+        fetch(c0, yq + 2 * CH * DT);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) one_step(c1.b[k], c1.l[k], oq + (CH + k) * DT, k);
+        yq += 2 * CH * DT;
+        oq += 2 * CH * DT;
+    }
+    // the last (at most three full and one partial) chunks; c0 holds chunk c
+    for (; c * CH < nsteps; ++c) {
+        fetch_clamped(c1, c + 1);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (1 + c * CH + k > nsteps) break;
+            one_step(c0.b[k], c0.l[k], oq + k * DT, k);
+        }
+        oq += CH * DT;
+        c0 = c1;
+    }
+    return dead ? -INFINITY : (double)esum * 0.6931471805599453;
+}
+
+template <int W>
+__global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const double* __restrict__ lp, double* __restrict__ alpha, double* __restrict__ beta,
                                                              const int32_t* __restrict__ in_len, const int32_t* __restrict__ labels,
                                                              const int32_t* __restrict__ lab_len, float* __restrict__ nll_out, float* __restrict__ nll_raw,
-                                                             int T_, int Lmax, int Smax, int blank, int zero_infinity) {
+                                                             int T_, int Lmax, int blank, int zero_infinity) {
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int Tb = in_len[b], L = lab_len[b], S = 2 * L + 1;
-    const float* lpb = lp + (size_t)b * T_ * Smax;
-    float* ab = alpha + (size_t)b * T_ * Smax;
-    float* bb = beta + (size_t)b * T_ * Smax;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: each wave runs only its own direction
+    const int Tb = in_len[b], L = lab_len[b];
+    constexpr size_t RW = 2 * (size_t)W;
+    const double* lpb = lp + (size_t)b * T_ * RW;
+    double* ab = alpha + (size_t)b * T_ * RW;
+    double* bb = beta + (size_t)b * T_ * RW;
     const int32_t* lab = labels + (size_t)b * Lmax;
-    __shared__ float s_off;
-    float off = 0.f;
-    if (Tb > 0) off = ctc_recursion<NS>(lpb, w == 0 ? ab : bb, lab, Tb, L, Smax, blank, lane, w == 1);
-    if (threadIdx.x == 0) s_off = off;  // wave 0 = alpha
+    __shared__ double s_logc;
+    if (Tb > 0 && (W >= 64 || lane < W)) {   // W = 32: half a wave
+        if (w == 0) {
+            const double logc = ctc_recursion<W, false>(lpb, ab, lab, Tb, L, lane);
+            if (lane == 0) s_logc = logc;
+        } else {
+            ctc_recursion<W, true>(lpb, bb, lab, Tb, L, lane);
+        }
+    }
     __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -268,10 +346,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
         if (Tb <= 0) {
             nll = (L == 0) ? 0.f : INFINITY;
         } else {
-            const float* last = ab + (size_t)(Tb - 1) * Smax;
-            const float l1 = last[S - 1], l2 = S > 1 ? last[S - 2] : NEG_INF;
-            const float m = fmaxf(l1, l2);
-            nll = (m == NEG_INF) ? INFINITY : -(s_off + m + logf(expf(l1 - m) + expf(l2 - m)));
+            const double* last = ab + (size_t)(Tb - 1) * RW;
+            const double tail = last[L] + (L > 0 ? last[W + L - 1] : 0.0);
+            nll = (tail > 0.0 && s_logc != -INFINITY) ? (float)(-(s_logc + log(tail))) : INFINITY;
         }
         nll_raw[b] = nll;
         nll_out[b] = (nll == INFINITY && zero_infinity) ? 0.f : nll;
@@ -280,11 +357,11 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------- kernel 3
 template <typename T>
-__global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ logits, T* __restrict__ dlogits, const float* __restrict__ lp,
-                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ logits, T* __restrict__ dlogits, const double* __restrict__ lp,
+                                                       const double* __restrict__ alpha, const double* __restrict__ beta,
                                                        const float* __restrict__ lse_in, const int32_t* __restrict__ in_len,
                                                        const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                       const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int Smax, int blank,
+                                                       const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank,
                                                        float scale) {
     extern __shared__ __attribute__((aligned(16))) float occ[];  // V floats: posterior mass per label
     constexpr int N = Vec<T>::N;
@@ -307,23 +384,31 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
             continue;
         }
         const T* x = logits + (size_t)row * V;
-        const int L = lab_len[b], S = 2 * L + 1;
+        const int L = lab_len[b];
         const float lse = lse_in[row];
         if (threadIdx.x < 64) {
-            // log posterior of state s at this frame, up to a per-frame constant: alpha+beta-lp.
-            // sum_s alpha_t(s) beta_t(s) / y_t(l'_s) = p(l|x) for EVERY t, so normalising over s is
-            // exact and needs neither nll nor the recursion offsets (no large-number cancellation).
-            const size_t o = (size_t)row * Smax;
-            float mx = NEG_INF;
-            for (int si = threadIdx.x; si < S; si += 64) mx = fmaxf(mx, alpha[o + si] + beta[o + si] - lp[o + si]);
-            mx = wave_max(mx);
-            float sum = 0.f;
-            for (int si = threadIdx.x; si < S; si += 64) sum += expf(alpha[o + si] + beta[o + si] - lp[o + si] - mx);
-            sum = wave_sum(sum);
-            const float inv = 1.f / sum;
-            for (int si = threadIdx.x; si < S; si += 64) {
-                const int c = (si & 1) ? labels[(size_t)b * Lmax + (si >> 1)] : blank;
-                atomicAdd(&occ[c], expf(alpha[o + si] + beta[o + si] - lp[o + si] - mx) * inv);
+            // posterior of a state at this frame, up to a per-frame constant: alpha * beta / y
+            // (both recursions include y_t).  sum_s alpha_t(s) beta_t(s) / y_t(l'_s) = p(l|x) for
+            // EVERY t, so normalising over s is exact and needs neither nll nor the scale factors.
+            const size_t o = (size_t)row * 2 * W;
+            double sum_b = 0.0, sum_l = 0.0;
+            for (int i = threadIdx.x; i <= L; i += 64) {
+                const double yb = lp[o + i], yl = lp[o + W + i];
+                sum_b += yb > 0.0 ? alpha[o + i] * beta[o + i] / yb : 0.0;
+                sum_l += (i < L && yl > 0.0) ? alpha[o + W + i] * beta[o + W + i] / yl : 0.0;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sum_b += __shfl_xor(sum_b, off, 64);
+                sum_l += __shfl_xor(sum_l, off, 64);
+            }
+            const double sum = sum_b + sum_l;
+            if (sum > 0.0) {
+                if (threadIdx.x == 0) occ[blank] = (float)(sum_b / sum);      // all blank states share one class
+                for (int i = threadIdx.x; i < L; i += 64) {
+                    const double yl = lp[o + W + i];
+                    if (yl > 0.0) atomicAdd(&occ[labels[(size_t)b * Lmax + i]], (float)(alpha[o + W + i] * beta[o + W + i] / yl / sum));
+                }
             }
         }
         __syncthreads();
@@ -339,10 +424,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
             for (int i = threadIdx.x; i < V; i += 256) dl[i] = from_f32<T>(scale * (expf(to_f32<T>(x[i]) - lse) - occ[i]));
         }
         __syncthreads();
-        for (int si = threadIdx.x; si < S; si += 256) {
-            const int c = (si & 1) ? labels[(size_t)b * Lmax + (si >> 1)] : blank;
-            occ[c] = 0.f;
-        }
+        if (threadIdx.x == 0) occ[blank] = 0.f;
+        for (int i = threadIdx.x; i < L; i += 256) occ[labels[(size_t)b * Lmax + i]] = 0.f;
         __syncthreads();
     }
 }
@@ -425,12 +508,15 @@ __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits,
     }
 }
 
-static inline int smax_of(int Lmax) { return (2 * Lmax + 1 + 3) & ~3; }
+// lattice row stride: whole waves (see ctc_recursion)
+// half-width W of a lattice row ([blanks | labels], 2W doubles): L+1 blanks must fit
+static inline int width_of(int Lmax) { return Lmax < 32 ? 32 : Lmax < 64 ? 64 : Lmax < 128 ? 128 : 256; }
+static inline int smax_of(int Lmax) { return 2 * width_of(Lmax); }
 
 }  // namespace
 
 extern "C" size_t asr_ctc_workspace_bytes(int B, int T, int Lmax) {
-    return ((size_t)3 * B * T * smax_of(Lmax) + (size_t)B * T + (size_t)B) * sizeof(float);
+    return (size_t)3 * B * T * smax_of(Lmax) * sizeof(double) + ((size_t)B * T + (size_t)B) * sizeof(float);
 }
 
 extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len, const int32_t* labels, const int32_t* lab_len,
@@ -438,35 +524,33 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
                                size_t ws_bytes, int dtype, void* stream) {
     if (!logits || !in_len || !labels || !lab_len || !nll || !ws) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: null pointer");
     if (B <= 0 || T <= 0 || V <= 1 || Lmax <= 0 || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: bad shape B=%d T=%d V=%d Lmax=%d blank=%d", B, T, V, Lmax, blank);
-    if (2 * Lmax + 1 > 1024) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: 2*Lmax+1 = %d > 1024 lattice states", 2 * Lmax + 1);
+    if (Lmax > 255) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: Lmax = %d: label sequences longer than 255 are not supported", Lmax);
     if (ws_bytes < asr_ctc_workspace_bytes(B, T, Lmax)) ASR_FAIL(ASR_EWORKSPACE, "asr_ctc_fwd_bwd: workspace %zu < %zu", ws_bytes, asr_ctc_workspace_bytes(B, T, Lmax));
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_ctc_fwd_bwd: dtype %d", dtype);
     const size_t lds = (size_t)((V + 3) & ~3) * sizeof(float);
     if (dlogits && lds > 160 * 1024) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: V=%d does not fit the LDS posterior table", V);
     hipStream_t st = (hipStream_t)stream;
-    const int Smax = smax_of(Lmax);
-    float* lp = (float*)ws;
-    float* alpha = lp + (size_t)B * T * Smax;
-    float* beta = alpha + (size_t)B * T * Smax;
-    float* lse = beta + (size_t)B * T * Smax;
+    const int W = width_of(Lmax), Smax = 2 * W;
+    double* lp = (double*)ws;
+    double* alpha = lp + (size_t)B * T * Smax;
+    double* beta = alpha + (size_t)B * T * Smax;
+    float* lse = (float*)(beta + (size_t)B * T * Smax);
     float* nll_raw = lse + (size_t)B * T;
     const int rows = B * T;
     int g1 = ceil_div(rows, 4);
     if (g1 > 4096) g1 = 4096;
-    if (dtype == ASR_F32) ctc_lse_gather_kernel<float><<<g1, 256, 0, st>>>((const float*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, Smax, blank);
-    else ctc_lse_gather_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, Smax, blank);
-    const int NS = ceil_div(2 * Lmax + 1, 64);
-#define AB(N) ctc_alpha_beta_kernel<N><<<B, 128, 0, st>>>(lp, alpha, beta, in_len, labels, lab_len, nll, nll_raw, T, Lmax, Smax, blank, zero_infinity)
-    if (NS <= 1) AB(1);
-    else if (NS <= 2) AB(2);
-    else if (NS <= 4) AB(4);
-    else if (NS <= 8) AB(8);
-    else AB(16);
+    if (dtype == ASR_F32) ctc_lse_gather_kernel<float><<<g1, 256, 0, st>>>((const float*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
+    else ctc_lse_gather_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
+#define AB(N) ctc_alpha_beta_kernel<N><<<B, 128, 0, st>>>(lp, alpha, beta, in_len, labels, lab_len, nll, nll_raw, T, Lmax, blank, zero_infinity)
+    if (W == 32) AB(32);
+    else if (W == 64) AB(64);
+    else if (W == 128) AB(128);
+    else AB(256);
 #undef AB
     if (dlogits) {
         int g3 = rows < 2048 ? rows : 2048;
-        if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, Smax, blank, grad_scale);
-        else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, Smax, blank, grad_scale);
+        if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
+        else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
     }
     ASR_CHECK_LAUNCH("asr_ctc_fwd_bwd");
     return ASR_OK;

@@ -130,7 +130,7 @@ int asr_sdpa_dropout_mask(uint8_t* mask, int B, int H, int Tq, int Tk, float dro
  * BASELINE.json north_star.  Semantics = torch.nn.functional.ctc_loss(log_softmax(logits), ...,
  * blank, reduction='none') and its gradient wrt logits (ATen native/LossCTC.cpp).
  * logits: (B, T, V) `dtype`;  in_len: (B) int32 frames per utterance (<= T);
- * labels: (B, Lmax) int32 padded; lab_len: (B) int32 (<= Lmax, 2*Lmax+1 <= 1024).
+ * labels: (B, Lmax) int32 padded; lab_len: (B) int32 (<= Lmax <= 255).
  * nll: (B) f32 = -log p(labels | x) (+inf when infeasible; 0 if zero_infinity).
  * dlogits: (B, T, V) `dtype` (may alias logits) = grad_scale * d(sum_b nll_b)/dlogits,
  * rows t >= in_len[b] are 0.  If dlogits is NULL only nll is computed.

@@ -51,7 +51,7 @@ def test_error_reporting_without_gpu():
     rc = _lib.lib.asr_add_ln_fwd(None, None, None, None, None, None, None, None, None, 1, 1, 8, 0.0, 0, 0, 0, None)
     assert rc == -1 and "null pointer" in _lib.last_error()
     rc = _lib.lib.asr_ctc_workspace_bytes(32, 500, 22)
-    assert rc == (3 * 32 * 500 * 48 + 32 * 500 + 32) * 4
+    assert rc == 3 * 32 * 500 * 64 * 8 + (32 * 500 + 32) * 4
     with pytest.raises(_lib.AsrHipError):
         _lib.check(-1, "x")
 
