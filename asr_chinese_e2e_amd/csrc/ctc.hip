@@ -94,6 +94,46 @@ __device__ __forceinline__ float wave_row_lse(const T* __restrict__ x, int V, in
     return m + logf(s);
 }
 
+// ---- bf16 fast path: a wave holds one whole row in registers (NV 16-byte vectors per lane)
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int NV>
+__device__ __forceinline__ void wave_row_load(const bf16_t* __restrict__ x, int nvec, int lane, u32x4 (&xv)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        // out-of-range vectors repeat the row's last vector: harmless for the max, masked in the sum
+        xv[k] = *(const u32x4*)(x + (size_t)min(i, nvec - 1) * 8);
+    }
+}
+// log-sum-exp of the row in xv: all loads in flight at once, ONE maximum, then one fma + v_exp_f32
+// per element (the online form costs an extra rescale exp per vector and a precise expf per element)
+template <int NV>
+__device__ __forceinline__ float wave_row_lse_regs(const u32x4 (&xv)[NV], int nvec, int lane) {
+    float m = NEG_INF;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, fmaxf(bf16_lo(xv[k][j]), bf16_hi(xv[k][j])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float mb = m * LOG2E;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            a += __builtin_amdgcn_exp2f(fmaf(bf16_lo(xv[k][j]), LOG2E, -mb)) + __builtin_amdgcn_exp2f(fmaf(bf16_hi(xv[k][j]), LOG2E, -mb));
+        s += (lane + 64 * k < nvec) ? a : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    return m + __logf(s);
+}
+
 // ---------------------------------------------------------------------------------- lattice layout
 // The 2L+1 states of the blank-augmented label sequence are kept as two arrays per frame:
 //   blanks  Bk[i] = state 2i     (i = 0..L)        labels  Lb[i] = state 2i+1  (i = 0..L-1)
@@ -124,6 +164,43 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict
             out[i] = i <= L ? yb : 0.0;
             const int c = labels[(size_t)b * Lmax + min(i, Lmax - 1)];
             out[W + i] = i < L ? exp((double)(to_f32<T>(x[c]) - lse)) : 0.0;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* __restrict__ logits, const int32_t* __restrict__ in_len,
+                                                                  const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
+                                                                  double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int Lmax,
+                                                                  int W, int blank) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rows = B * T_, nvec = V >> 3;
+    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+        const int b = row / T_, t = row - b * T_;
+        if (t >= in_len[b]) continue;
+        const bf16_t* x = logits + (size_t)row * V;
+        u32x4 xv[NV];
+        wave_row_load<NV>(x, nvec, lane, xv);
+        const int L = lab_len[b];
+        // the gathers are issued before the reduction so that their latency overlaps it
+        float xl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            xl[j] = (i < W) ? (float)x[labels[(size_t)b * Lmax + min(i, Lmax - 1)]] : 0.f;
+        }
+        const float xb = (float)x[blank];
+        const float lse = wave_row_lse_regs<NV>(xv, nvec, lane);
+        if (lane == 0) lse_out[row] = lse;
+        double* out = lp + (size_t)row * 2 * W;
+        const double yb = exp((double)(xb - lse));   // y_t(blank): linear domain, fp64
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            if (i < W) {   // zero beyond the valid entries: the recursion runs unpredicated
+                out[i] = i <= L ? yb : 0.0;
+                out[W + i] = i < L ? exp((double)(xl[j] - lse)) : 0.0;
+            }
         }
     }
 }
@@ -430,6 +507,97 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     }
 }
 
+// bf16 fast path of kernel 3: ONE WAVE per frame, the row in registers, no LDS and no workgroup
+// barrier.  The posterior mass of the (at most L + 1) classes that occur in the label sequence is
+// subtracted by overwriting those few elements after the row has been stored.
+template <int NV>
+__global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const bf16_t* __restrict__ logits, bf16_t* __restrict__ dlogits, const double* __restrict__ lp,
+                                                            const double* __restrict__ alpha, const double* __restrict__ beta,
+                                                            const float* __restrict__ lse_in, const int32_t* __restrict__ in_len,
+                                                            const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
+                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank,
+                                                            float scale) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rows = B * T_, nvec = V >> 3;
+    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+        const int b = row / T_, t = row - b * T_;
+        bf16_t* dl = dlogits + (size_t)row * V;
+        // padded frame, or infeasible utterance (nll = +inf): zero gradient
+        if (t >= in_len[b] || nll_raw[b] == INFINITY) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int i = lane; i < nvec; i += 64) *(u32x4*)(dl + (size_t)i * 8) = z;
+            continue;
+        }
+        const bf16_t* x = logits + (size_t)row * V;
+        u32x4 xv[NV];
+        wave_row_load<NV>(x, nvec, lane, xv);
+        const int L = lab_len[b];
+        const float lse = lse_in[row];
+        // posterior of a state at this frame, up to a per-frame constant: alpha * beta / y (both
+        // recursions include y_t).  sum_s alpha_t(s) beta_t(s) / y_t(l'_s) = p(l|x) for EVERY t, so
+        // normalising over s is exact and needs neither nll nor the scale factors.
+        const size_t o = (size_t)row * 2 * W;
+        double pb = 0.0, pl[4], yl[4];
+        int lab[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            pl[j] = 0.0;
+            yl[j] = 0.0;
+            lab[j] = -1;
+            if (i <= L && i < W) {
+                const double yb = lp[o + i];
+                pb += yb > 0.0 ? alpha[o + i] * beta[o + i] / yb : 0.0;
+                if (i < L) {
+                    yl[j] = lp[o + W + i];
+                    pl[j] = yl[j] > 0.0 ? alpha[o + W + i] * beta[o + W + i] / yl[j] : 0.0;
+                    lab[j] = labels[(size_t)b * Lmax + i];
+                }
+            }
+        }
+        double sum = pb + pl[0] + pl[1] + pl[2] + pl[3];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += __shfl_xor(sum, off, 64);
+            pb += __shfl_xor(pb, off, 64);
+        }
+        const double inv = sum > 0.0 ? 1.0 / sum : 0.0;
+        // the row: scale * softmax
+        const float lb = lse * LOG2E;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = lane + 64 * k;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] = scale * __builtin_amdgcn_exp2f(fmaf(bf16_lo(xv[k][j]), LOG2E, -lb));
+                v[2 * j + 1] = scale * __builtin_amdgcn_exp2f(fmaf(bf16_hi(xv[k][j]), LOG2E, -lb));
+            }
+            if (i < nvec) store8<bf16_t>(dl + (size_t)i * 8, v);
+        }
+        // occupancy of each label's class = sum over the positions that carry the same label
+        float occ[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (64 * jj >= L) break;
+            const int cnt = min(64, L - 64 * jj);
+            const float pj_all = (float)(pl[jj] * inv);
+            for (int q = 0; q < cnt; ++q) {
+                const int lq = __shfl(lab[jj], q, 64);
+                const float pq = __shfl(pj_all, q, 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) occ[j] += (lab[j] == lq) ? pq : 0.f;
+            }
+        }
+        // the row's stores must have reached L2 before the same wave overwrites some of its elements
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) dl[blank] = (bf16_t)(scale * ((float)lp[o] - (float)(pb * inv)));   // every blank state has the same y
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lab[j] >= 0) dl[lab[j]] = (bf16_t)(scale * ((float)yl[j] - occ[j]));       // positions with equal labels write equal values
+    }
+}
+
 // ---------------------------------------------------------------------------------- xent
 template <typename T>
 __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits, const int32_t* __restrict__ gold, const float* __restrict__ n_valid,
@@ -528,7 +696,7 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     if (ws_bytes < asr_ctc_workspace_bytes(B, T, Lmax)) ASR_FAIL(ASR_EWORKSPACE, "asr_ctc_fwd_bwd: workspace %zu < %zu", ws_bytes, asr_ctc_workspace_bytes(B, T, Lmax));
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_ctc_fwd_bwd: dtype %d", dtype);
     const size_t lds = (size_t)((V + 3) & ~3) * sizeof(float);
-    if (dlogits && lds > 160 * 1024) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: V=%d does not fit the LDS posterior table", V);
+    if (dlogits && lds > 160 * 1024 && !(dtype == ASR_BF16 && V % 8 == 0 && V <= 8192)) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: V=%d does not fit the LDS posterior table", V);
     hipStream_t st = (hipStream_t)stream;
     const int W = width_of(Lmax), Smax = 2 * W;
     double* lp = (double*)ws;
@@ -539,7 +707,23 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     const int rows = B * T;
     int g1 = ceil_div(rows, 4);
     if (g1 > 4096) g1 = 4096;
-    if (dtype == ASR_F32) ctc_lse_gather_kernel<float><<<g1, 256, 0, st>>>((const float*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
+    // bf16 rows of whole 16-byte vectors that fit a wave's registers take the row-in-registers kernels
+    const int need = ceil_div(V / 8, 64);
+    const bool rows_path = dtype == ASR_BF16 && V % 8 == 0 && need <= 16 && ((uintptr_t)logits % 16) == 0 && (!dlogits || ((uintptr_t)dlogits % 16) == 0);
+#define ROWS_DISPATCH(CALL)           \
+    do {                              \
+        if (need <= 2) { CALL(2); }   \
+        else if (need <= 4) { CALL(4); }   \
+        else if (need <= 6) { CALL(6); }   \
+        else if (need <= 9) { CALL(9); }   \
+        else if (need <= 12) { CALL(12); } \
+        else { CALL(16); }            \
+    } while (0)
+    if (rows_path) {
+#define K1(NV) ctc_lse_gather_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank)
+        ROWS_DISPATCH(K1);
+#undef K1
+    } else if (dtype == ASR_F32) ctc_lse_gather_kernel<float><<<g1, 256, 0, st>>>((const float*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
     else ctc_lse_gather_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
 #define AB(N) ctc_alpha_beta_kernel<N><<<B, 128, 0, st>>>(lp, alpha, beta, in_len, labels, lab_len, nll, nll_raw, T, Lmax, blank, zero_infinity)
     if (W == 32) AB(32);
@@ -549,7 +733,11 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
 #undef AB
     if (dlogits) {
         int g3 = rows < 2048 ? rows : 2048;
-        if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
+        if (rows_path) {
+#define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale)
+            ROWS_DISPATCH(K3);
+#undef K3
+        } else if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
         else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
     }
     ASR_CHECK_LAUNCH("asr_ctc_fwd_bwd");

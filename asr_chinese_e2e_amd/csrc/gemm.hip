@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
 //   * XCD-aware tile order so the tiles that share an A row-panel run on one XCD's L2.
 // Rows past M / N are clamped on load (their results are never stored).
 constexpr int DBN = 128, DBK = 64;
+#ifndef SWZ_NEW
+#define SWZ_NEW 1
+#endif
 constexpr int DEPS = 272;                        // epilogue row stride (bytes)
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -182,11 +185,12 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restri
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 31, hh = lane >> 5;
     // staging: GROUPS pieces of 8 rows per stage (A rows first, then W rows), PW per wave
-    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const int srow = lane >> 3;
     const bf16_t* src[PW];
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         const int g = w * PW + j;
+        const int schunk = (lane & 7) ^ (SWZ_NEW ? (((g & 1) << 2) | (srow >> 1)) : srow);   // key = (row >> 1) & 7
         src[j] = g < BM_ / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
                              : W + (size_t)min(n0 + 8 * (g - BM_ / 8) + srow, N - 1) * ldb + schunk * 8;
     }
@@ -203,14 +207,15 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restri
         for (int b = 0; b < MI; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    const int sw = r & 7;
+    const int sw = SWZ_NEW ? (r >> 1) & 7 : r & 7;
     const int a_row = (wm * (BM_ / 2) + r) * 128;            // + mi*32*128
     const int w_row = BM_ * 128 + (wn * 64 + r) * 128;       // + ni*32*128
     const int nk = K / DBK;
     stage(0, 0);
     if (RING_ > 2 && nk > 1) stage(1, DBK);
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    bf16x8 af[2][MI], wf[2][2];
+    for (int kt = 0; kt < (DBG == 3 ? 1 : nk); ++kt) {
         if (RING_ > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave's part of tile kt landed; the slot refilled next is no longer read
@@ -218,7 +223,6 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restri
         const char* sb = smem_dma + cur * Cfg::STAGE;
         cur = cur == RING_ - 1 ? 0 : cur + 1;
         if (DBG == 1) continue;
-        bf16x8 af[2][MI], wf[2][2];
         auto load_frags = [&](int buf, int ks) {
             const int coff = ((2 * ks + hh) ^ sw) << 4;
 #pragma unroll
@@ -226,10 +230,12 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restri
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
         };
-        load_frags(0, 0);
+        if (DBG != 4 || kt == 0) load_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+            if (DBG == 4) {
+                if (kt == 0 && ks == 0) load_frags(1, 1);
+            } else if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -277,6 +283,15 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restri
     }
 }
 
+static int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <int ACT, int BM_, int RING_, int DBG>
 static void launch_nt_dma(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st) {
     using Cfg = DmaCfg<BM_, RING_>;
@@ -287,6 +302,226 @@ static void launch_nt_dma(const bf16_t* a, const bf16_t* w, const float* bias, b
     }
     const int t_n = ceil_div(N, DBN), t_m = ceil_div(M, BM_);
     gemm_nt_dma_kernel<ACT, BM_, RING_, DBG><<<t_n * t_m, 256, Cfg::LDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n);
+}
+
+// ------------------------------------------------------------------------- NT, persistent version
+// Attribution of the kernel above on the config-2 shapes (tools/gemm_dbg_scan.sh): one k-step plus
+// the fixed per-tile costs (dispatch, first-tile latency, store tail) is HALF its time, and the
+// other half is DMA latency + MFMA in series (ring 2: one stage in flight per workgroup); LDS
+// fragment reads and bank conflicts are not on the critical path.  So this version
+//   * is PERSISTENT: one workgroup per CU walks a list of tiles, and the LDS-DMA ring runs across
+//     tile boundaries - the first stages of the next tile are in flight during the store tail;
+//   * uses 256 x 128 x 64 tiles (4 waves, wave tile 128 x 64 = 4 x 2 MFMA 32x32x16 tiles): 0.75 x
+//     the staged bytes per flop of 128 x 128, and a 3-stage ring (144 KiB) keeps TWO 48-KiB
+//     stages in flight under every MFMA block (counted vmcnt, one raw s_barrier per k-step);
+//   * stores through wave-private 8-KiB LDS transpose buffers (64 rows x 128 B, XOR-swizzled) placed
+//     in the ring slot that was consumed last, while the other two slots receive the next tile;
+//   * orders each XCD's tiles so that the 32 CUs of an XCD work on consecutive tiles (shared A
+//     row-panels and W served by that XCD's L2).
+constexpr int PBM = 256, PBN = 128, PBK = 64, PRING = 3;
+constexpr int PSTAGE = (PBM + PBN) * 128;          // 49152 B
+constexpr int PLDS = PRING * PSTAGE;               // 147456 B
+template <int NW> struct PCfg {                    // NW waves as (NW/2) x 2; wave tile (32*MI) x 64
+    static constexpr int MI = 8 / NW * 2;          // 4 waves: 4, 8 waves: 2
+    static constexpr int PPW = (PBM + PBN) / 8 / NW;   // DMA wave-instructions per wave per stage (12 / 6)
+    static constexpr int RM = NW == 4 ? 2 : 1;     // 32-row blocks per transpose round (staging must fit one ring slot)
+    static constexpr int PEPI = RM * 32 * 128;     // per-wave transpose buffer
+    static constexpr int PSTORES = 4 * MI;         // global stores per wave per tile (vmcnt accounting)
+};
+
+template <int ACT, int NW, int DBG = 0>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                                     bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+                                                                     int tiles_n, int ntiles) {
+    using Cfg = PCfg<NW>;
+    constexpr int MI = Cfg::MI, PPW = Cfg::PPW, RM = Cfg::RM, PEPI = Cfg::PEPI, PSTORES = Cfg::PSTORES;
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this workgroup's tiles: XCD x owns the contiguous range [lo, hi), its workgroups interleave inside it
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int nb_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int tq = ntiles >> 3, trem = ntiles & 7;          // XCD x owns tq + (x < trem) tiles: never fewer than its workgroups
+    const int lo = xcd * tq + min(xcd, trem), hi = lo + tq + (xcd < trem ? 1 : 0);
+    const int first = lo + idx;
+    if (first >= hi) return;
+    const int my_tiles = (hi - first + nb_x - 1) / nb_x;
+    const int nk = K / PBK;
+    const int total = my_tiles * nk;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int srow = lane >> 3;
+
+    // ---- DMA issue cursor: runs PRING-1 k-steps ahead of the MFMAs, across tile boundaries
+    int it_tile = first, it_k = 0, it_slot = 0, issued = 0;
+    const bf16_t* src[PPW];   // this lane's source of each of the wave's one-KiB pieces, at k = 0 of the tile being staged
+    auto set_tile = [&](int tile) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int m0 = tm * PBM, n0 = tn * PBN;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int g = w * PPW + j;                       // 8-row group: 0..31 = A rows, 32..47 = W rows
+            const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));   // slot of chunk c in row R: c ^ ((R >> 1) & 7)
+            src[j] = g < PBM / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
+                                 : W + (size_t)min(n0 + 8 * (g - PBM / 8) + srow, N - 1) * ldb + schunk * 8;
+        }
+    };
+    auto dma = [&](int j) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + it_k * PBK), (lds_void_t*)(smem_p + it_slot * PSTAGE + (w * PPW + j) * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        ++issued;
+        it_slot = it_slot == PRING - 1 ? 0 : it_slot + 1;
+        if (++it_k == nk) {
+            it_k = 0;
+            it_tile += nb_x;
+            if (issued < total) set_tile(it_tile);
+        }
+    };
+
+    const int sw = (r >> 1) & 7;
+    const int a_row = (wm * 32 * MI + r) * 128;              // + mi*32*128
+    const int w_row = PBM * 128 + (wn * 64 + r) * 128;       // + ni*32*128
+
+    unsigned long long* stamps = DBG == 5 ? (unsigned long long*)bias + (size_t)blockIdx.x * 16 : nullptr;
+    if (DBG == 5) { bias = nullptr; if (tid == 0) stamps[0] = __builtin_amdgcn_s_memrealtime(); }
+    set_tile(first);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) dma(j);
+    advance();
+    if (total > 1) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) dma(j);
+        advance();
+    }
+    int c_slot = 0, i = 0;
+    bool prev_stores = false;   // the previous tile issued exactly PSTORES stores per wave (interior tile)
+    for (int c_tile = first; c_tile < hi; c_tile += nb_x) {
+        const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
+        const int m0 = tm * PBM + wm * 32 * MI, n0 = tn * PBN + wn * 64;
+        // The accumulators START at bias[n] (n = n0 + ni*32 + 8*g4 + 4*hh + e for register 4*g4 + e): one
+        // VALU op per element less in the store tail, where nothing overlaps it.  The address of each
+        // 8-float group is wave-uniform, so these are SCALAR loads (lgkmcnt): a vector load here would
+        // make the compiler wait for the prefetched DMA stages queued before it (vmcnt is in order).
+        // They live only inside this iteration: tile loop outside, k loop inside keeps them in AGPRs
+        // (one flat loop over (tile, k) made hipcc copy all of them in and out every k-step).
+        f32x16 acc[2][MI];  // [ni][mi]: C^T tiles (n in registers, m on the lane)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nb = min(n0 + ni * 32 + 8 * g4, N - 8);   // clamped groups are never stored
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
+                    const float bv = hh ? b_hi : b_lo;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[ni][mi][4 * g4 + e] = bv;
+                }
+            }
+        // One k-step: 8*MI MFMAs per wave.  The DMA instructions of the stage two steps ahead are
+        // spread BETWEEN the MFMAs (three per 8 MFMAs): a wave issues in order and the texture path
+        // takes a 1-KiB DMA instruction every 16 cycles per CU, so a block of 48 of them in front
+        // of the MFMAs kept the matrix pipes idle for as long as the MFMAs themselves take (in-kernel
+        // stamps: 0.52 us DMA-only + 0.82 us MFMA-only = 1.28 us per k-step, i.e. no overlap at all).
+        auto k_step = [&](const bool more) {   // more (wave-uniform): a stage is left to be issued
+            const char* sb = smem_p + c_slot * PSTAGE;
+            c_slot = c_slot == PRING - 1 ? 0 : c_slot + 1;
+            bf16x8 af[2][MI], wf[2][2];
+            auto load_frags = [&](int buf, int ks) {
+                const int coff = ((2 * ks + hh) ^ sw) << 4;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[buf][mi] = *(const bf16x8*)(sb + a_row + mi * 32 * 128 + coff);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+                for (int q = 0; q < 2 * MI; ++q) {
+                    const int ni = q / MI, mi = q % MI;
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+                    const int g = ks * 2 * MI + q, g8 = g & 7;   // MFMA number in this step
+                    if (g8 == 1 || g8 == 4 || g8 == 6) {     // the MFMAs stay on ONE code path (two copies of this
+                        __builtin_amdgcn_sched_barrier(0);   // body made hipcc move the accumulators AGPR <-> VGPR every step)
+                        if (more) dma((g >> 3) * 3 + (g8 == 1 ? 0 : g8 == 4 ? 1 : 2));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (more) advance();
+        };
+        for (int c_k = 0; c_k < nk; ++c_k, ++i) {
+            // item i has landed when at most (the DMA of item i+1) + (the stores of a store tail in one
+            // of the last two iterations) are still outstanding; vmcnt retires in order.  Needs nk >= 2.
+            if (i + 1 < total) {
+                if (prev_stores && c_k < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + PSTORES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();   // every wave's part of item i landed; nobody still reads the slot refilled during this step
+            if (DBG == 5 && tid == 0 && i < 12) stamps[1 + i] = __builtin_amdgcn_s_memrealtime();
+            k_step(issued < total);
+        }
+        // ---- store tail of tile c_tile: activation in registers, transpose through wave-private LDS
+        // buffers, 16-byte row stores.  Exactly PSTORES global stores per wave on an interior tile.
+        // Staging area: the ring slot the last k-step consumed.  It is free until the next step's
+        // DMA (issued after that step's barrier, which every wave reaches only after its LDS reads
+        // here); the barrier below makes sure the other waves have finished their fragment reads.
+        __builtin_amdgcn_s_barrier();
+        char* epi = smem_p + (c_slot == 0 ? PRING - 1 : c_slot - 1) * PSTAGE + w * PEPI;
+#pragma unroll
+        for (int round = 0; round < MI / RM; ++round) {
+#pragma unroll
+            for (int m2 = 0; m2 < RM; ++m2)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int mi = round * RM + m2;
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[ni][mi][4 * g4 + e];
+                            if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
+                            o[e] = x;
+                        }
+                        // row m2*32 + r (= m), columns ni*32 + 8*g4 + 4*hh .. +3  ->  16-byte chunk ni*4 + g4, half hh
+                        store4<bf16_t>((bf16_t*)(epi + (m2 * 32 + r) * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
+                    }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4 * RM; ++q) {
+                const int row = q * 8 + srow, ch = lane & 7;
+                const u32x4 v = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
+                if (m < M && n + 8 <= N) *(u32x4*)(C + (size_t)m * ldc + n) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // an edge tile may skip whole store instructions: then the shorter wait (which also covers
+        // its stores) is the safe one
+        prev_stores = (tm * PBM + PBM <= M) && (tn * PBN + PBN <= N);
+        if (DBG == 5 && tid == 0 && c_tile == first) {
+            stamps[13] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamps[14] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+}
+
+template <int ACT, int NW, int DBG = 0>
+static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<ACT, NW, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        attr = true;
+    }
+    const int t_n = ceil_div(N, PBN), t_m = ceil_div(M, PBM), ntiles = t_n * t_m;
+    const int grid = ntiles < cu_count() ? ntiles : cu_count();
+    gemm_nt_persist_kernel<ACT, NW, DBG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles);
 }
 
 // ---------------------------------------------------------------------------------------- TN
@@ -422,12 +657,24 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     do {                                                                                                                     \
         if (dbg == 1) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 1>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);                \
         else if (dbg == 2) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 2>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);           \
+        else if (dbg == 3) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 3>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);           \
+        else if (dbg == 4) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 4>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);           \
         else if (act == ASR_ACT_RELU) launch_nt_dma<ASR_ACT_RELU, BM_, RING_, 0>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st); \
         else launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 0>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);                         \
     } while (0)
-        // measured on config-2 shapes (tools/gemm_bench.py): 128 x 128, ring 2, two workgroups per
-        // CU is the fastest or within 3 % of it everywhere (535 / 437 / 527 / 634 / 545 TF/s)
-        if (cfg == 1) NT_DMA(256, 3);
+        // (of the non-persistent variants 128 x 128, ring 2, two workgroups per CU was the fastest;
+        // they stay selectable through ASR_GEMM_CFG for A/B runs)
+        // default: the persistent 8-wave kernel (tools/gemm_bench.py on the config-2 shapes, us:
+        // 38.4 / 17.4 / 27.0 / 23.8 / 116.8 vs 46.2 / 19.4 / 32.1 / 27.1 / 130.0 for 128 x 128 ring 2)
+        if ((cfg == 0 || cfg == 8) && K >= 2 * PBK && N % 8 == 0) {
+            if (dbg == 5) launch_nt_persist<ASR_ACT_NONE, 8, 5>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+            else if (act == ASR_ACT_RELU) launch_nt_persist<ASR_ACT_RELU, 8>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+            else launch_nt_persist<ASR_ACT_NONE, 8>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+        } else if (cfg == 4 && K >= 2 * PBK && N % 8 == 0) {
+            if (dbg == 5) launch_nt_persist<ASR_ACT_NONE, 4, 5>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+            else if (act == ASR_ACT_RELU) launch_nt_persist<ASR_ACT_RELU, 4>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+            else launch_nt_persist<ASR_ACT_NONE, 4>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+        } else if (cfg == 1) NT_DMA(256, 3);
         else if (cfg == 2) NT_DMA(128, 3);
         else if (cfg == 3) NT_DMA(256, 2);
         else NT_DMA(128, 2);

@@ -198,7 +198,9 @@ def ctc_case(seed, B, T, V, Lmax, repeat=False, dtype=torch.float32):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("seed,B,T,V,Lmax,repeat", [(0, 4, 20, 12, 5, False), (1, 3, 33, 50, 7, True), (2, 2, 100, 4232, 22, False),
-                                                    (3, 5, 64, 31, 40, True), (4, 2, 12, 9, 3, False)])
+                                                    (3, 5, 64, 31, 40, True), (4, 2, 12, 9, 3, False),
+                                                    # bf16 row-in-registers kernels (V % 8 == 0): repeated labels, 2 and 4 registers per lane
+                                                    (5, 3, 40, 64, 9, True), (6, 2, 160, 1024, 70, True), (7, 2, 300, 512, 130, True)])
 def test_ctc(K, ws, dtype, seed, B, T, V, Lmax, repeat):
     lt, in_len, labels, lab_len = ctc_case(seed, B, T, V, Lmax, repeat, dtype)
     # oracle: numpy float64 alpha/beta on the (rounded) logits + torch F.ctc_loss as second opinion
@@ -233,6 +235,23 @@ def test_ctc_infeasible_and_inplace(K, ws):
     close(dl[1], torch.from_numpy(gref[1]), rtol=1e-4, atol=1e-6, what="inplace grad")
     nll0, _ = K.ctc_fwd_bwd(logits.to(DEV), in_len.to(DEV), labels.to(DEV), lab_len.to(DEV), ws, zero_infinity=True)
     assert float(nll0[0]) == 0.0
+
+
+def test_ctc_rows_kernel_inplace_and_padding(K, ws):
+    """bf16, V % 8 == 0: dlogits aliasing logits, padded frames zeroed, an infeasible utterance zeroed."""
+    lt, in_len, labels, lab_len = ctc_case(11, 4, 24, 256, 6, True, torch.bfloat16)
+    in_len[2] = 2
+    lab_len[2] = 6      # infeasible: 6 labels in 2 frames
+    nll_ref, g_ref = ctc_ref.ctc_batch(lt.double().numpy(), in_len, labels, lab_len, zero_infinity=True)
+    x = lt.to(DEV).clone()
+    nll, dl = K.ctc_fwd_bwd(x, torch.from_numpy(in_len).int().to(DEV), torch.from_numpy(labels).int().to(DEV),
+                            torch.from_numpy(lab_len).int().to(DEV), ws, zero_infinity=True, dlogits=x)
+    assert dl.data_ptr() == x.data_ptr()
+    close(nll, torch.from_numpy(nll_ref), rtol=1e-4, atol=1e-4, what="ctc nll (in place)")
+    close(dl, torch.from_numpy(g_ref), rtol=1e-2, atol=4e-3, what="ctc dlogits (in place)")
+    assert float(dl[2].abs().max()) == 0.0
+    for b in range(4):
+        assert float(dl[b, in_len[b]:].abs().max() if in_len[b] < 24 else 0.0) == 0.0
 
 
 def test_ctc_full_size_properties(K, ws):
