@@ -621,6 +621,180 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
         }
 }
 
+// ------------------------------------------------------------------------- TN, LDS-DMA version
+// Same pipeline as the persistent NT kernel, applied to the weight gradient: a 4-stage ring of
+// 64-row stages (dY 64 x 128 | X 64 x 128, 32 KiB) filled by LDS-DMA, one raw s_barrier per
+// stage, counted vmcnt with two to three stages in flight, the eight DMA instructions of a wave
+// issued BETWEEN its 16 MFMAs.  The register-staged kernel above spends ~1.3 us per 64-row stage
+// where the MFMAs need 0.33 us; the limit of this form is the LDS array (transposed fragment reads
+// of both operands + the DMA writes: ~96 KiB per stage).
+//   * a DMA instruction writes 1 KiB = 4 rows of 256 B; 16-byte chunk c of row R is stored in
+//     slot c ^ (4 * (R & 3)) (swizzle on the source address), so the four rows one half-wave
+//     reads with ds_read_b64_tr_b16 sit on disjoint 64-byte bank groups;
+//   * rows past the end of the split's range and columns past N / K come from a zero page.
+constexpr int TSTAGE = 2 * TM * 256;   // 32768 B
+__device__ __attribute__((aligned(256))) unsigned tn_zero_page[64];
+
+// ds_read_b64_tr_b16 through inline asm: after an LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of
+// the builtin form of this read (it cannot tell the read from the DMA's LDS target), which drains
+// the whole prefetch ring every k-step.  The asm form is invisible to that pass, so the reads are
+// ordered by hand: counted lgkmcnt waits + sched_barrier in the main loop (guide 5.4 rule 18).
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr16(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// byte offset inside a stage half (64 rows x 256 B, swizzled) of this lane's piece of the fragment
+// lane (r, hh), j = 0..7  ->  tile[16*s + 8*(j>>2) + 4*hh + (j&3)][col0 + r];  + s*4096 (+2048 for j >= 4)
+__device__ __forceinline__ unsigned tn_frag_off(int col0, int lane) {
+    const int G = lane >> 4, i = lane & 15;
+    const int row = 4 * (G >> 1) + (i >> 2);                    // row & 3 == (i >> 2) & 3 for every s
+    const int chunk = ((col0 >> 3) + 2 * (G & 1) + ((i & 3) >> 1)) ^ (4 * ((i >> 2) & 3));
+    return (unsigned)(row * 256 + (chunk << 4) + 8 * (i & 1));
+}
+template <int S>
+__device__ __forceinline__ bf16x8 tn_frag_swz(unsigned addr) {
+    const bf16x4 lo = lds_tr16<S * 4096>(addr), hi = lds_tr16<S * 4096 + 2048>(addr);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int TRING>   // 4: one workgroup per CU (128 KiB ring); 2: two per CU (64 KiB each)
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
+                                                             int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
+                                                             int use_atomic, const void* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = tiles_k * tiles_n;
+    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    const int split = vid / ntiles, tile = vid - split * ntiles;
+    const int tk = tile % tiles_k, tn = tile / tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    const int nsteps = (mend - mbeg + TM - 1) / TM;
+    if (nsteps <= 0) return;
+    const int wn = w >> 1, wk = w & 1;
+
+    // this lane's part of each of the wave's 8 one-KiB pieces: waves 0,1 stage dY (rows 4g.. of piece
+    // g = 0..15), waves 2,3 stage X.  Running pointers, advanced by one uniform add per stage: the
+    // address work per DMA must stay within a few instructions, or it - not the MFMAs - paces the
+    // loop (an MFMA hides about five other instructions of its wave).
+    // Columns past N / K are CLAMPED to the last valid 16-byte chunk: they only feed accumulator
+    // columns that are never stored.  Rows past the end of the range must read zeros: only the last
+    // stage of a range can be partial, and only there the per-lane select runs.
+    const int lrow = lane >> 4, slot = lane & 15;
+    const bool is_y = w < 2;
+    const bf16_t* cur[8];
+    int prow[8];   // row inside the stage
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gg = (w & 1) * 8 + j;
+        const int row = 4 * gg + lrow;
+        const int col = (slot ^ (4 * (row & 3))) * 8;
+        prow[j] = row;
+        cur[j] = is_y ? dY + (size_t)(mbeg + row) * ldy + min(n0 + col, N - 8) : X + (size_t)(mbeg + row) * ldx + min(k0 + col, K - 8);
+    }
+    const size_t stage_step = (size_t)TM * (is_y ? ldy : ldx);   // elements per stage (wave-uniform)
+    const bool ragged = ((mend - mbeg) % TM) != 0;
+    int it = 0, it_slot = 0;   // next stage to issue
+    auto dma = [&](int j) {
+        const void* q = cur[j];
+        if (ragged && it == nsteps - 1) q = (mbeg + it * TM + prow[j] < mend) ? q : zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)q, (lds_void_t*)(smem_t + it_slot * TSTAGE + (w * 8 + j) * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        ++it;
+        it_slot = it_slot == TRING - 1 ? 0 : it_slot + 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cur[j] += stage_step;
+    };
+
+    f32x16 acc[2][2];  // [ni][ki]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_t;
+    const unsigned y_off[2] = {tn_frag_off(wn * 64, lane), tn_frag_off(wn * 64 + 32, lane)};
+    const unsigned x_off[2] = {TM * 256 + tn_frag_off(wk * 64, lane), TM * 256 + tn_frag_off(wk * 64 + 32, lane)};
+
+    for (int p = 0; p < TRING - 1 && p < nsteps; ++p) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma(j);
+        advance();
+    }
+    int c_slot = 0;
+    for (int i = 0; i < nsteps; ++i) {
+        // stage i has landed when only the younger stages (8 DMA instructions each) are outstanding
+        const int younger = min(TRING - 2, nsteps - 1 - i);
+        if (TRING >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (TRING >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's part of stage i landed; nobody still reads the slot refilled during this step
+        const bool more = it < nsteps;
+        const unsigned sbase = lds_base + c_slot * TSTAGE;
+        c_slot = c_slot == TRING - 1 ? 0 : c_slot + 1;
+        bf16x8 yf[2][2], xf[2][2];
+#define TN_LOAD(BUF, S)                                              \
+    do {                                                             \
+        yf[BUF][0] = tn_frag_swz<S>(sbase + y_off[0]);               \
+        yf[BUF][1] = tn_frag_swz<S>(sbase + y_off[1]);               \
+        xf[BUF][0] = tn_frag_swz<S>(sbase + x_off[0]);               \
+        xf[BUF][1] = tn_frag_swz<S>(sbase + x_off[1]);               \
+    } while (0)
+#define TN_MMA(BUF, KS)                                                                                                       \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                       \
+            const int ni = q >> 1, ki = q & 1;                                                                                \
+            acc[ni][ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[BUF][ni], xf[BUF][ki], acc[ni][ki], 0, 0, 0);            \
+            if (q & 1) { /* one DMA instruction after every second MFMA */                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                            \
+                if (more) dma(KS * 2 + (q >> 1));                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                                            \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    } while (0)
+        // 8 reads per k-sub-step; LDS reads retire in order, so lgkmcnt(8) = "all but the 8 just issued"
+        TN_LOAD(0, 0);
+        TN_LOAD(1, 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TN_MMA(0, 0);
+        TN_LOAD(0, 2);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TN_MMA(1, 1);
+        TN_LOAD(1, 3);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TN_MMA(0, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TN_MMA(1, 3);
+#undef TN_LOAD
+#undef TN_MMA
+        if (more) advance();
+    }
+    // accumulator: row = n (registers), col = k (lane): 32 consecutive k per register -> 128-B segments
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+            const int kc = k0 + wk * 64 + ki * 32 + (lane & 31);
+            if (kc >= K) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + ni * 32 + acc_row(e, lane);
+                if (n >= N) continue;
+                float* dst = dW + (size_t)n * ldw + kc;
+                if (use_atomic) atomicAdd(dst, acc[ni][ki][e]);
+                else *dst = acc[ni][ki][e];
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int rows, int cols, int ld) {
     const size_t total = (size_t)rows * cols;
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -706,17 +880,43 @@ extern "C" int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M,
     if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ldw < K) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: N, K, ldy, ldx must be multiples of 8 (N=%d K=%d ldy=%d ldx=%d)", N, K, ldy, ldx);
     if (((uintptr_t)dY | (uintptr_t)X) % 16) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int tiles_n = ceil_div(N, 128), tiles_k = ceil_div(K, 128);
-    const int splits = tn_splits(M, N, K);
+    const int tiles_n = ceil_div(N, 128), tiles_k = ceil_div(K, 128), tiles = tiles_n * tiles_k;
+    static const int tn_cfg = getenv("ASR_GEMM_TN_CFG") ? atoi(getenv("ASR_GEMM_TN_CFG")) : 0;   // 1 = register-staged kernel (A/B runs)
+    static const int tn_noatomic = getenv("ASR_GEMM_TN_NOATOMIC") ? atoi(getenv("ASR_GEMM_TN_NOATOMIC")) : 0;   // timing experiments only (wrong results)
+    // M-splits: every split adds N*K*4 bytes of atomics, every workgroup beyond what is resident at
+    // once adds a whole second round.  The DMA kernel holds one workgroup per CU with its 4-stage
+    // ring; if that leaves more than ~20 % of the CUs idle it runs two per CU with a 2-stage ring.
+    const int cus = cu_count();
+    const int max_s = ceil_div(M, 4 * TM);   // at least 4 reduction stages per workgroup
+    int splits = tn_splits(M, N, K), ring = 0;
+    if (tn_cfg != 1) {
+        const int s_floor = cus / tiles > 0 ? cus / tiles : 1;
+        if (tiles * s_floor * 5 >= cus * 4) { splits = s_floor; ring = 4; }
+        else { splits = ceil_div(2 * cus, tiles) > 1 ? (2 * cus) / tiles : 1; ring = 2; }
+        if (splits > max_s) splits = max_s;
+        if (splits < 1) splits = 1;
+    }
     const int rows_per_split = ceil_div(ceil_div(M, splits), TM) * TM;
     const int nsplit = ceil_div(M, rows_per_split);
-    const int use_atomic = (nsplit > 1) || accumulate;
+    const int use_atomic = tn_noatomic ? 0 : ((nsplit > 1) || accumulate);
     if (nsplit > 1 && !accumulate) {
         size_t total = (size_t)N * K;
         int g = (int)((total + 255) / 256);
         zero_f32_kernel<<<g < 1024 ? g : 1024, 256, 0, st>>>(dW, N, K, ldw);
     }
-    gemm_tn_kernel<<<tiles_n * tiles_k * nsplit, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic);
+    const int grid = tiles * nsplit;
+    if (tn_cfg == 1) {
+        gemm_tn_kernel<<<grid, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic);
+    } else {
+        static void* zero_page = nullptr;
+        if (!zero_page) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);
+            if (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: zero page symbol not found");
+        }
+        if (ring == 4) gemm_tn_dma_kernel<4><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page);
+        else gemm_tn_dma_kernel<2><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page);
+    }
     ASR_CHECK_LAUNCH("asr_gemm_tn_bf16");
     return ASR_OK;
 }
