@@ -103,6 +103,19 @@ def cpu_baseline(args):
                       f"python-loop masks as the reference), {dt:.2f} s/step"}
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed PMC summary (None if absent)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    pat = {"gemm_nt": "gemm_nt", "gemm_tn": "gemm_tn", "lib_gemm_dgrad": "Cijk"}[family]
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    rows = [v for k, v in table.items() if pat in k]
+    n = sum(r["launches"] for r in rows)
+    return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,10 +212,11 @@ def main():
             dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
             if dom:
                 a = fam[dom]["work_per_s"] / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": {"gemm_nt": "gemm_nt_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_kernel (asr_gemm_tn_bf16)",
+                out["roofline"] = {"bound": "mfma", "kernel": {"gemm_nt": "gemm_nt_persist_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
                                                                "lib_gemm_dgrad": "hipBLASLt dgrad GEMM"}[dom],
                                    "achieved": a, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_BF16_PEAK_TFLOPS,
-                                   "traffic": None, "avg_launch_us": fam[dom]["avg_us"], "launches": fam[dom]["launches"],
+                                   "traffic": pmc_traffic(dom), "traffic_source": "profiles/round1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command (separate runs), bytes per launch averaged over the family's launches, FETCH_SIZE x2 (gfx950 correction)",
+                                   "avg_launch_us": fam[dom]["avg_us"], "launches": fam[dom]["launches"],
                                    "flop_per_launch": fam[dom]["work_per_launch"],
                                    "share_of_step": fam[dom]["total_ms"] / n_inst / (1e3 * dt / args.steps)}
                 out["kernel_families"] = {k: {"tflops": v["work_per_s"] / 1e12, "avg_us": v["avg_us"], "launches": v["launches"],
