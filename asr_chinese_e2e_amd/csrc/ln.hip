@@ -177,13 +177,15 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
             RS::store(dx + (size_t)row * d, d, lane, o);
         }
     }
-    __shared__ __attribute__((aligned(16))) float sred[LN_WAVES][2048];
+    // LN_WAVES x d floats of dynamic LDS (8 KiB at d = 512): a fixed 32-KiB array left room for only
+    // one of these workgroups per CU beside the weight-gradient GEMM's 128-KiB ring on the other stream
+    extern __shared__ __attribute__((aligned(16))) float sred[];
     float* slot = ws + (size_t)blockIdx.x * 3 * d;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        RS::storef(sred[w], d, lane, k == 0 ? acc_g : (k == 1 ? acc_b : acc_z));
+        RS::storef(sred + (size_t)w * d, d, lane, k == 0 ? acc_g : (k == 1 ? acc_b : acc_z));
         __syncthreads();
-        for (int c = threadIdx.x; c < d; c += LN_WAVES * WAVE) slot[k * d + c] = sred[0][c] + sred[1][c] + sred[2][c] + sred[3][c];
+        for (int c = threadIdx.x; c < d; c += LN_WAVES * WAVE) slot[k * d + c] = sred[c] + sred[d + c] + sred[2 * d + c] + sred[3 * d + c];
         __syncthreads();
     }
 }
@@ -261,7 +263,7 @@ static void launch_ln_bwd(const void* dy, const void* dy2, const void* xhat, con
                           int T_, int d, uint32_t seed, uint32_t thr, float dscale, hipStream_t st) {
     const int grid = ln_grid(rows);
 #define LN_BWD(N, V)                                                                      \
-    add_ln_bwd_kernel<T, N, V, DROP><<<grid, LN_WAVES * WAVE, 0, st>>>(                    \
+    add_ln_bwd_kernel<T, N, V, DROP><<<grid, LN_WAVES * WAVE, (size_t)LN_WAVES * d * sizeof(float), st>>>(                    \
         (const T*)dy, (const T*)dy2, (const T*)xhat, rstd, gamma, lens, (T*)dz, (T*)dx, ws, rows, T_, d, seed, thr, dscale)
     if (d % 512 == 0 && d <= 2048) {
         switch (d / 512) {
