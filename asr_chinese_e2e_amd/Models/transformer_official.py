@@ -82,6 +82,8 @@ class _SpeechTransformer(BaseModel):
                 blocks += E.ffn_param_block(f"decoder.layer_stack.{i}.pos_ffn.", d, ff)
         self._flat = E.FlatParams(blocks)
         self._engine = None
+        self._views_checked = False   # parameters verified to be views of the flat buffer
+        self._grads_checked = False   # .grad attributes verified to be views of the flat gradient
         self._flat_device = None
 
         # ---- nn.Parameters with the reference's names / shapes / init distributions
@@ -152,6 +154,8 @@ class _SpeechTransformer(BaseModel):
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
         f = self._flat
         ok = self._engine is not None and self._flat_device == device
+        if ok and self._views_checked:      # fast path of every step: nothing has touched the parameters' storage
+            return self._engine
         if ok:
             for name, p in self._named_flat_params():
                 off, shape = f.index[name]
@@ -159,6 +163,7 @@ class _SpeechTransformer(BaseModel):
                     ok = False
                     break
         if ok:
+            self._views_checked = True
             return self._engine
         old = {name: p.detach().to(device=device, dtype=torch.float32) for name, p in self._named_flat_params()}
         old_mv = (f.m.to(device), f.v.to(device)) if f.m is not None else None   # keep Adam state across a device move
@@ -177,10 +182,23 @@ class _SpeechTransformer(BaseModel):
         pe = self.encoder.positional_encoding.pe[0].to(device).contiguous()
         self._engine = E.Engine(f, self.config, self.V, self.use_decoder, self.use_ctc, pe)
         self._flat_device = device
+        self._views_checked = True
+        self._grads_checked = True
         return self._engine
+
+    def zero_grad(self, set_to_none=True):
+        self._grads_checked = False      # nn.Module.zero_grad may drop the .grad views
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def _apply(self, fn, *a, **kw):
+        # .cuda() / .to() / .float() replace the parameters' storage: re-validate the flat views on the next step
+        self._views_checked = False
+        self._grads_checked = False
+        return super()._apply(fn, *a, **kw)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         state_dict = {k: v for k, v in state_dict.items()}
+        self._views_checked = False
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._flat.p is not None:
             self._flat.refresh_lowp()
@@ -189,9 +207,12 @@ class _SpeechTransformer(BaseModel):
     def zero_flat_grads(self):
         f = self._flat
         f.g.zero_()
+        if self._grads_checked:             # fast path: .grad views were verified and nobody reset them
+            return
         for name, p in self._named_flat_params():
             if p.grad is None or p.grad.data_ptr() != f.g.data_ptr() + 4 * f.index[name][0]:
                 p.grad = f.view(f.g, name)
+        self._grads_checked = True
 
     # ------------------------------------------------------------------ reference API
     def _prepare(self, input, training=False):

@@ -27,8 +27,17 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_DEV_INDEX = None
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of torch's current stream.  torch.cuda.current_stream() builds a Stream object and
+    resolves the device index through several Python layers (~8 us, ~160 calls per step); the
+    private raw getter is a single C call."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()   # one process per GPU: set once (dist.init / .cuda()) before the first launch
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
 
 
 def _chk_f32(*ts):

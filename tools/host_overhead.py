@@ -28,3 +28,5 @@ for _ in range(10):
     model.iterate(pack, optimizer=opt)
 pr.disable(); torch.cuda.synchronize()
 st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(18)
+print("=== by cumulative time")
+st.sort_stats("cumtime").print_stats(45)
