@@ -437,7 +437,29 @@ def test_gemm_nt_integer_exact(K):
     assert torch.equal(out.cpu().float(), w.float().t())
 
 
-@pytest.mark.parametrize("M,N,K_", [(256, 128, 128), (1000, 512, 80), (4000, 1536, 512), (513, 4232, 64), (70, 40, 24)])
+@pytest.mark.parametrize("N,K_", [(1536, 512), (4232, 512), (512, 1024)])
+def test_gemm_full_size_persistent_paths(K, N, K_):
+    """BASELINE-size GEMMs (M = 16000): every workgroup of the persistent NT kernel walks several
+    tiles (ring and vmcnt accounting across tile boundaries, interior and edge tiles), the wgrad
+    kernel takes both its ring-4 and its two-per-CU ring-2 form.  Reference: fp32 GEMM on the GPU."""
+    M = 16000
+    torch.manual_seed(N)
+    a = torch.randn(M, K_, device=DEV).bfloat16()
+    w = (torch.randn(N, K_, device=DEV) * 0.05).bfloat16()
+    b = torch.randn(N, device=DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    for _ in range(2):          # second launch: same result with warm caches / different arrival order
+        K.gemm_nt(a, w, b, out, 1)
+        ref = torch.relu(a.float() @ w.float().t() + b)
+        close(out, ref, rtol=1e-2, atol=1e-2, what="persistent gemm_nt")
+    dy = (torch.randn(M, N, device=DEV) * 0.5).bfloat16()
+    dw = torch.zeros(N, K_, device=DEV)
+    K.gemm_tn(dy, a, dw, accumulate=True)
+    ref = dy.float().t() @ a.float()
+    close(dw, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="dma gemm_tn")
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 128, 128), (1000, 512, 80), (4000, 1536, 512), (513, 4232, 64), (70, 40, 24), (8197, 512, 512)])
 def test_gemm_tn(K, M, N, K_):
     torch.manual_seed(M + K_)
     dy = (torch.randn(M, N) * 0.5).bfloat16()
