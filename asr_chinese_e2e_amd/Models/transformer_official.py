@@ -272,7 +272,29 @@ class _SpeechTransformer(BaseModel):
         pack.add(loss=loss[0])
         if self.use_decoder:
             pack.add(cer=torch.Tensor([self._cer(output.pred, output.gold)]))
+        if self.use_ctc:
+            # best-path CTC decoding on the device; the label strings (no sos/eos) are the reference
+            cer = self._ctc_cer(output.ctc_logits.contiguous(), input.wave_len.to(torch.int32), prep[2], prep[4])
+            pack.add(**({"ctc_cer": torch.Tensor([cer])} if self.use_decoder else {"cer": torch.Tensor([cer])}))
         return pack
+
+    def ctc_greedy_search(self, input):
+        """Best-path CTC hypotheses of a batch: list of id lists (repeats merged, blanks removed)."""
+        with torch.no_grad():
+            out = self.forward(input)
+        ids, lens = K.ctc_greedy_decode(out.ctc_logits.contiguous(), input.wave_len.to(torch.int32), PAD_ID)
+        ids, lens = ids.cpu(), lens.cpu()
+        return [ids[b, : int(lens[b])].tolist() for b in range(ids.shape[0])]
+
+    def _ctc_cer(self, logits, wave_len, labels32, lab_len):
+        ids, lens = K.ctc_greedy_decode(logits, wave_len, PAD_ID)
+        ids, lens, labels32, lab_len = ids.cpu(), lens.cpu(), labels32.cpu(), lab_len.cpu()
+        tot = 0.0
+        for b in range(ids.shape[0]):
+            hyp = self.vocab.convert_id2str(ids[b, : int(lens[b])].tolist())
+            ref = self.vocab.convert_id2str(labels32[b, : int(lab_len[b])].tolist())
+            tot += calculate_cer(hyp, ref)
+        return tot * 100 / ids.shape[0]
 
     def train_step(self, input, loss_scale=1.0, n_valid_override=None, ctc_batch=None):
         """Forward + backward into the flat gradient buffer (no optimizer).  Returns the metrics

@@ -36,6 +36,7 @@ SIGNATURES = {
     "asr_sdpa_dropout_mask": (I, [P, I, I, I, I, F, U, P]),
     "asr_ctc_workspace_bytes": (Z, [I, I, I]),
     "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, P, Z, I, P]),
+    "asr_ctc_greedy_decode": (I, [P, P, P, P, I, I, I, I, I, P]),
     "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),
     "asr_dec_preprocess": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "asr_embed_pe_fwd": (I, [P, P, P, P, F, I, I, I, I, F, U, I, P]),

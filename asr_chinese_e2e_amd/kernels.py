@@ -207,6 +207,18 @@ def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, ze
     return nll, dlogits
 
 
+def ctc_greedy_decode(logits, in_len, blank=0):
+    """logits (B,T,V) -> (ids (B,T) int32, collapsed and 0-padded; lens (B,) int32)."""
+    B, T, V = logits.shape
+    assert logits.is_contiguous()
+    _chk_i32(in_len)
+    ids = torch.empty(B, T, dtype=torch.int32, device=logits.device)
+    lens = torch.empty(B, dtype=torch.int32, device=logits.device)
+    check(lib.asr_ctc_greedy_decode(_p(logits), _p(in_len), _p(ids), _p(lens), B, T, V, int(blank), _dt(logits), _stream()),
+          "asr_ctc_greedy_decode")
+    return ids, lens
+
+
 def xent_fwd_bwd(logits, gold, n_valid, ignore_index=0, smoothing=0.0, grad_scale=1.0, dlogits=None, want_grad=True,
                  row_nll=None):
     M, V = logits.shape

@@ -142,6 +142,16 @@ int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len,
                     size_t ws_bytes, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Greedy CTC decoding: per-frame argmax over the vocabulary (first index wins ties, as
+ * torch.argmax), frames t >= in_len[b] count as blank, then the CTC collapse (merge repeats, drop
+ * blanks).  NOT in the reference (no CTC there; its decoder-side search is the Python beam loop
+ * transformer_official.py:331-434) - SURVEY.md 8(f) rank 1.
+ * logits: (B, T, V) `dtype`; out_ids: (B, T) int32 = collapsed label ids, 0-padded; out_len: (B).
+ */
+int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* out_ids,
+                          int32_t* out_len, int B, int T, int V, int blank, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Softmax cross-entropy with ignore_index, forward + gradient in one pass over the logits.
  * Replaces:  F.cross_entropy(pred, gold, ignore_index=0, reduction='mean')  Utils/loss.py:47-49
  *            (+ label smoothing branch Utils/loss.py:30-45 when smoothing > 0)

@@ -228,6 +228,36 @@ def cer_percent(pred, gold, id2token, greedy="topk"):
     return tot * 100.0 / len(gold)
 
 
+def ctc_greedy_decode(logits, lens, blank=0):
+    """Best-path CTC decoding (Graves 2006, B(.)): argmax per frame (first index on ties), merge
+    repeats, drop blanks.  NOT in the reference (no CTC there): parity unpinned by the reference,
+    pinned by hand-made paths in tests/test_oracle_ctc.py.  logits (B,T,V) array-like; returns a
+    list of id lists."""
+    import numpy as np
+    x = np.asarray(logits, dtype=np.float64)
+    out = []
+    for b in range(x.shape[0]):
+        path = x[b, : int(lens[b])].argmax(-1)
+        hyp, prev = [], blank
+        for p in path:
+            p = int(p)
+            if p != blank and p != prev:
+                hyp.append(p)
+            prev = p
+        out.append(hyp)
+    return out
+
+
+def ctc_cer_percent(hyps, labels, lab_len, id2token):
+    """CER of collapsed CTC hypotheses against the label sequences, with the reference's CER
+    convention (score.py:11-13: edit distance over the space-joined strings / reference tokens)."""
+    tot = 0.0
+    for h, g, n in zip(hyps, labels, lab_len):
+        hs, gs = ids_to_str(h, id2token), ids_to_str(list(g[: int(n)]), id2token)
+        tot += edit_distance(hs, gs) / max(len(gs.split(" ")), 1)
+    return tot * 100.0 / len(hyps)
+
+
 # ----------------------------------------------------------------------------- optimizer
 def noam_rate(step, model_size, warmup, factor=1.0):
     """Trainer/optimizer.py:24-28."""

@@ -254,6 +254,29 @@ def test_ctc_rows_kernel_inplace_and_padding(K, ws):
         assert float(dl[b, in_len[b]:].abs().max() if in_len[b] < 24 else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,V", [(3, 37, 11), (4, 130, 64), (2, 500, 4232)])
+def test_ctc_greedy_decode(K, dtype, B, T, V):
+    from oracle import ref_model as R
+    rng = np.random.RandomState(B * T + V)
+    # peaked logits along a random path with repeats and blanks, plus noise and a few exact ties
+    path = rng.randint(0, min(V, 6), size=(B, T))
+    path[:, 1::3] = path[:, 0:-1:3][:, : path[:, 1::3].shape[1]]
+    x = rng.randn(B, T, V).astype(np.float32)
+    np.put_along_axis(x, path[..., None], 6.0, axis=-1)
+    x[0, 2, :] = 0.0                  # all-equal frame: first index (= blank) wins
+    x[1, 3, 1] = x[1, 3, 4] = 9.0      # two-way tie: id 1 wins
+    lens = rng.randint(T // 2, T + 1, size=B)
+    lens[0] = T
+    lt = torch.from_numpy(x).to(dtype)
+    want = R.ctc_greedy_decode(lt.float().numpy(), lens)
+    ids, n = K.ctc_greedy_decode(lt.to(DEV), torch.from_numpy(lens).int().to(DEV))
+    ids, n = ids.cpu(), n.cpu()
+    for b in range(B):
+        assert ids[b, : int(n[b])].tolist() == want[b]
+        assert int(ids[b, int(n[b]):].abs().sum()) == 0
+
+
 def test_ctc_full_size_properties(K, ws):
     """BASELINE size (B=32, T=500, V=4232): size-independent properties - every gradient row of a
     valid frame sums to 0 (softmax minus a distribution), padded frames are exactly 0, and the

@@ -181,6 +181,30 @@ def test_bf16_mfma_path_matches_oracle(mode):
     assert worst > 0.99
 
 
+@pytest.mark.parametrize("mode", ["ctc_only", "joint"])
+def test_ctc_greedy_cer_matches_oracle(mode):
+    """Evaluation of a CTC model reports the CER of best-path decoding: the device decode of the
+    model's own logits equals the oracle's decode, and the CER follows the reference's convention."""
+    over = dict(d_model=32, hidden_size=8, num_head=4, ff_size=64, layer_num=2)
+    over.update(dict(use_decoder=False, ctc_weight=1.0) if mode == "ctc_only" else dict(ctc_weight=0.3))
+    cfg, sd, batch = oracle_case(5, 40, 16, 30, 7, over)
+    model = build(cfg, 30, "TransformerCTC" if mode == "ctc_only" else "TransformerOffical", dtype="fp32").cuda()
+    model.load_state_dict({k: v for k, v in sd.items()})
+    model.eval()
+    pack = to_pack(batch)
+    out = model.forward(pack)
+    want = R.ctc_greedy_decode(out.ctc_logits.float().cpu().numpy(), batch["wave_len"].numpy())
+    assert model.ctc_greedy_search(pack) == want
+    labels = [[int(t) for t in row if int(t) != 0] for row in batch["tgt_for_input"]]   # Decoder.preprocess strips the 0 padding
+    ev, _ = model.iterate(pack, is_train=False)
+    key = "cer" if mode == "ctc_only" else "ctc_cer"
+    hyp_s = [model.vocab.convert_id2str(h) for h in want]
+    ref_s = [model.vocab.convert_id2str(l) for l in labels]
+    cer = sum(R.edit_distance(h, r) / len(r.split(" ")) for h, r in zip(hyp_s, ref_s)) * 100 / len(want)
+    assert abs(float(getattr(ev, key)) - cer) < 1e-4
+    assert np.isfinite(float(ev.loss))
+
+
 def test_padded_rows_are_exact_zero_and_ignore_garbage():
     """Post-LN pad zeroing (transformer_official.py:208, 211): encoder output rows t >= wave_len are
     exactly 0 and garbage in the padded input frames cannot change any valid output."""

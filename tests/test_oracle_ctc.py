@@ -62,3 +62,21 @@ def test_matches_torch_fp64(seed):
     tn, tg = torch_ctc(logits, in_len, labels, lab_len, zero_infinity=True)
     assert np.allclose(nll, tn, rtol=1e-10, atol=1e-10)
     assert np.allclose(g, tg, rtol=1e-8, atol=1e-10)
+
+
+def test_greedy_decode_known_answers():
+    """Best-path decoding on hand-made paths: repeats merge, blanks split repeats, padded frames ignored."""
+    import numpy as np
+    from oracle import ref_model as R
+    V = 6
+    paths = [[0, 3, 3, 0, 3, 4, 4, 0, 0, 5], [2, 2, 2, 2, 2, 2, 2, 2, 2, 2], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 0, 0, 2, 3, 3, 1]]
+    lens = [10, 10, 10, 7]
+    x = np.full((4, 10, V), -1.0)
+    for b, p in enumerate(paths):
+        for t, c in enumerate(p):
+            x[b, t, c] = 2.0
+    assert R.ctc_greedy_decode(x, lens) == [[3, 3, 4, 5], [2], [], [1, 1, 2]]
+    x[0, 1, 4] = 2.0      # tie between ids 3 and 4 at frame 1: the first index (3) wins
+    assert R.ctc_greedy_decode(x, lens)[0] == [3, 3, 4, 5]
+    toks = {i: str(i) for i in range(V)}
+    assert R.ctc_cer_percent([[3, 3, 4, 5], [2]], [[3, 4, 5, 0], [2, 0, 0, 0]], [3, 1], toks) == pytest.approx(100.0 * (2 / 3 + 0) / 2)
