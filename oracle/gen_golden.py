@@ -306,6 +306,76 @@ def op_cases():
     print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB")
 
 
+def beam_case(name, cfg, B, T, V, wave_len, seed, beam, nbest, decode_max_len):
+    """Golden hypotheses of the reference's own beam search (Decoder.recognize_beam,
+    transformer_official.py:331-434) on a small random model, one utterance at a time as the
+    reference does.  Stored: weights, inputs, encoder output, and per utterance the n-best token
+    sequences (with sos/eos) and scores."""
+    import contextlib
+    import io
+    from Predictor import Models
+    from Predictor.data_handler import Vocab
+    from Predictor.Utils import Pack
+
+    torch.manual_seed(seed)
+    Model = Models.TransformerOffical
+    config = Model.get_default_config()()
+    config.fn_build(dict(cfg))
+    vocab = make_vocab(Vocab, V)
+    model = Model(config, vocab)
+    model.eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "layer_norm" in n and n.endswith("weight"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.add_(0.05 * torch.randn_like(p))
+        # sharpen the output distribution a little so that hypotheses end (eos) before maxlen sometimes
+        model.decoder.tgt_word_emb.weight.mul_(3.0)
+    F = cfg["n_mels"] * cfg["lfr_m"]
+    pack = make_batch(Pack, B, T, F, 3, V, wave_len, [1] * B, seed + 1)
+    out = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("positional_encoding.pe"):
+            out["pe_head/" + k] = _np(v[:, :64])
+        else:
+            out["sd/" + k] = _np(v)
+    out["in/wave"] = _np(pack.wave)
+    out["in/wave_len"] = _np(pack.wave_len)
+    # torch >= 1.2 rejects the uint8 mask recognize_beam builds (masked_fill wants bool; the training
+    # path converts with .gt(0), this one does not): cast that ONE mask to bool here - same values,
+    # the reference's files are untouched.  Without it the reference's beam search cannot run at all.
+    import Predictor.Models.transformer_official as TO
+    orig_mask = TO.get_subsequent_mask
+    TO.get_subsequent_mask = lambda seq: orig_mask(seq).bool()
+    char_list = [str(i) for i in range(V)]
+    args = types.SimpleNamespace(beam_size=beam, nbest=nbest, decode_max_len=decode_max_len)
+    with torch.no_grad():
+        enc_out = model.encoder(pack.wave, pack.wave_len)[0]
+        out["fwd/enc_out"] = _np(enc_out)
+        for b in range(B):
+            with contextlib.redirect_stdout(io.StringIO()):
+                hyps = model.decoder.recognize_beam(enc_out[b, : int(pack.wave_len[b])], char_list, args)
+            L = max(len(h["yseq"]) for h in hyps)
+            seqs = np.zeros((len(hyps), L), dtype=np.int64)
+            for i, h in enumerate(hyps):
+                seqs[i, : len(h["yseq"])] = h["yseq"]
+            out[f"beam/{b}/yseq"] = seqs
+            out[f"beam/{b}/len"] = np.array([len(h["yseq"]) for h in hyps], dtype=np.int64)
+            out[f"beam/{b}/score"] = np.array([float(h["score"]) for h in hyps], dtype=np.float64)
+            print(f"  utt {b}: " + "; ".join(f"{h['yseq']} {float(h['score']):.4f}" for h in hyps))
+    TO.get_subsequent_mask = orig_mask
+    out["cfg/keys"] = np.array(sorted(cfg.keys()))
+    out["cfg/vals"] = np.array([float(cfg[k]) for k in sorted(cfg.keys())])
+    out["cfg/V"] = np.int64(V)
+    out["cfg/beam"] = np.int64(beam)
+    out["cfg/nbest"] = np.int64(nbest)
+    out["cfg/decode_max_len"] = np.int64(decode_max_len)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -313,6 +383,10 @@ def main():
     torch.set_num_threads(4)
     base = dict(n_mels=20, lfr_m=1, d_model=32, hidden_size=8, ff_size=64, num_head=4,
                 dropout=0.0, layer_num=2)
+    if len(sys.argv) > 1 and sys.argv[1] == "beam":     # only the beam-search fixtures (the others stay byte-identical)
+        beam_case("beam_small", base, B=3, T=20, V=12, wave_len=[20, 13, 7], seed=31, beam=3, nbest=3, decode_max_len=0)
+        beam_case("beam_small_maxlen", dict(base, layer_num=1), B=2, T=16, V=9, wave_len=[16, 10], seed=37, beam=4, nbest=2, decode_max_len=6)
+        return
     # ragged case: one full-length row, one length-1 target, short utterances
     model_case("model_small_ragged", base, B=4, T=24, Lmax=7, V=30,
                wave_len=[24, 17, 9, 13], tgt_len=[7, 3, 1, 5], seed=11)

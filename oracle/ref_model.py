@@ -145,6 +145,57 @@ def decoder_forward(sd, cfg, tgt, enc_out, cross_len, loop_masks=False):
     return pred, ys_out
 
 
+def decoder_step_logits(sd, cfg, ys, enc_out):
+    """The decoder pass recognize_beam runs for ONE hypothesis (transformer_official.py:360-379):
+    ys (1, i) ids, causal self-attention mask only, NO cross-attention mask, all-ones non_pad;
+    returns log_softmax of the last position (V,)."""
+    i = ys.shape[1]
+    d = cfg.d_model
+    emb = sd["decoder.tgt_word_emb.weight"]
+    causal = torch.triu(torch.ones(i, i, dtype=torch.bool), diagonal=1).unsqueeze(0)
+    nomask = torch.zeros(1, i, enc_out.shape[1], dtype=torch.bool)
+    x = emb[ys] * (d ** -0.5) + positional_encoding(i, d, enc_out.dtype).unsqueeze(0)
+    for l in range(cfg.layer_num):
+        pre = f"decoder.layer_stack.{l}."
+        x = multi_head_attention(sd, pre + "slf_attn.", x, x, causal, cfg.num_head, cfg.hidden_size)
+        x = multi_head_attention(sd, pre + "enc_attn.", x, enc_out, nomask, cfg.num_head, cfg.hidden_size)
+        x = feed_forward(sd, pre + "pos_ffn.", x)
+    return F.log_softmax(F.linear(x[:, -1], emb), dim=1)[0]
+
+
+def beam_search(sd, cfg, enc_out, beam, nbest=1, decode_max_len=0):
+    """Decoder.recognize_beam (transformer_official.py:331-434) for one utterance: enc_out (T, d).
+    Every live hypothesis is extended by its `beam` best tokens, the best `beam` of all extensions
+    survive, those that end in eos leave the beam for the ended list; at the last step eos is
+    appended to whatever is left.  Scores are sums of log-softmax values, no length normalisation.
+    Returns [(ids incl. sos/eos, score)] sorted by score, at most nbest.  Pinned by the golden
+    vectors tests/golden/beam_*.npz (the reference's own search, see oracle/gen_golden.py)."""
+    T = enc_out.shape[0]
+    maxlen = T if decode_max_len == 0 else decode_max_len
+    enc = enc_out.unsqueeze(0)
+    hyps = [(0.0, [SOS_ID])]
+    ended = []
+    for i in range(maxlen):
+        kept = []
+        for score, seq in hyps:
+            lp = decoder_step_logits(sd, cfg, torch.tensor([seq]), enc)
+            vals, ids = torch.topk(lp, beam)
+            for j in range(beam):
+                kept.append((score + float(vals[j]), seq + [int(ids[j])]))
+            kept = sorted(kept, key=lambda h: h[0], reverse=True)[:beam]      # stable, as the reference's sorted()
+        hyps = kept
+        if i == maxlen - 1:
+            hyps = [(s_, q + [EOS_ID]) for s_, q in hyps]
+        remained = []
+        for h in hyps:
+            (ended if h[1][-1] == EOS_ID else remained).append(h)
+        hyps = remained
+        if not hyps:
+            break
+    ended = sorted(ended, key=lambda h: h[0], reverse=True)[: min(len(ended), nbest)]
+    return [(q, s_) for s_, q in ended]
+
+
 def ce_loss(pred, gold, smoothing=0.0):
     """Utils/loss.py:26-51."""
     pred = pred.reshape(-1, pred.shape[-1])

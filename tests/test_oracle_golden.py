@@ -171,3 +171,23 @@ def test_logmel_oracle_selfconsistency():
     assert fb[: 1].sum() == 0                  # 0 Hz bin is below f_min = 40 Hz
     n = LM.utt_normalize(lm)
     assert abs(n.mean()) < 1e-12 and abs(n.std(ddof=1) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["beam_small.npz", "beam_small_maxlen.npz"])
+def test_beam_search_oracle_matches_reference_golden(case):
+    """oracle.beam_search against the reference's own Decoder.recognize_beam (n-best token sequences
+    exactly, scores to 1e-4) - generated by oracle/gen_golden.py beam."""
+    import numpy as np
+    z = load_npz(case)
+    cfg = R.default_cfg(**{k: (int(v) if float(v).is_integer() else float(v)) for k, v in zip(z["cfg/keys"], z["cfg/vals"])})
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    enc = torch.from_numpy(z["fwd/enc_out"])
+    lens = z["in/wave_len"]
+    beam, nbest, dml = int(z["cfg/beam"]), int(z["cfg/nbest"]), int(z["cfg/decode_max_len"])
+    for b in range(enc.shape[0]):
+        got = R.beam_search(sd, cfg, enc[b, : int(lens[b])], beam, nbest, dml)
+        want_seq, want_len, want_score = z[f"beam/{b}/yseq"], z[f"beam/{b}/len"], z[f"beam/{b}/score"]
+        assert len(got) == len(want_len)
+        for (ids, score), ws, wl, wsc in zip(got, want_seq, want_len, want_score):
+            assert ids == [int(t) for t in ws[: int(wl)]]
+            assert abs(score - float(wsc)) < 1e-4
