@@ -278,6 +278,13 @@ class _SpeechTransformer(BaseModel):
             pack.add(**({"ctc_cer": torch.Tensor([cer])} if self.use_decoder else {"cer": torch.Tensor([cer])}))
         return pack
 
+    def beam_search(self, input, beam_size=5, nbest=1, decode_max_len=0):
+        """Attention-decoder beam search for a batch (Decoder.recognize_beam, transformer_official.py:
+        331-434, batched on the GPU with key/value caches): per utterance a list of at most `nbest`
+        {'yseq': [sos, ..., eos], 'score': float}."""
+        from .. import decode
+        return decode.beam_search(self, input, beam_size, nbest, decode_max_len)
+
     def ctc_greedy_search(self, input):
         """Best-path CTC hypotheses of a batch: list of id lists (repeats merged, blanks removed)."""
         with torch.no_grad():
@@ -356,11 +363,9 @@ class _SpeechTransformer(BaseModel):
             metrics.add(cer=torch.Tensor([sum(calculate_cer(h, r) for h, r in zip(hyp, ref)) * 100 / len(hyp)]))
         return metrics, None
 
-    def greedy_search(self):
-        pass
-
-    def beam_search(self):
-        pass
+    def greedy_search(self, input, decode_max_len=0):
+        """transformer_official.py:106-107 is an empty stub in the reference; here: beam search with one beam."""
+        return self.beam_search(input, 1, 1, decode_max_len)
 
     @classmethod
     def get_default_config(cls):

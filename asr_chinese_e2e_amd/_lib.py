@@ -37,6 +37,10 @@ SIGNATURES = {
     "asr_ctc_workspace_bytes": (Z, [I, I, I]),
     "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, P, Z, I, P]),
     "asr_ctc_greedy_decode": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "asr_decode_attn": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
+    "asr_logsoftmax_topk": (I, [P, P, P, I, I, I, I, I, P]),
+    "asr_beam_step": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "asr_cache_gather": (I, [P, P, P, I, I, I, I, I, I, P]),
     "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),
     "asr_dec_preprocess": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "asr_embed_pe_fwd": (I, [P, P, P, P, F, I, I, I, I, F, U, I, P]),

@@ -104,3 +104,221 @@ extern "C" int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, 
     ASR_CHECK_LAUNCH("asr_ctc_greedy_decode");
     return ASR_OK;
 }
+
+// ================================================================================================
+// Attention-decoder beam search (transformer_official.py:331-434), batched over utterances and
+// beams with key/value caches.  The reference re-runs the whole decoder over the growing prefix for
+// every hypothesis and step (O(len^2) layers per hypothesis, Python loop, one utterance at a
+// time); here one step costs one token per live hypothesis:
+//   asr_decode_attn        single-query attention over a K/V cache (self) or the encoder K/V (cross)
+//   asr_logsoftmax_topk    log_softmax over the vocabulary + the `beam` best entries per row
+//   asr_beam_step          per utterance: merge beam x beam candidates, keep the best `beam`
+//                          (stable order, as Python's sorted()), retire hypotheses that emitted
+//                          eos, force eos at the last step; records (token, parent, end, score)
+//                          per step for the host-side backtrace
+//   asr_cache_gather       reorder the self-attention caches by parent hypothesis
+namespace {
+
+// one wave per (row r, head h).  Keys/values of row r are rows (r / kv_div) * Tk_cap + t of k / v.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ o,
+                                                          const int32_t* __restrict__ k_len, int k_len_uniform, int len_div, int R, int H, int dk,
+                                                          int Tk_cap, int kv_div, int ldq, int ldk, int ldv, int ldo, float scale) {
+    extern __shared__ float sc_all[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* sc = sc_all + (size_t)w * Tk_cap;
+    const int pair = blockIdx.x * 4 + w;
+    if (pair >= R * H) return;
+    const int r = pair / H, h = pair - r * H;
+    int n = k_len ? k_len[r / len_div] : k_len_uniform;
+    n = min(n, Tk_cap);
+    const T* qp = q + (size_t)r * ldq + h * dk;
+    const size_t kv_row0 = (size_t)(r / kv_div) * Tk_cap;
+    const T* kp = k + kv_row0 * ldk + h * dk;
+    const T* vp = v + kv_row0 * ldv + h * dk;
+    // phase 1: lane per key
+    float m = -INFINITY;
+    for (int t = lane; t < n; t += 64) {
+        const T* kr = kp + (size_t)t * ldk;
+        float s = 0.f;
+        for (int d = 0; d < dk; ++d) s = fmaf(to_f32<T>(qp[d]), to_f32<T>(kr[d]), s);
+        s *= scale;
+        sc[t] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int t = lane; t < n; t += 64) {
+        const float e = expf(sc[t] - m);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    // phase 2: lane per output dimension
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    for (int d = lane; d < dk; d += 64) {
+        float acc = 0.f;
+        for (int t = 0; t < n; ++t) acc = fmaf(sc[t], to_f32<T>(vp[(size_t)t * ldv + d]), acc);
+        o[(size_t)r * ldo + h * dk + d] = from_f32<T>(acc * inv);
+    }
+}
+
+// one wave per row: vals[j] = j-th largest log_softmax value (ties: smaller index first), ids[j] its index
+template <typename T>
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restrict__ logits, float* __restrict__ vals, int32_t* __restrict__ ids, int R, int V,
+                                                              int ld, int beam) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    if (r >= R) return;
+    const T* x = logits + (size_t)r * ld;
+    float m = -INFINITY;
+    for (int i = lane; i < V; i += 64) m = fmaxf(m, to_f32<T>(x[i]));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < V; i += 64) s += expf(to_f32<T>(x[i]) - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    float last_v = INFINITY;
+    int last_i = -1;
+    for (int j = 0; j < beam; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < V; i += 64) {
+            const float xv = to_f32<T>(x[i]);
+            const bool eligible = xv < last_v || (xv == last_v && i > last_i);   // strictly after the previous pick
+            if (eligible && (xv > bv || (xv == bv && i < bi))) { bv = xv; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+        }
+        if (lane == 0) {
+            vals[(size_t)r * beam + j] = bv - lse;
+            ids[(size_t)r * beam + j] = bi == 0x7fffffff ? 0 : bi;
+        }
+        last_v = bv;
+        last_i = bi;
+    }
+}
+
+// one 64-lane workgroup per utterance; beam * beam <= 64
+__global__ __launch_bounds__(64) void beam_step_kernel(const float* __restrict__ top_vals, const int32_t* __restrict__ top_ids, float* __restrict__ score,
+                                                       int32_t* __restrict__ alive, int32_t* __restrict__ last_tok, int32_t* __restrict__ parent,
+                                                       int32_t* __restrict__ rec_tok, int32_t* __restrict__ rec_par, int32_t* __restrict__ rec_end,
+                                                       float* __restrict__ rec_score, const int32_t* __restrict__ maxlen, int32_t* __restrict__ alive_total,
+                                                       int B, int beam, int step, int eos) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const int h = c / beam, j = c - h * beam;
+    const bool valid = c < beam * beam && alive[b * beam + h] != 0 && step < maxlen[b];
+    const float cs = valid ? score[b * beam + h] + top_vals[(size_t)(b * beam + h) * beam + j] : -INFINITY;
+    // stable rank among the valid candidates (Python sorted(reverse=True) keeps first-come order on ties)
+    int rank = 0;
+    for (int o = 0; o < 64; ++o) {
+        const float so = __shfl(cs, o, 64);
+        const int vo = __shfl((int)valid, o, 64);
+        if (vo && (so > cs || (so == cs && o < c))) ++rank;
+    }
+    const bool keep = valid && rank < beam;
+    const int tok = keep ? top_ids[(size_t)(b * beam + h) * beam + j] : 0;
+    const bool last = step == maxlen[b] - 1;
+    __syncthreads();   // every lane has read the old state
+    // default for the slots no candidate lands in
+    if (c < beam) {
+        const size_t rec = ((size_t)step * B + b) * beam + c;
+        alive[b * beam + c] = 0;
+        parent[b * beam + c] = c;
+        rec_tok[rec] = 0;
+        rec_par[rec] = 0;
+        rec_end[rec] = 0;
+        rec_score[rec] = -INFINITY;
+    }
+    __syncthreads();
+    if (keep) {
+        const int kslot = rank;
+        const size_t rec = ((size_t)step * B + b) * beam + kslot;
+        // a hypothesis leaves the beam when it emits eos; at the last step eos is APPENDED to every
+        // survivor (also after an eos of its own: transformer_official.py:399-403)
+        const int end = last ? 2 : (tok == eos ? 1 : 0);
+        score[b * beam + kslot] = cs;
+        last_tok[b * beam + kslot] = tok;
+        parent[b * beam + kslot] = h;
+        alive[b * beam + kslot] = end ? 0 : 1;
+        rec_tok[rec] = tok;
+        rec_par[rec] = h;
+        rec_end[rec] = end;
+        rec_score[rec] = cs;
+        if (!end) atomicAdd(alive_total, 1);
+    }
+}
+
+// dst[l][r][t][:] = src[l][b*beam + parent[r]][t][:]  for t < n_pos; rows of row_bytes bytes (multiple of 16)
+__global__ __launch_bounds__(256) void cache_gather_kernel(const char* __restrict__ src, char* __restrict__ dst, const int32_t* __restrict__ parent, int L, int R,
+                                                           int beam, int Lcap, int n_pos, int row_bytes) {
+    const int lr = blockIdx.x;   // l * R + r
+    const int l = lr / R, r = lr - l * R;
+    const int b = r / beam;
+    const int pr = b * beam + parent[r];
+    const size_t per_row = (size_t)Lcap * row_bytes;
+    const u32x4* s = (const u32x4*)(src + ((size_t)l * R + pr) * per_row);
+    u32x4* d = (u32x4*)(dst + ((size_t)l * R + r) * per_row);
+    const int nvec = n_pos * (row_bytes / 16);
+    for (int i = threadIdx.x; i < nvec; i += 256) d[i] = s[i];
+}
+
+}  // namespace
+
+extern "C" int asr_decode_attn(const void* q, const void* k, const void* v, void* o, const int32_t* k_len, int k_len_uniform, int len_div, int R, int H,
+                               int dk, int Tk_cap, int kv_div, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream) {
+    if (!q || !k || !v || !o) ASR_FAIL(ASR_EINVAL, "asr_decode_attn: null pointer");
+    if (R <= 0 || H <= 0 || dk <= 0 || Tk_cap <= 0 || kv_div <= 0 || len_div <= 0) ASR_FAIL(ASR_EINVAL, "asr_decode_attn: bad shape R=%d H=%d dk=%d Tk=%d", R, H, dk, Tk_cap);
+    if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_decode_attn: dtype %d", dtype);
+    const size_t lds = (size_t)4 * Tk_cap * sizeof(float);
+    if (lds > 160 * 1024) ASR_FAIL(ASR_EINVAL, "asr_decode_attn: Tk_cap=%d does not fit the LDS score buffer", Tk_cap);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ceil_div(R * H, 4);
+    if (dtype == ASR_F32) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)decode_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        decode_attn_kernel<float><<<grid, 256, lds, st>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, k_len, k_len_uniform, len_div, R, H, dk, Tk_cap, kv_div, ldq, ldk, ldv, ldo, scale);
+    } else {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)decode_attn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        decode_attn_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, k_len, k_len_uniform, len_div, R, H, dk, Tk_cap, kv_div, ldq, ldk, ldv, ldo, scale);
+    }
+    ASR_CHECK_LAUNCH("asr_decode_attn");
+    return ASR_OK;
+}
+
+extern "C" int asr_logsoftmax_topk(const void* logits, float* vals, int32_t* ids, int R, int V, int ld, int beam, int dtype, void* stream) {
+    if (!logits || !vals || !ids) ASR_FAIL(ASR_EINVAL, "asr_logsoftmax_topk: null pointer");
+    if (R <= 0 || V <= 0 || ld < V || beam <= 0 || beam > V) ASR_FAIL(ASR_EINVAL, "asr_logsoftmax_topk: bad shape R=%d V=%d ld=%d beam=%d", R, V, ld, beam);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ASR_F32) logsoftmax_topk_kernel<float><<<ceil_div(R, 4), 256, 0, st>>>((const float*)logits, vals, ids, R, V, ld, beam);
+    else if (dtype == ASR_BF16) logsoftmax_topk_kernel<bf16_t><<<ceil_div(R, 4), 256, 0, st>>>((const bf16_t*)logits, vals, ids, R, V, ld, beam);
+    else ASR_FAIL(ASR_EDTYPE, "asr_logsoftmax_topk: dtype %d", dtype);
+    ASR_CHECK_LAUNCH("asr_logsoftmax_topk");
+    return ASR_OK;
+}
+
+extern "C" int asr_beam_step(const float* top_vals, const int32_t* top_ids, float* score, int32_t* alive, int32_t* last_tok, int32_t* parent, int32_t* rec_tok,
+                             int32_t* rec_par, int32_t* rec_end, float* rec_score, const int32_t* maxlen, int32_t* alive_total, int B, int beam, int step,
+                             int eos, void* stream) {
+    if (!top_vals || !top_ids || !score || !alive || !last_tok || !parent || !rec_tok || !rec_par || !rec_end || !rec_score || !maxlen || !alive_total)
+        ASR_FAIL(ASR_EINVAL, "asr_beam_step: null pointer");
+    if (B <= 0 || beam <= 0 || beam * beam > 64 || step < 0) ASR_FAIL(ASR_EINVAL, "asr_beam_step: bad shape B=%d beam=%d (beam <= 8) step=%d", B, beam, step);
+    beam_step_kernel<<<B, 64, 0, (hipStream_t)stream>>>(top_vals, top_ids, score, alive, last_tok, parent, rec_tok, rec_par, rec_end, rec_score, maxlen, alive_total, B, beam, step, eos);
+    ASR_CHECK_LAUNCH("asr_beam_step");
+    return ASR_OK;
+}
+
+extern "C" int asr_cache_gather(const void* src, void* dst, const int32_t* parent, int L, int R, int beam, int Lcap, int n_pos, int row_bytes, void* stream) {
+    if (!src || !dst || !parent) ASR_FAIL(ASR_EINVAL, "asr_cache_gather: null pointer");
+    if (L <= 0 || R <= 0 || beam <= 0 || R % beam || Lcap <= 0 || n_pos < 0 || n_pos > Lcap || row_bytes <= 0 || row_bytes % 16) ASR_FAIL(ASR_EINVAL, "asr_cache_gather: bad shape");
+    if (((uintptr_t)src | (uintptr_t)dst) % 16) ASR_FAIL(ASR_EINVAL, "asr_cache_gather: misaligned pointer");
+    if (n_pos > 0) cache_gather_kernel<<<L * R, 256, 0, (hipStream_t)stream>>>((const char*)src, (char*)dst, parent, L, R, beam, Lcap, n_pos, row_bytes);
+    ASR_CHECK_LAUNCH("asr_cache_gather");
+    return ASR_OK;
+}

@@ -1,0 +1,113 @@
+"""Beam search of the attention decoder on the GPU.
+
+Same search as the reference's Decoder.recognize_beam (Predictor/Models/transformer_official.py:
+331-434) - see include/asr_hip.h for the exact rules - but batched over utterances x beams, one
+token per live hypothesis per step through key/value caches, instead of re-running the whole
+decoder over the growing prefix for every hypothesis in a Python loop.
+
+Device state per step: scores / alive flags / last tokens (B, beam); per layer a self-attention
+K|V cache (B*beam, Lcap, 2*H*dk) in two copies (the step's survivors are gathered by parent into
+the other copy); the encoder-side K|V of every layer are projected once.  The hypotheses
+themselves are (token, parent) records per step; the n-best lists are rebuilt on the host by
+following the parents, in the order the reference's lists would have (steps ascending, beam order
+inside a step, stable sort by score).
+"""
+import torch
+
+from . import kernels as K
+
+SOS_ID, EOS_ID = 2, 3   # transformer_official.py:53-54
+
+
+def beam_search(model, input, beam_size=5, nbest=1, decode_max_len=0, check_every=8):
+    """input: the reference's batch Pack (wave, wave_len).  Returns, per utterance, a list of at most
+    `nbest` dicts {'yseq': [sos, ..., eos], 'score': float} - recognize_beam's result format."""
+    if beam_size < 1 or beam_size > 8:
+        raise ValueError("beam_size must be in 1..8 (asr_beam_step merges beam*beam <= 64 candidates per wave)")
+    eng = model._ensure_engine(input.wave.device)
+    if not eng.use_decoder:
+        raise RuntimeError("this model has no attention decoder; use ctc_greedy_search")
+    was_training, eng.training = eng.training, False
+    try:
+        with torch.no_grad():
+            return _search(model, eng, input, int(beam_size), int(nbest), int(decode_max_len), int(check_every))
+    finally:
+        eng.training = was_training
+
+
+def _search(model, eng, input, beam, nbest, decode_max_len, check_every):
+    x = input.wave.to(eng.dtype).contiguous()
+    wave_len = input.wave_len.to(torch.int32).contiguous()
+    B, T, _ = x.shape
+    dev = x.device
+    d, H, dk, L, V = eng.d, eng.H, eng.dk, eng.L, eng.V
+    hd = H * dk
+    enc, _ = eng.encoder_fwd(x, wave_len, model.attn_window)            # (B*T, d)
+    maxlen = wave_len.clone() if decode_max_len == 0 else torch.full_like(wave_len, decode_max_len)
+    Lcap = int(maxlen.max())
+    if Lcap > eng.pe.shape[0]:
+        raise ValueError(f"decode length {Lcap} exceeds the positional-encoding table ({eng.pe.shape[0]})")
+    R = B * beam
+    # encoder-side keys / values of every layer, once
+    cross_kv = [cross.kv.fwd(enc) for _, cross, _ in eng.dec]            # (B*T, 2hd)
+    caches = [torch.zeros(L, R, Lcap, 2 * hd, dtype=eng.dtype, device=dev) for _ in range(2)]
+    score = torch.zeros(B, beam, dtype=torch.float32, device=dev)
+    alive = torch.zeros(B, beam, dtype=torch.int32, device=dev)
+    alive[:, 0] = 1                                                       # one hypothesis [sos] per utterance
+    last_tok = torch.full((B, beam), SOS_ID, dtype=torch.int32, device=dev)
+    parent = torch.zeros(B, beam, dtype=torch.int32, device=dev)
+    rec_tok = torch.zeros(Lcap, B, beam, dtype=torch.int32, device=dev)
+    rec_par = torch.zeros_like(rec_tok)
+    rec_end = torch.zeros_like(rec_tok)
+    rec_score = torch.full((Lcap, B, beam), float("-inf"), dtype=torch.float32, device=dev)
+    alive_total = torch.zeros(Lcap, dtype=torch.int32, device=dev)
+    row_bytes = 2 * hd * caches[0].element_size()
+    cur = 0
+    steps_done = 0
+    for i in range(Lcap):
+        cache = caches[cur]
+        y = K.embed_pe_fwd(last_tok.reshape(-1), eng.emb32, eng.pe[i:i + 1], d ** -0.5, R, 1, eng.dtype)   # :369-371
+        for l, (slf, cross, ffn) in enumerate(eng.dec):
+            q = slf.q.fwd(y)
+            slf.kv.fwd(y, out=cache[l, :, i, :])                          # this step's key | value straight into the cache
+            kv = cache[l].view(R * Lcap, 2 * hd)
+            o = K.decode_attn(q, kv[:, :hd], kv[:, hd:], H, dk, Lcap, kv_div=1, k_len_uniform=i + 1)
+            y, _, _ = K.add_ln_fwd(slf.fc.fwd(o), y, slf.ln.g, slf.ln.b, None, None, R, 1)
+            q = cross.q.fwd(y)
+            ckv = cross_kv[l]
+            o = K.decode_attn(q, ckv[:, :hd], ckv[:, hd:], H, dk, T, kv_div=beam, k_len=wave_len, len_div=beam)
+            y, _, _ = K.add_ln_fwd(cross.fc.fwd(o), y, cross.ln.g, cross.ln.b, None, None, R, 1)
+            h = ffn.w1.fwd(y, act=1)
+            y, _, _ = K.add_ln_fwd(ffn.w2.fwd(h), y, ffn.ln.g, ffn.ln.b, None, None, R, 1)
+        logits = eng.prj.fwd(y)                                           # tied projection, no bias (:379)
+        vals, ids = K.logsoftmax_topk(logits, beam)
+        K.beam_step(vals, ids, score, alive, last_tok, parent, rec_tok, rec_par, rec_end, rec_score, maxlen, alive_total[i:i + 1],
+                    B, beam, i, EOS_ID)
+        steps_done = i + 1
+        if i + 1 < Lcap:
+            K.cache_gather(caches[cur], caches[cur ^ 1], parent.reshape(-1), L, R, beam, Lcap, i + 1, row_bytes)
+            cur ^= 1
+        if (i % check_every) == check_every - 1 and int(alive_total[i]) == 0:   # the only host sync of the loop
+            break
+    return _backtrace(rec_tok[:steps_done].cpu(), rec_par[:steps_done].cpu(), rec_end[:steps_done].cpu(), rec_score[:steps_done].cpu(), B, beam, nbest)
+
+
+def _backtrace(rec_tok, rec_par, rec_end, rec_score, B, beam, nbest):
+    steps = rec_tok.shape[0]
+    out = []
+    for b in range(B):
+        ended = []                                           # in the order the reference appends to ended_hyps
+        for i in range(steps):
+            for k in range(beam):
+                e = int(rec_end[i, b, k])
+                if not e:
+                    continue
+                seq, kk = [], k
+                for s in range(i, -1, -1):
+                    seq.append(int(rec_tok[s, b, kk]))
+                    kk = int(rec_par[s, b, kk])
+                seq = [SOS_ID] + seq[::-1] + ([EOS_ID] if e == 2 else [])
+                ended.append((float(rec_score[i, b, k]), seq))
+        ended = sorted(ended, key=lambda h: h[0], reverse=True)[: min(len(ended), nbest)]
+        out.append([{"yseq": seq, "score": sc} for sc, seq in ended])
+    return out

@@ -219,6 +219,40 @@ def ctc_greedy_decode(logits, in_len, blank=0):
     return ids, lens
 
 
+def decode_attn(q, k, v, H, dk, Tk_cap, kv_div=1, k_len=None, k_len_uniform=0, len_div=1, scale=None, o=None):
+    """Single-query attention of R = q.shape[0] rows over cached keys/values (see include/asr_hip.h)."""
+    R = q.shape[0]
+    ldq, ldk, ldv = _strided_rows(q, H, dk), _strided_rows(k, H, dk), _strided_rows(v, H, dk)
+    assert q.dtype == k.dtype == v.dtype
+    _chk_i32(k_len)
+    o = torch.empty(R, H * dk, dtype=q.dtype, device=q.device) if o is None else o
+    scale = float(dk) ** -0.5 if scale is None else float(scale)
+    check(lib.asr_decode_attn(_p(q), _p(k), _p(v), _p(o), _p(k_len), int(k_len_uniform), int(len_div), R, H, dk, int(Tk_cap), int(kv_div),
+                              ldq, ldk, ldv, _strided_rows(o, H, dk), scale, _dt(q), _stream()), "asr_decode_attn")
+    return o
+
+
+def logsoftmax_topk(logits, beam):
+    R, V = logits.shape
+    assert logits.stride(1) == 1
+    vals = torch.empty(R, beam, dtype=torch.float32, device=logits.device)
+    ids = torch.empty(R, beam, dtype=torch.int32, device=logits.device)
+    check(lib.asr_logsoftmax_topk(_p(logits), _p(vals), _p(ids), R, V, logits.stride(0), int(beam), _dt(logits), _stream()), "asr_logsoftmax_topk")
+    return vals, ids
+
+
+def beam_step(top_vals, top_ids, score, alive, last_tok, parent, rec_tok, rec_par, rec_end, rec_score, maxlen, alive_total, B, beam, step, eos):
+    _chk_f32(top_vals, score, rec_score)
+    _chk_i32(top_ids, alive, last_tok, parent, rec_tok, rec_par, rec_end, maxlen, alive_total)
+    check(lib.asr_beam_step(_p(top_vals), _p(top_ids), _p(score), _p(alive), _p(last_tok), _p(parent), _p(rec_tok), _p(rec_par), _p(rec_end),
+                            _p(rec_score), _p(maxlen), _p(alive_total), B, beam, int(step), int(eos), _stream()), "asr_beam_step")
+
+
+def cache_gather(src, dst, parent, L, R, beam, Lcap, n_pos, row_bytes):
+    _chk_i32(parent)
+    check(lib.asr_cache_gather(_p(src), _p(dst), _p(parent), L, R, beam, Lcap, int(n_pos), int(row_bytes), _stream()), "asr_cache_gather")
+
+
 def xent_fwd_bwd(logits, gold, n_valid, ignore_index=0, smoothing=0.0, grad_scale=1.0, dlogits=None, want_grad=True,
                  row_nll=None):
     M, V = logits.shape

@@ -152,6 +152,42 @@ int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* ou
                           int32_t* out_len, int B, int T, int V, int blank, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Beam search of the attention decoder, batched over utterances x beams
+ * with key/value caches.  Replaces Decoder.recognize_beam, transformer_official.py:331-434, which
+ * re-runs the whole decoder over the growing prefix for every hypothesis at every step in a
+ * Python loop, one utterance at a time.  Same search: every live hypothesis is extended by its
+ * `beam` best tokens (log_softmax scores, no length normalisation), the best `beam` extensions
+ * survive (stable order on ties), hypotheses that emit eos leave the beam, at step maxlen-1 eos is
+ * appended to every survivor.
+ *
+ * asr_decode_attn: single-query attention.  q: (R, H*dk) rows of stride ldq; keys/values of row r
+ *   are rows (r / kv_div) * Tk_cap + t, t < len, of k / v (strides ldk / ldv, head h at columns
+ *   [h*dk, (h+1)*dk)); len = k_len[r / len_div] if k_len else k_len_uniform.  No mask other than the
+ *   length (recognize_beam passes dec_enc_attn_mask=None and a causal mask that only hides the
+ *   future, which a cache never contains).  o: (R, H*dk), stride ldo.
+ * asr_logsoftmax_topk: vals/ids (R, beam) = the `beam` largest log_softmax(logits[r]) entries,
+ *   descending, ties by ascending index (transformer_official.py:381-384).
+ * asr_beam_step: one search step for B utterances (beam <= 8).  In/out state score, alive,
+ *   last_tok, parent: (B, beam).  Records of step `step` at [(step*B + b)*beam + slot]: rec_tok,
+ *   rec_par (slot of the parent at the previous step), rec_end (0 live, 1 ended by its own eos,
+ *   2 eos appended at the last step), rec_score.  maxlen: (B) int32 steps allowed per utterance.
+ *   *alive_total += number of hypotheses still live after the step.
+ * asr_cache_gather: dst[l][r][t] = src[l][(r / beam) * beam + parent[r]][t] for t < n_pos, with
+ *   L caches of R rows x Lcap positions x row_bytes bytes (multiple of 16).
+ */
+int asr_decode_attn(const void* q, const void* k, const void* v, void* o, const int32_t* k_len,
+                    int k_len_uniform, int len_div, int R, int H, int dk, int Tk_cap, int kv_div,
+                    int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+int asr_logsoftmax_topk(const void* logits, float* vals, int32_t* ids, int R, int V, int ld,
+                        int beam, int dtype, void* stream);
+int asr_beam_step(const float* top_vals, const int32_t* top_ids, float* score, int32_t* alive,
+                  int32_t* last_tok, int32_t* parent, int32_t* rec_tok, int32_t* rec_par,
+                  int32_t* rec_end, float* rec_score, const int32_t* maxlen, int32_t* alive_total,
+                  int B, int beam, int step, int eos, void* stream);
+int asr_cache_gather(const void* src, void* dst, const int32_t* parent, int L, int R, int beam,
+                     int Lcap, int n_pos, int row_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Softmax cross-entropy with ignore_index, forward + gradient in one pass over the logits.
  * Replaces:  F.cross_entropy(pred, gold, ignore_index=0, reduction='mean')  Utils/loss.py:47-49
  *            (+ label smoothing branch Utils/loss.py:30-45 when smoothing > 0)

@@ -205,6 +205,58 @@ def test_ctc_greedy_cer_matches_oracle(mode):
     assert np.isfinite(float(ev.loss))
 
 
+@pytest.mark.parametrize("case", ["beam_small.npz", "beam_small_maxlen.npz"])
+def test_beam_search_matches_reference_golden(case):
+    """GPU beam search (KV caches, batched beams) against the hypotheses the reference's own
+    Decoder.recognize_beam produced: n-best token sequences exactly, scores to 1e-4 (fp32 mode)."""
+    from tests.helpers import load_npz
+    from asr_chinese_e2e_amd.Utils import Pack
+    z = load_npz(case)
+    cfg = R.default_cfg(**{k: (int(v) if float(v).is_integer() else float(v)) for k, v in zip(z["cfg/keys"], z["cfg/vals"])})
+    V = int(z["cfg/V"])
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    model = build(cfg, V, dtype="fp32").cuda()
+    model.load_state_dict(sd, strict=False)
+    model.eval()
+    pack = Pack()
+    pack.add(wave=torch.from_numpy(z["in/wave"]).to(DEV), wave_len=torch.from_numpy(z["in/wave_len"]).to(DEV))
+    beam, nbest, dml = int(z["cfg/beam"]), int(z["cfg/nbest"]), int(z["cfg/decode_max_len"])
+    got = model.beam_search(pack, beam, nbest, dml)
+    for b, hyps in enumerate(got):
+        want_seq, want_len, want_score = z[f"beam/{b}/yseq"], z[f"beam/{b}/len"], z[f"beam/{b}/score"]
+        assert len(hyps) == len(want_len), (b, hyps)
+        for h, ws, wl, wsc in zip(hyps, want_seq, want_len, want_score):
+            assert h["yseq"] == [int(t) for t in ws[: int(wl)]], (b, h, ws)
+            assert abs(h["score"] - float(wsc)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,beam", [("fp32", 4), ("bf16", 3)])
+def test_beam_search_matches_oracle(dtype, beam):
+    """Random model at MFMA-capable geometry (d_model 64, heads of 64 in bf16): fp32 must give the
+    oracle's hypotheses; bf16 must give the same best hypothesis score within bf16 tolerance."""
+    over = dict(d_model=64, hidden_size=64 if dtype == "bf16" else 16, num_head=2 if dtype == "bf16" else 4, ff_size=128, layer_num=2)
+    cfg, sd, batch = oracle_case(3, 18, 16, 24, 5, over, seed=9)
+    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 3.0      # peaked outputs: hypotheses end before maxlen
+    if "decoder.tgt_word_prj.weight" in sd:                                             # tied: the state dict carries both names
+        sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    model = build(cfg, 24, dtype=dtype).cuda()
+    model.load_state_dict({k: v for k, v in sd.items()})
+    model.eval()
+    pack = to_pack(batch)
+    got = model.beam_search(pack, beam, 2, 10)
+    enc = R.encoder_forward(sd, cfg, batch["wave"], batch["wave_len"])
+    for b in range(3):
+        want = R.beam_search(sd, cfg, enc[b, : int(batch["wave_len"][b])], beam, 2, 10)
+        assert len(got[b]) == len(want)
+        if dtype == "fp32":
+            for h, (ids, score) in zip(got[b], want):
+                assert h["yseq"] == ids
+                assert abs(h["score"] - score) < 1e-4 * max(1.0, abs(score))
+        else:
+            # ~10 steps of bf16 logits through a sharpened softmax: the summed log-probability moves by ~0.1
+            assert abs(got[b][0]["score"] - want[0][1]) < 0.3 * max(1.0, abs(want[0][1]))
+
+
 def test_padded_rows_are_exact_zero_and_ignore_garbage():
     """Post-LN pad zeroing (transformer_official.py:208, 211): encoder output rows t >= wave_len are
     exactly 0 and garbage in the padded input frames cannot change any valid output."""
