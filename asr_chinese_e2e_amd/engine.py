@@ -392,7 +392,12 @@ class Engine:
         dl = dl.view(B * T, self.V)
         self._wgrad(self.ctc_lo, dl, enc, bias_from=dl)
         d_enc = self.ctc_lo.dgrad(dl)
-        self._ready("ctc_lo.weight")
+        # "ready(o)" means every gradient at flat offsets >= o is final.  ctc_lo sits BELOW the decoder
+        # block in the flat buffer and the joint model runs the CTC backward BEFORE the decoder
+        # backward, so with a decoder the mark is raised at the end of decoder_bwd instead (raising it
+        # here all-reduced the still-empty decoder gradients: wrong with two or more ranks)
+        if not self.use_decoder:
+            self._ready("ctc_lo.weight")
         return nll, d_enc
 
     # ------------------------------------------------------------------ decoder
@@ -427,3 +432,5 @@ class Engine:
         dx = dy + dy2  # gradient wrt the embedding output
         K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1])
         self._ready("decoder.tgt_word_emb.weight")
+        if self.use_ctc:
+            self._ready("ctc_lo.weight")      # final since ctc_fwd_bwd, which ran before this function

@@ -130,3 +130,70 @@ def test_data_parallel_wrapper_one_rank_rccl(tmp_path):
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "dp ok" in p.stdout
+
+
+DP2_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from asr_chinese_e2e_amd import Models, dist as D
+from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+from asr_chinese_e2e_amd.Utils import Pack
+rank, world = D.init("gloo")          # two ranks share the one GPU of the test box: gloo moves the CUDA buckets
+torch.cuda.set_device(0)
+mode = sys.argv[2]
+def build():
+    torch.manual_seed(0)
+    M = Models.TransformerOffical if mode == "joint" else Models.TransformerCTC
+    cfg = M.get_default_config()()
+    cfg.fn_build(dict(n_mels=16, lfr_m=1, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=2, dropout=0.0,
+                      ctc_weight=0.3 if mode == "joint" else 1.0, dtype="fp32"))
+    m = M(cfg, Vocab.synthetic(40)).cuda()
+    return m, NoamOpt(64, 1, 10, FusedAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+full = synthetic_pack(6, 24, 16, 40, seed=5, ragged=True, Lmin=2, Lmax=6, device="cuda")
+lo, hi = (0, 3) if rank == 0 else (3, 6)
+mine = Pack()
+mine.add(**{k: full[k][lo:hi].contiguous() for k in ("wave", "wave_len", "tgt_for_input", "tgt_for_metric", "tgt_len")})
+m1, o1 = build()                      # single process, whole batch
+m2, o2 = build()                      # data parallel, half a batch per rank
+dp = D.DataParallel(m2, "cuda", bucket_bytes=64 << 10, reduce_loss=True)
+assert len(dp.bucketer.buckets) > 3
+# (1) the reduced gradients of one backward equal the single-process gradients of the whole batch
+m1._ensure_engine("cuda"); m1.zero_flat_grads(); m1.train_step(full)
+m2.zero_flat_grads(); dp.bucketer.begin()
+m2.train_step(mine, n_valid_override=dp._global_count if mode == "joint" else None, ctc_batch=6); dp.bucketer.finish()
+torch.cuda.synchronize()
+for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+    if n.endswith("w_ks.bias"):       # analytically zero gradient (softmax is shift-invariant): pure round-off
+        continue
+    sc = float(p.grad.abs().max()) + 1e-30
+    assert float((p.grad - q.grad).abs().max()) <= 1e-4 * sc, (n, float((p.grad - q.grad).abs().max()), sc)
+# (2) same loss trajectory through clip + Noam/Adam; parameters stay within a few learning rates
+# (Adam, eps 1e-9, turns the round-off of near-zero gradient elements into +-lr)
+for _ in range(3):
+    a, _ = m1.iterate(full, optimizer=o1)
+    b, _ = dp.iterate(mine, optimizer=o2)
+    assert abs(float(a.loss) - float(b.loss)) < 2e-5 * abs(float(a.loss)), (float(a.loss), float(b.loss))
+for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+    assert float((p.detach() - q.detach()).abs().max()) <= 3 * o1._rate, n
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+print("rank", rank, "dp2 ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["ctc", "joint"])
+def test_data_parallel_two_ranks_equals_single_process(tmp_path, mode):
+    """two ranks with half the minibatch each (bucketed all-reduce overlapped with
+    backward, global token count / global CTC batch normalisers, clip on the reduced gradients) follow
+    the same trajectory as one process on the concatenated batch.  gloo carries the CUDA buckets here
+    because the test box has one GPU; the RCCL path is the 1-rank test above and the driver's scaling run."""
+    script = tmp_path / "dp2_worker.py"
+    script.write_text(DP2_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551" if mode == "ctc" else "29552", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} dp2 ok" in o
