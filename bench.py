@@ -131,7 +131,7 @@ def main():
     use_dp = world > 1 or os.environ.get("ASR_FORCE_DP") == "1"    # ASR_FORCE_DP: exercise the RCCL path with one rank
     if use_dp:
         from asr_chinese_e2e_amd import dist as D
-        D.init("nccl")
+        D.init(os.environ.get("ASR_DIST_BACKEND", "nccl"))   # "gloo": rehearse N ranks on a one-GPU box (LOCAL_RANK=0 for all)
 
     joint = args.config == "joint"
     Model = Models.TransformerOffical if joint else Models.TransformerCTC
