@@ -59,6 +59,7 @@ class _SpeechTransformer(BaseModel):
         self.cross_mask = getattr(c, "cross_mask", "ref_compat")
         self.lowp = str(getattr(c, "dtype", "bf16")).lower() in ("bf16", "bfloat16")
         self.attn_window = int(getattr(c, "attn_window", -1))
+        self.label_smoothing = float(getattr(c, "label_smoothing", 0.0))   # Utils/loss.py:30-45 (the reference never enables it)
         self.cer_in_iterate = bool(getattr(c, "cer_in_iterate", True))
         self._step_seed = int(getattr(c, "seed", 0))   # advanced once per training step (dropout masks)
         d, H, dk, ff = c.d_model, c.num_head, c.hidden_size, c.ff_size
@@ -262,7 +263,7 @@ class _SpeechTransformer(BaseModel):
             pred, gold = output.pred, output.gold
             B, To, V = pred.shape
             n_valid = (gold != PAD_ID).sum().float().reshape(1)
-            row_nll, _ = K.xent_fwd_bwd(pred.reshape(B * To, V).contiguous(), gold.reshape(-1).int(), n_valid, PAD_ID, want_grad=False)
+            row_nll, _ = K.xent_fwd_bwd(pred.reshape(B * To, V).contiguous(), gold.reshape(-1).int(), n_valid, PAD_ID, smoothing=self.label_smoothing, want_grad=False)
         if self.use_ctc:
             prep = K.dec_preprocess(input.tgt_for_input.contiguous(), SOS_ID, EOS_ID)
             nll, _ = K.ctc_fwd_bwd(output.ctc_logits.contiguous(), input.wave_len.to(torch.int32), prep[2], prep[4], self._engine.ws, want_grad=False)
@@ -322,7 +323,7 @@ class _SpeechTransformer(BaseModel):
             if self.cer_in_iterate:
                 pg = (pred.view(B, -1, self.V).argmax(-1), ys_out)
             w_ce = (1.0 - lam) if self.use_ctc else 1.0
-            row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, grad_scale=w_ce * loss_scale, dlogits=pred)
+            row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, smoothing=self.label_smoothing, grad_scale=w_ce * loss_scale, dlogits=pred)
         if self.use_ctc:
             nb = float(ctc_batch if ctc_batch is not None else B)
             nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale=lam * loss_scale / nb)
@@ -378,6 +379,7 @@ class _SpeechTransformer(BaseModel):
             layer_num = 6
             share_weight = False
             ctc_weight = 0.0
+            label_smoothing = 0.0
             cross_mask = "ref_compat"
             dtype = "bf16"
             attn_window = -1

@@ -257,6 +257,32 @@ def test_beam_search_matches_oracle(dtype, beam):
             assert abs(got[b][0]["score"] - want[0][1]) < 0.3 * max(1.0, abs(want[0][1]))
 
 
+def test_label_smoothing_matches_reference_formula():
+    """config.label_smoothing switches on the reference's smoothing branch (Utils/loss.py:30-45):
+    loss and gradients follow the oracle's restatement of it."""
+    over = dict(d_model=32, hidden_size=8, num_head=4, ff_size=64, layer_num=2)
+    cfg, sd, batch = oracle_case(4, 20, 16, 30, 5, over, seed=13)
+    model = build(cfg, 30, dtype="fp32", label_smoothing=0.1).cuda()
+    model.load_state_dict({k: v for k, v in sd.items()})
+    pack = to_pack(batch)
+    model._ensure_engine(DEV)
+    model.zero_flat_grads()
+    loss, _ = model.train_step(pack)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "positional" not in k}
+    full = dict(sd, **sdg)
+    if "decoder.tgt_word_prj.weight" in full:
+        full["decoder.tgt_word_prj.weight"] = full["decoder.tgt_word_emb.weight"]
+    enc = R.encoder_forward(full, cfg, batch["wave"], batch["wave_len"])
+    pred, gold = R.decoder_forward(full, cfg, batch["tgt_for_input"], enc, batch["tgt_len"])
+    ref = R.ce_loss(pred, gold, 0.1)
+    ref.backward()
+    assert abs(float(loss[0]) - float(ref)) < 1e-5 * abs(float(ref))
+    for n, p in model.named_parameters():
+        if n in sdg and sdg[n].grad is not None and not n.endswith("tgt_word_prj.weight"):
+            g = sdg[n].grad
+            assert np.allclose(p.grad.cpu().numpy(), g.numpy(), rtol=3e-4, atol=3e-6 * max(float(g.abs().max()), 1.0)), n
+
+
 def test_padded_rows_are_exact_zero_and_ignore_garbage():
     """Post-LN pad zeroing (transformer_official.py:208, 211): encoder output rows t >= wave_len are
     exactly 0 and garbage in the padded input frames cannot change any valid output."""
