@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void utt_norm_lfr_kernel(const float* __restrict__ feat, const int32_t* __restrict__ wav_len, T* __restrict__ out,
-                                                            int32_t* __restrict__ out_len, int Tmax, int n_mels, int m, int n, int Tlfr_max) {
+__global__ __launch_bounds__(1024) void utt_norm_lfr_kernel(const float* __restrict__ feat, const int32_t* __restrict__ wav_len, const int32_t* __restrict__ masks,
+                                                            T* __restrict__ out, int32_t* __restrict__ out_len, int Tmax, int n_mels, int m, int n, int Tlfr_max) {
     __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int len = wav_len[b];
@@ -72,6 +72,27 @@ __global__ __launch_bounds__(1024) void utt_norm_lfr_kernel(const float* __restr
     for (int i = tid; i < cnt; i += 1024) { const float d = f[i] - mean; q += d * d; }
     const float var = cnt > 1 ? block_sum(q, red) / (float)(cnt - 1) : 1.f;  // unbiased (torch .std())
     const float rstd = rsqrtf(var);
+    // SpecAugment of the reference (augments.py:4-42 via processor.py:52-58): a time mask [t0, t1)
+    // filled with the mean of the normalised feature, THEN a mel mask [f0, f1) filled with the mean of
+    // the time-masked feature (cloned.mean() at each call).  The ranges come from the host's RNG.
+    int t0 = 0, t1 = 0, f0 = 0, f1 = 0;
+    float fill_t = 0.f, fill_f = 0.f;
+    if (masks) {
+        t0 = min(max(masks[4 * b + 0], 0), Tb);
+        t1 = min(max(masks[4 * b + 1], t0), Tb);
+        f0 = min(max(masks[4 * b + 2], 0), n_mels);
+        f1 = min(max(masks[4 * b + 3], f0), n_mels);
+        float sa = 0.f, sm = 0.f;
+        for (int i = tid; i < cnt; i += 1024) {
+            const float v = (f[i] - mean) * rstd;
+            const int t = i / n_mels;
+            sa += v;
+            if (t >= t0 && t < t1) sm += v;
+        }
+        const float sum_all = block_sum(sa, red), sum_masked = block_sum(sm, red);
+        fill_t = cnt > 0 ? sum_all / (float)cnt : 0.f;
+        fill_f = cnt > 0 ? (sum_all - sum_masked + (float)((t1 - t0) * n_mels) * fill_t) / (float)cnt : 0.f;
+    }
     const int W = m * n_mels;
     T* o = out + (size_t)b * Tlfr_max * W;
     const int total = Tlfr_max * W;
@@ -82,6 +103,8 @@ __global__ __launch_bounds__(1024) void utt_norm_lfr_kernel(const float* __restr
             const int j = c / n_mels, mm = c - j * n_mels;
             const int src = min(r * n + j, Tb - 1);   // tail frames repeat the last input frame
             val = (f[(size_t)src * n_mels + mm] - mean) * rstd;
+            if (mm >= f0 && mm < f1) val = fill_f;
+            else if (src >= t0 && src < t1) val = fill_t;
         }
         o[i] = from_f32<T>(val);
     }
@@ -100,14 +123,19 @@ extern "C" int asr_logmel_fwd(const float* wav, const int32_t* wav_len, const fl
     return ASR_OK;
 }
 
+extern "C" int asr_utt_norm_augment_lfr_fwd(const float* feat, const int32_t* wav_len, const int32_t* masks, void* out, int32_t* out_len, int B, int Tmax,
+                                            int n_mels, int m, int n, int Tlfr_max, int dtype, void* stream) {
+    if (!feat || !wav_len || !out || !out_len) ASR_FAIL(ASR_EINVAL, "asr_utt_norm_augment_lfr_fwd: null pointer");
+    if (B <= 0 || Tmax <= 0 || n_mels <= 0 || m <= 0 || n <= 0 || Tlfr_max <= 0) ASR_FAIL(ASR_EINVAL, "asr_utt_norm_augment_lfr_fwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ASR_F32) utt_norm_lfr_kernel<float><<<B, 1024, 0, st>>>(feat, wav_len, masks, (float*)out, out_len, Tmax, n_mels, m, n, Tlfr_max);
+    else if (dtype == ASR_BF16) utt_norm_lfr_kernel<bf16_t><<<B, 1024, 0, st>>>(feat, wav_len, masks, (bf16_t*)out, out_len, Tmax, n_mels, m, n, Tlfr_max);
+    else ASR_FAIL(ASR_EDTYPE, "asr_utt_norm_augment_lfr_fwd: dtype %d", dtype);
+    ASR_CHECK_LAUNCH("asr_utt_norm_augment_lfr_fwd");
+    return ASR_OK;
+}
+
 extern "C" int asr_utt_norm_lfr_fwd(const float* feat, const int32_t* wav_len, void* out, int32_t* out_len, int B, int Tmax, int n_mels, int m, int n,
                                     int Tlfr_max, int dtype, void* stream) {
-    if (!feat || !wav_len || !out || !out_len) ASR_FAIL(ASR_EINVAL, "asr_utt_norm_lfr_fwd: null pointer");
-    if (B <= 0 || Tmax <= 0 || n_mels <= 0 || m <= 0 || n <= 0 || Tlfr_max <= 0) ASR_FAIL(ASR_EINVAL, "asr_utt_norm_lfr_fwd: bad shape");
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == ASR_F32) utt_norm_lfr_kernel<float><<<B, 1024, 0, st>>>(feat, wav_len, (float*)out, out_len, Tmax, n_mels, m, n, Tlfr_max);
-    else if (dtype == ASR_BF16) utt_norm_lfr_kernel<bf16_t><<<B, 1024, 0, st>>>(feat, wav_len, (bf16_t*)out, out_len, Tmax, n_mels, m, n, Tlfr_max);
-    else ASR_FAIL(ASR_EDTYPE, "asr_utt_norm_lfr_fwd: dtype %d", dtype);
-    ASR_CHECK_LAUNCH("asr_utt_norm_lfr_fwd");
-    return ASR_OK;
+    return asr_utt_norm_augment_lfr_fwd(feat, wav_len, nullptr, out, out_len, B, Tmax, n_mels, m, n, Tlfr_max, dtype, stream);
 }

@@ -432,12 +432,14 @@ def logmel(wav, wav_len, window, melfb, Tmax, feat=None):
     return feat
 
 
-def utt_norm_lfr(feat, wav_len, m, n, Tlfr_max, dtype=torch.float32):
+def utt_norm_lfr(feat, wav_len, m, n, Tlfr_max, dtype=torch.float32, masks=None):
+    """masks: optional (B, 4) int32 [t0, t1, f0, f1] SpecAugment ranges (see include/asr_hip.h)."""
     _chk_f32(feat)
-    _chk_i32(wav_len)
+    _chk_i32(wav_len, masks)
     B, Tmax, n_mels = feat.shape
+    assert masks is None or tuple(masks.shape) == (B, 4)
     out = torch.empty(B, Tlfr_max, m * n_mels, dtype=dtype, device=feat.device)
     out_len = torch.empty(B, dtype=torch.int32, device=feat.device)
-    check(lib.asr_utt_norm_lfr_fwd(_p(feat), _p(wav_len), _p(out), _p(out_len), B, Tmax, n_mels, m, n, Tlfr_max,
-                                   _dt(out), _stream()), "asr_utt_norm_lfr_fwd")
+    check(lib.asr_utt_norm_augment_lfr_fwd(_p(feat), _p(wav_len), _p(masks), _p(out), _p(out_len), B, Tmax, n_mels, m, n, Tlfr_max,
+                                           _dt(out), _stream()), "asr_utt_norm_augment_lfr_fwd")
     return out, out_len

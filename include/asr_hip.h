@@ -295,6 +295,14 @@ int asr_logmel_fwd(const float* wav, const int32_t* wav_len, const float* window
 int asr_utt_norm_lfr_fwd(const float* feat, const int32_t* wav_len, void* out, int32_t* out_len,
                          int B, int Tmax, int n_mels, int m, int n, int Tlfr_max, int dtype,
                          void* stream);
+/* The same with SpecAugment between normalisation and frame stacking, as AudioParser.parse(augment=
+ * True) does (processor.py:52-58, 67-69; augments.py:4-42): masks (B, 4) int32 = [t0, t1, f0, f1]
+ * per utterance (frames / mel channels of the un-stacked feature, host RNG); frames [t0, t1) are
+ * filled with the mean of the normalised feature, then channels [f0, f1) with the mean of the
+ * time-masked feature.  masks == NULL: no augmentation. */
+int asr_utt_norm_augment_lfr_fwd(const float* feat, const int32_t* wav_len, const int32_t* masks,
+                                 void* out, int32_t* out_len, int B, int Tmax, int n_mels, int m,
+                                 int n, int Tlfr_max, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -376,6 +376,26 @@ def beam_case(name, cfg, B, T, V, wave_len, seed, beam, nbest, decode_max_len):
     print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB")
 
 
+def augment_cases():
+    """Golden SpecAugment outputs from the reference's own AudioParser.augment (processor.py:52-58:
+    augments.time_mask then augments.freq_mask) on normalised random features, seeded `random`."""
+    import random
+    from Predictor.data_handler.augments import freq_mask, time_mask
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    cases = [(80, 300, 1), (80, 57, 2), (40, 120, 3), (80, 41, 4), (80, 500, 5), (32, 200, 6)]   # fewer than 30 channels / 40 frames: the reference's randrange can raise
+    for n_mels, T, seed in cases:
+        f = torch.randn(n_mels, T, generator=g)
+        f = (f - f.mean()) / f.std()                    # what normalize() hands to augment()
+        random.seed(seed)
+        y = freq_mask(time_mask(f.unsqueeze(0))).squeeze(0)
+        out[f"aug/{n_mels}_{T}_{seed}/in"] = _np(f)
+        out[f"aug/{n_mels}_{T}_{seed}/out"] = _np(y)
+    path = os.path.join(OUT, "augment.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -383,6 +403,9 @@ def main():
     torch.set_num_threads(4)
     base = dict(n_mels=20, lfr_m=1, d_model=32, hidden_size=8, ff_size=64, num_head=4,
                 dropout=0.0, layer_num=2)
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":   # only the SpecAugment fixtures
+        augment_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "beam":     # only the beam-search fixtures (the others stay byte-identical)
         beam_case("beam_small", base, B=3, T=20, V=12, wave_len=[20, 13, 7], seed=31, beam=3, nbest=3, decode_max_len=0)
         beam_case("beam_small_maxlen", dict(base, layer_num=1), B=2, T=16, V=9, wave_len=[16, 10], seed=37, beam=4, nbest=2, decode_max_len=6)

@@ -85,3 +85,35 @@ def build_lfr(x, m, n):
 def front_end(wav, n_mels=80, lfr_m=4, lfr_n=3):
     """parse() without augmentation: log-mel -> normalise -> LFR (processor.py:61-71)."""
     return build_lfr(utt_normalize(log_mel(wav, n_mels)), lfr_m, lfr_n)
+
+
+def sample_spec_augment(n_mels, n_frames, rng, F=30, T=40):
+    """The randrange calls of augments.time_mask (augments.py:24-42) then augments.freq_mask (:4-21),
+    one mask each as AudioParser.augment uses them (processor.py:52-58).  Returns [t0, t1, f0, f1];
+    empty ranges where the reference returns early (width 0).  A range the reference cannot draw
+    (fewer frames / channels than the width: its randrange raises) gives no mask."""
+    t0 = t1 = f0 = f1 = 0
+    t = rng.randrange(0, T)
+    if n_frames - t > 0:
+        tz = rng.randrange(0, n_frames - t)
+        if t > 0:
+            t0, t1 = tz, rng.randrange(tz, tz + t)
+    f = rng.randrange(0, F)
+    if n_mels - f > 0:
+        fz = rng.randrange(0, n_mels - f)
+        if f > 0:
+            f0, f1 = fz, rng.randrange(fz, fz + f)
+    return [t0, t1, f0, f1]
+
+
+def spec_augment(feature, masks):
+    """feature (n_mels, T) normalised; time mask filled with the mean, then mel mask filled with the
+    mean of the time-masked feature (cloned.mean() at each call, replace_with_zero=False).
+    Pinned by tests/golden/augment.npz (the reference's own functions)."""
+    t0, t1, f0, f1 = masks
+    y = np.array(feature, dtype=np.float64, copy=True)
+    if t1 > t0:
+        y[:, t0:t1] = y.mean()
+    if f1 > f0:
+        y[f0:f1, :] = y.mean()
+    return y

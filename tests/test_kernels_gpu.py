@@ -497,6 +497,33 @@ def test_gemm_tn(K, M, N, K_):
 
 
 # ------------------------------------------------------------------------------------ front end
+@pytest.mark.parametrize("m,n", [(1, 1), (4, 3)])
+def test_spec_augment_in_front_end(K, m, n):
+    """Normalise -> SpecAugment -> frame stacking on the device == oracle (whose augment step is pinned
+    by the reference's own time_mask / freq_mask outputs), masks drawn with the reference's RNG calls."""
+    import random
+    from asr_chinese_e2e_amd.data_handler.processor import sample_spec_augment
+    rng = np.random.RandomState(3)
+    B, Tmax, n_mels = 5, 260, 80
+    lens = [160 * (Tmax - 1), 160 * 199 + 11, 160 * 64, 160 * 45, 160 * 120 + 159]
+    feat = torch.from_numpy(rng.randn(B, Tmax, n_mels).astype(np.float32) * 3 - 5).to(DEV)
+    pyrng = random.Random(11)
+    frames = [1 + l // 160 for l in lens]
+    masks = [sample_spec_augment(n_mels, fr, pyrng) for fr in frames]
+    assert any(mk[1] > mk[0] for mk in masks) and any(mk[3] > mk[2] for mk in masks)
+    wl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    Tl = (Tmax + n - 1) // n
+    out, out_len = K.utt_norm_lfr(feat, wl, m, n, Tl, torch.float32, masks=torch.tensor(masks, dtype=torch.int32, device=DEV))
+    for i, fr in enumerate(frames):
+        x = logmel_ref.utt_normalize(feat[i, :fr].cpu().double().numpy())          # (T, n_mels)
+        y = logmel_ref.spec_augment(x.T, masks[i]).T                                 # augment works on (n_mels, T)
+        ref = logmel_ref.build_lfr(y, m, n)
+        got = out[i, : ref.shape[0]].cpu().numpy()
+        assert int(out_len[i]) == ref.shape[0]
+        assert np.allclose(got, ref, rtol=1e-4, atol=2e-5), i
+        assert float(out[i, ref.shape[0]:].abs().max() if ref.shape[0] < Tl else 0.0) == 0.0
+
+
 def test_logmel_lfr(K):
     rng = np.random.RandomState(0)
     lens = [16000 * 2 + 37, 16000, 4001]

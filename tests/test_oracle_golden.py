@@ -191,3 +191,24 @@ def test_beam_search_oracle_matches_reference_golden(case):
         for (ids, score), ws, wl, wsc in zip(got, want_seq, want_len, want_score):
             assert ids == [int(t) for t in ws[: int(wl)]]
             assert abs(score - float(wsc)) < 1e-4
+
+
+def test_spec_augment_oracle_matches_reference_golden():
+    """Mask ranges drawn with the reference's randrange sequence + mean fills == the reference's own
+    time_mask / freq_mask outputs (tests/golden/augment.npz, oracle/gen_golden.py augment); the product's
+    sampler draws the same ranges."""
+    import random
+    from asr_chinese_e2e_amd.data_handler.processor import sample_spec_augment
+    z = load_npz("augment.npz")
+    keys = sorted({k.rsplit("/", 1)[0] for k in z.files})
+    assert len(keys) >= 6
+    masked_any = False
+    for k in keys:
+        n_mels, T, seed = (int(v) for v in k.split("/")[1].split("_"))
+        x, want = z[k + "/in"], z[k + "/out"]
+        m = LM.sample_spec_augment(n_mels, T, random.Random(seed))
+        assert m == sample_spec_augment(n_mels, T, random.Random(seed))
+        got = LM.spec_augment(x, m)
+        assert np.allclose(got, want, rtol=0, atol=2e-6), k
+        masked_any |= (m[1] > m[0]) or (m[3] > m[2])
+    assert masked_any
