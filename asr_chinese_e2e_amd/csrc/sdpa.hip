@@ -118,7 +118,7 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&acc)[2], float mul, 
 
 // ---------------------------------------------------------------- forward
 template <bool DROP>
-__global__ __launch_bounds__(256) void sdpa_fwd_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+__global__ __launch_bounds__(256, 2) void sdpa_fwd_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                             bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
                                                             int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
                                                             uint32_t dseed, uint32_t dthr, float dscale) {
@@ -168,13 +168,22 @@ __global__ __launch_bounds__(256) void sdpa_fwd_bf16_kernel(const bf16_t* __rest
         const bool need_mask = (k0 + TILE > klen) || (causal && k0 + TILE - 1 > q0) ||
                                (window >= 0 && (k0 + TILE - 1 - q0 > window || q0 + 31 - k0 > window));
         if (need_mask) {
+            if (!causal && window < 0) {   // key-length mask only (encoder self-attention): one compare per element
+                const int lim = klen - k0 - 4 * (lane >> 5);      // key (32*sub + (i&3) + 8*(i>>2)) + 4*hh + k0 < klen
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int kj = k0 + 32 * sub + acc_row(i, lane);
-                    if (!visible(qi, kj, klen, causal, window)) st[sub][i] = -INFINITY;
-                }
+                    for (int i = 0; i < 16; ++i)
+                        if (32 * sub + (i & 3) + 8 * (i >> 2) >= lim) st[sub][i] = -INFINITY;
+            } else {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int kj = k0 + 32 * sub + acc_row(i, lane);
+                        if (!visible(qi, kj, klen, causal, window)) st[sub][i] = -INFINITY;
+                    }
+            }
         }
         float tmax = M_INIT;
 #pragma unroll
@@ -313,9 +322,16 @@ __global__ __launch_bounds__(256, 3) void sdpa_bwd_dq_bf16_kernel(const bf16_t* 
             const int ks0 = k0 + 32 * sub;
             const bool need_mask = (ks0 + 32 > klen) || (causal && ks0 + 31 > q0) || (window >= 0 && (ks0 + 31 - q0 > window || q0 + 31 - ks0 > window));
             if (need_mask) {
+                if (!causal && window < 0) {   // key-length mask only
+                    const int lim = klen - ks0 - 4 * (lane >> 5);
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (!visible(qi, ks0 + acc_row(i, lane), klen, causal, window)) st[i] = -INFINITY;
+                    for (int i = 0; i < 16; ++i)
+                        if ((i & 3) + 8 * (i >> 2) >= lim) st[i] = -INFINITY;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (!visible(qi, ks0 + acc_row(i, lane), klen, causal, window)) st[i] = -INFINITY;
+                }
             }
             if constexpr (DROP) {   // dP = (dO V^T) o keep / (1-p)
                 const uint32_t rowbase = (((uint32_t)(b * H + h)) * Tq + min(qi, Tq - 1)) * ((Tk + 1) & ~1);
@@ -411,6 +427,18 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t*
             f32x16 ds;
             const int qs0 = q0 + 32 * sub;   // wave-uniform: does this 32x32 sub-tile touch any mask edge?
             const bool need_mask = (kk0 + 32 > klen) || (causal && kk0 + 31 > qs0) || (window >= 0 && (kk0 + 31 - qs0 > window || qs0 + 31 - kk0 > window));
+            if (need_mask) {
+                if (!causal && window < 0) {   // key-length mask only: the key is this lane's, one test per tile
+                    if (kj >= klen) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) st[i] = -INFINITY;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (!visible(q0 + 32 * sub + acc_row(i, lane), kj, klen, causal, window)) st[i] = -INFINITY;
+                }
+            }
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int r0 = 32 * sub + 8 * g4 + 4 * (lane >> 5);
@@ -419,8 +447,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t*
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g4 + e;
-                    float sv = st[i];
-                    if (need_mask && !visible(q0 + r0 + e, kj, klen, causal, window)) sv = -INFINITY;
+                    const float sv = st[i];
                     const float p = __builtin_amdgcn_exp2f(fmaf(sv, sc2, -l4[e]));
                     float keepf = 1.f;
                     if constexpr (DROP) {
