@@ -662,7 +662,7 @@ __device__ __forceinline__ bf16x8 tn_frag_swz(unsigned addr) {
 template <int TRING>   // 4: one workgroup per CU (128 KiB ring); 2: two per CU (64 KiB each)
 __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
                                                              int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
-                                                             int use_atomic, const void* __restrict__ zero_page) {
+                                                             int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = tiles_k * tiles_n;
@@ -719,6 +719,15 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_t;
     const unsigned y_off[2] = {tn_frag_off(wn * 64, lane), tn_frag_off(wn * 64 + 32, lane)};
     const unsigned x_off[2] = {TM * 256 + tn_frag_off(wk * 64, lane), TM * 256 + tn_frag_off(wk * 64 + 32, lane)};
+    // Bias gradient (column sums of dY) from the dY stages already in LDS, by the workgroups of the
+    // first k-tile: thread (chunk = tid & 15, phase = tid >> 4) adds rows phase, phase+16, +32, +48 of
+    // its 8 columns; rows with equal (r & 3) keep a chunk in the same swizzled slot.  Replaces a
+    // separate pass over dY (colsum + finalize launches) per projection.
+    const bool do_bias = dbias != nullptr && tk == 0;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    const unsigned b_off = (unsigned)((tid >> 4) * 256 + (((tid & 15) ^ (4 * ((tid >> 4) & 3))) << 4));
 
     for (int p = 0; p < TRING - 1 && p < nsteps; ++p) {
 #pragma unroll
@@ -756,6 +765,17 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
             }                                                                                                                 \
         }                                                                                                                     \
     } while (0)
+        if (do_bias) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const u32x4 c8 = *(const u32x4*)(smem_t + (sbase - lds_base) + b_off + qq * 16 * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(c8[e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(c8[e] & 0xffff0000u);
+                }
+            }
+        }
         // 8 reads per k-sub-step; LDS reads retire in order, so lgkmcnt(8) = "all but the 8 just issued"
         TN_LOAD(0, 0);
         TN_LOAD(1, 1);
@@ -793,6 +813,19 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
                 else *dst = acc[ni][ki][e];
             }
         }
+    if (do_bias) {   // 16 row phases -> one sum per column, through the (now idle) ring memory
+        __syncthreads();
+        float* red = (float*)smem_t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < 16; ++ph) t += red[ph * 128 + tid];
+            atomicAdd(dbias + n0 + tid, t);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int rows, int cols, int ld) {
@@ -872,8 +905,16 @@ extern "C" size_t asr_gemm_tn_workspace_bytes(int M, int N, int K) {
     return 0;  // partial tiles are combined with fp32 atomics; no scratch needed
 }
 
+extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy, int ldx, int ldw,
+                                     int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* ws,
                                 size_t ws_bytes, void* stream) {
+    return asr_gemm_tn_bias_bf16(dY, X, dW, nullptr, M, N, K, ldy, ldx, ldw, accumulate, ws, ws_bytes, stream);
+}
+
+extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy, int ldx, int ldw,
+                                     int accumulate, void* ws, size_t ws_bytes, void* stream) {
     (void)ws; (void)ws_bytes;
     if (!dY || !X || !dW) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: null pointer");
     if (M <= 0 || N <= 0 || K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: bad shape M=%d N=%d K=%d", M, N, K);
@@ -906,6 +947,7 @@ extern "C" int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M,
     }
     const int grid = tiles * nsplit;
     if (tn_cfg == 1) {
+        if (dbias) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bias_bf16: the register-staged kernel (ASR_GEMM_TN_CFG=1) has no bias path");
         gemm_tn_kernel<<<grid, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic);
     } else {
         static void* zero_page = nullptr;
@@ -914,8 +956,8 @@ extern "C" int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M,
             (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);
             if (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: zero page symbol not found");
         }
-        if (ring == 4) gemm_tn_dma_kernel<4><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page);
-        else gemm_tn_dma_kernel<2><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page);
+        if (ring == 4) gemm_tn_dma_kernel<4><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        else gemm_tn_dma_kernel<2><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
     }
     ASR_CHECK_LAUNCH("asr_gemm_tn_bf16");
     return ASR_OK;

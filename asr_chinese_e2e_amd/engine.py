@@ -144,11 +144,17 @@ class Linear:
             return K.timed("lib_gemm_dgrad", flops, lambda: torch.mm(dy, w))
         return K.timed("lib_gemm_dgrad", flops, lambda: torch.mm(dy, w, out=out))
 
-    def wgrad(self, dy, x):
-        """gw += dy^T x  (fp32 accumulation into the flat gradient buffer)."""
+    def fused_bias_wgrad(self, dy, x):
+        """True when wgrad can also produce the bias gradient (MFMA weight-gradient kernel path)."""
+        return (self.gb is not None and dy.dtype == torch.bfloat16 and self.N % 8 == 0 and self.K % 8 == 0 and
+                dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0)
+
+    def wgrad(self, dy, x, with_bias=False):
+        """gw += dy^T x  (fp32 accumulation into the flat gradient buffer); with_bias (only when
+        fused_bias_wgrad): also gb += column sums of dy, inside the same kernel."""
         M = x.shape[0]
         if dy.dtype == torch.bfloat16 and self.N % 8 == 0 and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
-            K.gemm_tn(dy, x, self.gw, accumulate=True)
+            K.gemm_tn(dy, x, self.gw, accumulate=True, dbias=self.gb if with_bias else None)
         elif dy.dtype == torch.bfloat16:
             self.gw.add_(torch.mm(dy.t(), x).float())
         else:
@@ -262,18 +268,19 @@ class Engine:
 
     def _wgrad(self, lin, dy, x, bias_from=None):
         """lin.gw += dy^T x (and lin.gb += colsum(bias_from)) on the side stream."""
+        fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
         if not self.overlap_wgrad:
-            if bias_from is not None:
+            if bias_from is not None and not fused:
                 lin.bgrad(bias_from, self.ws_side)
-            lin.wgrad(dy, x)
+            lin.wgrad(dy, x, with_bias=fused)
             return
         ev = torch.cuda.Event()
         ev.record()
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
-            if bias_from is not None:
+            if bias_from is not None and not fused:
                 lin.bgrad(bias_from, self.ws_side)
-            lin.wgrad(dy, x)
+            lin.wgrad(dy, x, with_bias=fused)
         if not torch.cuda.is_current_stream_capturing():   # graph pools never recycle during capture
             for t in (dy, x):
                 t.record_stream(self.side)
@@ -344,8 +351,9 @@ class Engine:
                                drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(f.w2, dxg, c["h"])
         dh = f.w2.dgrad(dxg)
-        K.relu_bwd_(dh, c["h"], f.w1.gb, self.ws)
-        self._wgrad(f.w1, dh, c["x"])
+        fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
+        K.relu_bwd_(dh, c["h"], None if fused else f.w1.gb, self.ws)
+        self._wgrad(f.w1, dh, c["x"], bias_from=dh if fused else None)
         dx = f.w1.dgrad(dh)
         return dx, dz
 

@@ -337,7 +337,7 @@ def relu_(x):
 def relu_bwd_(da, a, dbias, ws):
     """da *= (a > 0) in place; dbias (f32) += column sums."""
     assert da.is_contiguous() and a.is_contiguous() and da.shape == a.shape and da.dtype == a.dtype and da.dim() == 2
-    _chk_f32(dbias)
+    _chk_f32(dbias)      # None: mask only (the bias gradient then comes from the weight-gradient GEMM)
     rows, cols = da.shape
     w = ws.get(lib.asr_colsum_workspace_bytes(rows, cols))
     check(lib.asr_relu_bwd(_p(da), _p(a), _p(dbias), _p(w), w.numel(), rows, cols, _dt(da), _stream()), "asr_relu_bwd")
@@ -407,15 +407,17 @@ def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None):
     return out
 
 
-def gemm_tn(dy, x, dw, accumulate=True):
-    """dw (N,K) f32 (+)= dy (M,N)^T @ x (M,K); bf16 operands, MFMA kernel."""
+def gemm_tn(dy, x, dw, accumulate=True, dbias=None):
+    """dw (N,K) f32 (+)= dy (M,N)^T @ x (M,K); bf16 operands, MFMA kernel.  dbias (N) f32 += column sums of dy."""
     assert dy.dtype == x.dtype == torch.bfloat16 and dw.dtype == torch.float32
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dw.shape == (N, K) and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
+    _chk_f32(dbias)
+    assert dbias is None or dbias.numel() == N
     timed("gemm_tn", 2.0 * M * N * K, lambda: check(
-        lib.asr_gemm_tn_bf16(_p(dy), _p(x), _p(dw), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), None, 0,
-                             _stream()), "asr_gemm_tn_bf16"))
+        lib.asr_gemm_tn_bias_bf16(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), None, 0,
+                                  _stream()), "asr_gemm_tn_bias_bf16"))
     return dw
 
 

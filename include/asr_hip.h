@@ -278,6 +278,11 @@ int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void
 size_t asr_gemm_tn_workspace_bytes(int M, int N, int K);
 int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy,
                      int ldx, int ldw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The same, and dbias (N) f32 += column sums of dY (the bias gradient of the projection), taken
+ * from the dY tiles the kernel stages anyway - no separate pass over dY.  dbias == NULL: as above. */
+int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K,
+                          int ldy, int ldx, int ldw, int accumulate, void* ws, size_t ws_bytes,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Log-mel front end on device.

@@ -475,11 +475,13 @@ def test_gemm_full_size_persistent_paths(K, N, K_):
         K.gemm_nt(a, w, b, out, 1)
         ref = torch.relu(a.float() @ w.float().t() + b)
         close(out, ref, rtol=1e-2, atol=1e-2, what="persistent gemm_nt")
-    dy = (torch.randn(M, N, device=DEV) * 0.5).bfloat16()
+    dy = (torch.randn(M, N, device=DEV) * 0.5 + 0.1).bfloat16()
     dw = torch.zeros(N, K_, device=DEV)
-    K.gemm_tn(dy, a, dw, accumulate=True)
+    db = torch.ones(N, device=DEV)
+    K.gemm_tn(dy, a, dw, accumulate=True, dbias=db)
     ref = dy.float().t() @ a.float()
     close(dw, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="dma gemm_tn")
+    close(db - 1, dy.float().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="fused bias gradient")
 
 
 @pytest.mark.parametrize("M,N,K_", [(256, 128, 128), (1000, 512, 80), (4000, 1536, 512), (513, 4232, 64), (70, 40, 24), (8197, 512, 512)])
@@ -494,6 +496,9 @@ def test_gemm_tn(K, M, N, K_):
     dw2 = torch.full((N, K_), float("nan"), device=DEV)
     K.gemm_tn(dy.to(DEV), x.to(DEV), dw2, accumulate=False)
     close(dw2, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="gemm_tn overwrite")
+    db = torch.full((N,), 2.0, device=DEV)        # bias gradient from the same kernel (ragged M, clamped edge columns)
+    K.gemm_tn(dy.to(DEV), x.to(DEV), dw2, accumulate=True, dbias=db)
+    close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn bias gradient")
 
 
 # ------------------------------------------------------------------------------------ front end
