@@ -659,8 +659,13 @@ __device__ __forceinline__ bf16x8 tn_frag_swz(unsigned addr) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int TRING>   // 4: one workgroup per CU (128 KiB ring); 2: two per CU (64 KiB each)
-__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
+// TRING ring slots; G wave groups of four waves.  G = 2 is an intra-workgroup split of the reduction:
+// a ring slot then holds 128 rows, group 0 multiplies rows 0..63 and group 1 rows 64..127 into its
+// own accumulators, which are added through LDS at the end - two waves per SIMD hide each other's
+// barrier, LDS and DMA-issue latencies like two co-resident workgroups would, but the tile is
+// added to memory once.  Forms used: <2, 2> (one 8-wave workgroup per CU), <2, 1> (two per CU).
+template <int TRING, int G>
+__global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
                                                              int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
                                                              int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias) {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
@@ -671,36 +676,39 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
     const int tk = tile % tiles_k, tn = tile / tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
     const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
-    const int nsteps = (mend - mbeg + TM - 1) / TM;
+    constexpr int SR = TM * G;                 // rows per ring slot
+    constexpr int SBYTES = TSTAGE * G;         // bytes per ring slot: [dY SR x 256 B | X SR x 256 B]
+    const int nsteps = (mend - mbeg + SR - 1) / SR;
     if (nsteps <= 0) return;
-    const int wn = w >> 1, wk = w & 1;
+    const int grp = w >> 2, wl = w & 3;
+    const int wn = wl >> 1, wk = wl & 1;
 
-    // this lane's part of each of the wave's 8 one-KiB pieces: waves 0,1 stage dY (rows 4g.. of piece
-    // g = 0..15), waves 2,3 stage X.  Running pointers, advanced by one uniform add per stage: the
+    // this lane's part of each of the wave's 8 one-KiB pieces: the first half of the waves stages dY
+    // (rows 4g.. of piece g), the second half X.  Running pointers, advanced by one uniform add per stage: the
     // address work per DMA must stay within a few instructions, or it - not the MFMAs - paces the
     // loop (an MFMA hides about five other instructions of its wave).
     // Columns past N / K are CLAMPED to the last valid 16-byte chunk: they only feed accumulator
     // columns that are never stored.  Rows past the end of the range must read zeros: only the last
     // stage of a range can be partial, and only there the per-lane select runs.
     const int lrow = lane >> 4, slot = lane & 15;
-    const bool is_y = w < 2;
+    const bool is_y = w < 2 * G;
     const bf16_t* cur[8];
     int prow[8];   // row inside the stage
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int gg = (w & 1) * 8 + j;
+        const int gg = (w % (2 * G)) * 8 + j;
         const int row = 4 * gg + lrow;
         const int col = (slot ^ (4 * (row & 3))) * 8;
         prow[j] = row;
         cur[j] = is_y ? dY + (size_t)(mbeg + row) * ldy + min(n0 + col, N - 8) : X + (size_t)(mbeg + row) * ldx + min(k0 + col, K - 8);
     }
-    const size_t stage_step = (size_t)TM * (is_y ? ldy : ldx);   // elements per stage (wave-uniform)
-    const bool ragged = ((mend - mbeg) % TM) != 0;
+    const size_t stage_step = (size_t)SR * (is_y ? ldy : ldx);   // elements per stage (wave-uniform)
+    const bool ragged = ((mend - mbeg) % SR) != 0;
     int it = 0, it_slot = 0;   // next stage to issue
     auto dma = [&](int j) {
         const void* q = cur[j];
-        if (ragged && it == nsteps - 1) q = (mbeg + it * TM + prow[j] < mend) ? q : zero_page;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)q, (lds_void_t*)(smem_t + it_slot * TSTAGE + (w * 8 + j) * 1024), 16, 0, 0);
+        if (ragged && it == nsteps - 1) q = (mbeg + it * SR + prow[j] < mend) ? q : zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)q, (lds_void_t*)(smem_t + it_slot * SBYTES + (w * 8 + j) * 1024), 16, 0, 0);
     };
     auto advance = [&]() {
         ++it;
@@ -717,10 +725,10 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_t;
-    const unsigned y_off[2] = {tn_frag_off(wn * 64, lane), tn_frag_off(wn * 64 + 32, lane)};
-    const unsigned x_off[2] = {TM * 256 + tn_frag_off(wk * 64, lane), TM * 256 + tn_frag_off(wk * 64 + 32, lane)};
+    const unsigned y_off[2] = {grp * TM * 256 + tn_frag_off(wn * 64, lane), grp * TM * 256 + tn_frag_off(wn * 64 + 32, lane)};
+    const unsigned x_off[2] = {(SR + grp * TM) * 256 + tn_frag_off(wk * 64, lane), (SR + grp * TM) * 256 + tn_frag_off(wk * 64 + 32, lane)};
     // Bias gradient (column sums of dY) from the dY stages already in LDS, by the workgroups of the
-    // first k-tile: thread (chunk = tid & 15, phase = tid >> 4) adds rows phase, phase+16, +32, +48 of
+    // first k-tile: thread (chunk = tid & 15, phase = tid >> 4) adds rows phase, phase + 16 G, ... of
     // its 8 columns; rows with equal (r & 3) keep a chunk in the same swizzled slot.  Replaces a
     // separate pass over dY (colsum + finalize launches) per projection.
     const bool do_bias = dbias != nullptr && tk == 0;
@@ -743,7 +751,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave's part of stage i landed; nobody still reads the slot refilled during this step
         const bool more = it < nsteps;
-        const unsigned sbase = lds_base + c_slot * TSTAGE;
+        const unsigned sbase = lds_base + c_slot * SBYTES;
         c_slot = c_slot == TRING - 1 ? 0 : c_slot + 1;
         bf16x8 yf[2][2], xf[2][2];
 #define TN_LOAD(BUF, S)                                              \
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
         if (do_bias) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const u32x4 c8 = *(const u32x4*)(smem_t + (sbase - lds_base) + b_off + qq * 16 * 256);
+                const u32x4 c8 = *(const u32x4*)(smem_t + (sbase - lds_base) + b_off + qq * 16 * G * 256);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bsum[2 * e] += __uint_as_float(c8[e] << 16);
@@ -797,7 +805,29 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
 #undef TN_MMA
         if (more) advance();
     }
+    if (G > 1) {   // group 1 hands its accumulators to group 0 through the (now idle) ring memory
+        __syncthreads();
+        float* xch = (float*)smem_t + (size_t)wl * 64 * 64;
+        if (grp == 1) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xch[((ni * 2 + ki) * 16 + e) * 64 + lane] = acc[ni][ki][e];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[ni][ki][e] += xch[((ni * 2 + ki) * 16 + e) * 64 + lane];
+        }
+    }
     // accumulator: row = n (registers), col = k (lane): 32 consecutive k per register -> 128-B segments
+    if (grp == 0) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -813,7 +843,8 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
                 else *dst = acc[ni][ki][e];
             }
         }
-    if (do_bias) {   // 16 row phases -> one sum per column, through the (now idle) ring memory
+    }
+    if (do_bias) {   // 16 G row phases -> one sum per column, through the (now idle) ring memory
         __syncthreads();
         float* red = (float*)smem_t;
 #pragma unroll
@@ -822,7 +853,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
         if (tid < 128 && n0 + tid < N) {
             float t = 0.f;
 #pragma unroll
-            for (int ph = 0; ph < 16; ++ph) t += red[ph * 128 + tid];
+            for (int ph = 0; ph < 16 * G; ++ph) t += red[ph * 128 + tid];
             atomicAdd(dbias + n0 + tid, t);
         }
     }
@@ -925,19 +956,28 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
     static const int tn_cfg = getenv("ASR_GEMM_TN_CFG") ? atoi(getenv("ASR_GEMM_TN_CFG")) : 0;   // 1 = register-staged kernel (A/B runs)
     static const int tn_noatomic = getenv("ASR_GEMM_TN_NOATOMIC") ? atoi(getenv("ASR_GEMM_TN_NOATOMIC")) : 0;   // timing experiments only (wrong results)
     // M-splits: every split adds N*K*4 bytes of atomics, every workgroup beyond what is resident at
-    // once adds a whole second round.  The DMA kernel holds one workgroup per CU with its 4-stage
-    // ring; if that leaves more than ~20 % of the CUs idle it runs two per CU with a 2-stage ring.
+    // once adds a whole second round.  The DMA kernel holds one 8-wave workgroup per CU (two wave
+    // groups splitting each 128-row ring slot); if that leaves more than ~20 % of the CUs idle it
+    // runs two 4-wave workgroups per CU instead.
     const int cus = cu_count();
     const int max_s = ceil_div(M, 4 * TM);   // at least 4 reduction stages per workgroup
     int splits = tn_splits(M, N, K), ring = 0;
     if (tn_cfg != 1) {
         const int s_floor = cus / tiles > 0 ? cus / tiles : 1;
-        if (tiles * s_floor * 5 >= cus * 4) { splits = s_floor; ring = 4; }
+        if (tiles * s_floor * 5 >= cus * 4) { splits = s_floor; ring = 4; }   // "4" = the one-per-CU form <2, 2>
         else { splits = ceil_div(2 * cus, tiles) > 1 ? (2 * cus) / tiles : 1; ring = 2; }
         if (splits > max_s) splits = max_s;
         if (splits < 1) splits = 1;
     }
-    const int rows_per_split = ceil_div(ceil_div(M, splits), TM) * TM;
+    // One workgroup per CU comes in two forms: four waves with a 4-stage ring (default), or eight waves
+    // = two wave groups splitting 128-row slots (ASR_GEMM_TN_CFG=8).  Stand-alone the 8-wave form is
+    // ~12 % faster (46 / 24 / 33 / 33 us vs 53 / 27 / 37 / 37 on the config-2 shapes), but this GEMM
+    // runs on the side stream BESIDE the dgrad / attention / LayerNorm chain, and two of its waves per
+    // SIMD take issue slots from that chain: the whole step is 2 % slower with it (A/B in one process:
+    // 8.10 vs 8.28 k utterances/s).  The step time decides.
+    const bool eight = ring == 4 && tn_cfg == 8;
+    const int gran = eight ? 2 * TM : TM;          // rows per ring slot
+    const int rows_per_split = ceil_div(ceil_div(M, splits), gran) * gran;
     const int nsplit = ceil_div(M, rows_per_split);
     const int use_atomic = tn_noatomic ? 0 : ((nsplit > 1) || accumulate);
     if (nsplit > 1 && !accumulate) {
@@ -952,12 +992,14 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
     } else {
         static void* zero_page = nullptr;
         if (!zero_page) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
-            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);
+            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
             if (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: zero page symbol not found");
         }
-        if (ring == 4) gemm_tn_dma_kernel<4><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
-        else gemm_tn_dma_kernel<2><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        if (ring == 4 && !eight) gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        else if (ring == 4) gemm_tn_dma_kernel<2, 2><<<grid, 512, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        else gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
     }
     ASR_CHECK_LAUNCH("asr_gemm_tn_bf16");
     return ASR_OK;

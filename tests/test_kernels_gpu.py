@@ -16,7 +16,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from oracle import ctc_ref, logmel_ref, ref_model as R  # noqa: E402
-from tests.helpers import golden_model_case, load_npz  # noqa: E402
+from tests.helpers import ROOT, golden_model_case, load_npz  # noqa: E402
 
 DEV = "cuda"
 
@@ -447,6 +447,29 @@ def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
     K.gemm_nt(a.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV), out, act, None if res is None else res.to(DEV))
     close(out, ref, rtol=1e-2, atol=1e-2, what="gemm_nt")
+
+
+def test_gemm_tn_eight_wave_form():
+    """The 8-wave (intra-workgroup split) form of the wgrad kernel, selected by ASR_GEMM_TN_CFG=8 in a
+    child process (the library reads the variable once): same results as the fp32 GEMM on the GPU."""
+    import subprocess, sys
+    code = """
+import math, sys, torch
+sys.path.insert(0, %r)
+from asr_chinese_e2e_amd import kernels as K
+torch.manual_seed(1)
+for M, N, Kd in ((16000, 1536, 512), (8197, 512, 512), (300, 128, 128)):
+    dy = (torch.randn(M, N, device="cuda") * 0.5 + 0.1).bfloat16(); x = torch.randn(M, Kd, device="cuda").bfloat16()
+    dw = torch.zeros(N, Kd, device="cuda"); db = torch.zeros(N, device="cuda")
+    K.gemm_tn(dy, x, dw, accumulate=True, dbias=db)
+    ref = dy.float().t() @ x.float()
+    assert float((dw - ref).abs().max()) <= 2e-3 * math.sqrt(M) + 2e-3 * float(ref.abs().max()), (M, N, Kd)
+    assert float((db - dy.float().sum(0)).abs().max()) <= 1e-3 * math.sqrt(M) + 1e-4 * float(dy.float().sum(0).abs().max())
+print("eight ok")
+""" % ROOT
+    import os
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ASR_GEMM_TN_CFG="8"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "eight ok" in p.stdout, p.stdout + p.stderr
 
 
 def test_gemm_nt_integer_exact(K):
