@@ -1,0 +1,146 @@
+"""Waveform dataset + length-bucketed loader with the feature front end on the GPU
+(SURVEY.md 8(f) rank 2).
+
+The reference's input pipeline (data/data_loader/ai_shell_1.py:12-104) computes the features on
+the CPU per utterance (torchaudio), pads whole batches of FEATURES on the host, is unshuffled,
+unbucketed, single-process, and moves the batch to the GPU inside collate.  Here the host only
+decodes PCM and pads WAVEFORMS into a pinned buffer; the copy runs on its own stream, log-mel /
+normalisation / SpecAugment / frame stacking run on the GPU (data_handler.processor.AudioParser),
+and the next batch is prepared while the model trains on the current one.  Batches are drawn
+from length buckets so that padding stays small.
+
+The yielded Pack has the reference's batch contract (collat, ai_shell_1.py:75-88): wave (B, T, F),
+wave_len, tgt_for_input, tgt_for_metric (0-padded, int64), tgt_len.
+"""
+import random
+import wave as wave_module
+
+import numpy as np
+import torch
+
+from ..Utils import Pack
+from .padder import Padder
+from .processor import AudioParser
+
+
+def load_wav(path):
+    """16-bit PCM WAV -> (float32 mono waveform in [-1, 1), sample_rate); channels are averaged
+    (loader.py:5-17 of the reference did the same through torchaudio with normalization=True)."""
+    with wave_module.open(path, "rb") as f:
+        if f.getsampwidth() != 2:
+            raise ValueError(f"{path}: only 16-bit PCM is supported (sample width {f.getsampwidth()})")
+        sr, ch, n = f.getframerate(), f.getnchannels(), f.getnframes()
+        pcm = np.frombuffer(f.readframes(n), dtype="<i2").astype(np.float32) / 32768.0
+    if ch > 1:
+        pcm = pcm.reshape(-1, ch).mean(axis=1)
+    return pcm, sr
+
+
+class WaveDataset:
+    """items: list of (waveform, text) where waveform is a 1-D float array / tensor or a path to a
+    16-bit WAV file, and text is a string (converted by `vocab.convert_str(..., use_bos=False,
+    use_eos=False)` as ai_shell_1.py:53-54) or a list of ids."""
+
+    def __init__(self, items, vocab=None, sample_rate=16000):
+        self.items, self.vocab, self.sample_rate = items, vocab, sample_rate
+        self._len = [None] * len(items)
+
+    def __len__(self):
+        return len(self.items)
+
+    def wave(self, i):
+        w = self.items[i][0]
+        if isinstance(w, str):
+            w, sr = load_wav(w)
+            if sr != self.sample_rate:
+                raise ValueError(f"{self.items[i][0]}: sample rate {sr}, expected {self.sample_rate}")
+        return np.asarray(w, dtype=np.float32).reshape(-1)
+
+    def num_samples(self, i):
+        if self._len[i] is None:
+            w = self.items[i][0]
+            if isinstance(w, str):
+                with wave_module.open(w, "rb") as f:
+                    self._len[i] = f.getnframes()
+            else:
+                self._len[i] = int(np.asarray(w).size)
+        return self._len[i]
+
+    def ids(self, i):
+        t = self.items[i][1]
+        if isinstance(t, str):
+            return self.vocab.convert_str(t, use_bos=False, use_eos=False)
+        return [int(x) for x in t]
+
+
+def bucket_batches(lengths, batch_size, bucket_size=None, shuffle=True, drop_last=False, rng=None):
+    """Index batches drawn from length buckets: indices sorted by length are cut into buckets of
+    `bucket_size` (default 8 batches), each bucket is shuffled and cut into batches, the batches
+    are shuffled.  Every index appears exactly once (or is dropped with a short last batch)."""
+    rng = rng or random
+    order = sorted(range(len(lengths)), key=lambda i: (lengths[i], i))
+    bucket_size = bucket_size or 8 * batch_size
+    batches = []
+    for s in range(0, len(order), bucket_size):
+        b = order[s:s + bucket_size]
+        if shuffle:
+            rng.shuffle(b)
+        for t in range(0, len(b), batch_size):
+            batches.append(b[t:t + batch_size])
+    if drop_last:
+        batches = [b for b in batches if len(b) == batch_size]
+    if shuffle:
+        rng.shuffle(batches)
+    return batches
+
+
+class BucketedWaveLoader:
+    """Iterating yields Packs on `device`; one batch is prepared ahead on a side stream."""
+
+    def __init__(self, dataset, batch_size, parser=None, augment=False, shuffle=True, drop_last=False, seed=0, bucket_size=None,
+                 device="cuda", dtype=torch.bfloat16):
+        self.ds, self.batch_size, self.augment, self.shuffle, self.drop_last = dataset, batch_size, augment, shuffle, drop_last
+        self.device, self.dtype = torch.device(device), dtype
+        if self.device.type != "cuda":
+            raise RuntimeError("the feature front end runs on the GPU only (no CPU fallback)")
+        self.parser = parser or AudioParser(device=self.device)
+        self.rng = random.Random(seed)          # batch order AND SpecAugment masks (the reference uses the global `random`)
+        self.bucket_size = bucket_size
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.lengths = [dataset.num_samples(i) for i in range(len(dataset))]
+
+    def __len__(self):
+        n = len(self.ds)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _prepare(self, idx):
+        waves = [self.ds.wave(i) for i in idx]
+        smax = max(w.size for w in waves)
+        host = torch.zeros(len(idx), smax, dtype=torch.float32).pin_memory()
+        for r, w in enumerate(waves):
+            host[r, : w.size] = torch.from_numpy(w)
+        wav_len = torch.tensor([w.size for w in waves], dtype=torch.int32)
+        tgt = [self.ds.ids(i) for i in idx]
+        tgt_in, tgt_len = Padder.pad_two(tgt, 0)
+        with torch.cuda.stream(self.stream):
+            dev_wav = host.to(self.device, non_blocking=True)
+            dev_len = wav_len.to(self.device, non_blocking=True)
+            feat, feat_len = self.parser.parse_batch(dev_wav, dev_len, self.dtype, augment=self.augment, rng=self.rng)
+            pack = Pack()
+            pack.add(wave=feat, wave_len=feat_len.long(), tgt_for_input=tgt_in.long().to(self.device, non_blocking=True),
+                     tgt_for_metric=tgt_in.long().to(self.device, non_blocking=True), tgt_len=torch.tensor(tgt_len).long().to(self.device, non_blocking=True))
+            done = torch.cuda.Event()
+            done.record()
+        return pack, done, host          # host buffer kept alive until the copy has run
+
+    def __iter__(self):
+        batches = bucket_batches(self.lengths, self.batch_size, self.bucket_size, self.shuffle, self.drop_last, self.rng)
+        nxt = self._prepare(batches[0]) if batches else None
+        for k in range(len(batches)):
+            pack, done, _host = nxt
+            nxt = self._prepare(batches[k + 1]) if k + 1 < len(batches) else None      # overlaps the consumer's step
+            torch.cuda.current_stream().wait_event(done)
+            for v in pack.values():
+                if torch.is_tensor(v):
+                    v.record_stream(torch.cuda.current_stream())
+            yield pack

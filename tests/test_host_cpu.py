@@ -172,6 +172,33 @@ def test_flat_layout_and_buckets():
         assert all(bk[i][0] == bk[i + 1][1] for i in range(len(bk) - 1))      # contiguous, descending
 
 
+def test_bucketed_batches_and_wav_reader(tmp_path):
+    import random
+    import wave
+    from asr_chinese_e2e_amd.data_handler import bucket_batches, load_wav
+    rng = random.Random(3)
+    lengths = [rng.randrange(1000, 90000) for _ in range(203)]
+    for shuffle in (False, True):
+        batches = bucket_batches(lengths, 8, bucket_size=32, shuffle=shuffle, rng=random.Random(1))
+        assert sorted(i for b in batches for i in b) == list(range(203))            # every utterance once
+        assert all(len(b) <= 8 for b in batches) and sum(len(b) == 8 for b in batches) >= 24
+        # a batch never mixes lengths from different buckets: padding stays within one bucket's spread
+        order = sorted(range(203), key=lambda i: (lengths[i], i))
+        bucket_of = {i: k // 32 for k, i in enumerate(order)}
+        assert all(len({bucket_of[i] for i in b}) == 1 for b in batches)
+    assert all(len(b) == 8 for b in bucket_batches(lengths, 8, drop_last=True, rng=random.Random(1)))
+    # 16-bit PCM reader: mono and stereo (channels averaged), scaled to [-1, 1)
+    x = (np.sin(np.arange(1600) * 0.05) * 12000).astype("<i2")
+    for ch in (1, 2):
+        path = str(tmp_path / f"t{ch}.wav")
+        with wave.open(path, "wb") as f:
+            f.setnchannels(ch); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((np.stack([x, x // 2], 1) if ch == 2 else x).tobytes())
+        w, sr = load_wav(path)
+        want = x / 32768.0 if ch == 1 else (x + x // 2) / 2 / 32768.0
+        assert sr == 16000 and w.dtype == np.float32 and np.allclose(w, want, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------ DP over gloo
 WORKER = r"""
 import os, sys, torch
