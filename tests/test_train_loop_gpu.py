@@ -248,3 +248,31 @@ def test_bucketed_wave_loader_feeds_the_model(tmp_path):
     aug = BucketedWaveLoader(ds, 4, parser=parser, augment=True, shuffle=True, seed=2, bucket_size=8, dtype=torch.float32)
     losses = [float(model.iterate(pack, optimizer=opt)[0].loss) for pack in aug]
     assert len(losses) == 6 and all(np.isfinite(losses))
+
+
+def test_overfit_small_batch_then_decode_exactly():
+    """End to end: a small joint model memorises four utterances (loss falls by > 10x), after which
+    greedy CTC decoding and attention beam search both return the training transcripts."""
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+    torch.manual_seed(0)
+    M = Models.TransformerOffical
+    cfg = M.get_default_config()()
+    cfg.fn_build(dict(n_mels=16, lfr_m=1, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=2, dropout=0.0, ctc_weight=0.3,
+                      dtype="fp32", cross_mask="wave_len", cer_in_iterate=False))
+    model = M(cfg, Vocab.synthetic(20)).cuda()
+    opt = NoamOpt(64, 1, 60, FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+    pack = synthetic_pack(4, 40, 16, 20, seed=3, ragged=True, Lmin=3, Lmax=6, device="cuda")
+    model.train()
+    first = float(model.iterate(pack, optimizer=opt)[0].loss)
+    for _ in range(400):
+        last = float(model.iterate(pack, optimizer=opt)[0].loss)
+    assert np.isfinite(last) and last < 0.1 * first, (first, last)
+    model.eval()
+    labels = [[int(t) for t in row if int(t) != 0] for row in pack.tgt_for_input.cpu()]
+    assert model.ctc_greedy_search(pack) == labels
+    hyps = model.beam_search(pack, beam_size=3, nbest=1, decode_max_len=10)
+    assert [h[0]["yseq"][1:-1] for h in hyps] == labels
+    ev, _ = model.iterate(pack, is_train=False)
+    assert float(ev.cer) < 1e-6 and float(ev.ctc_cer) < 1e-6
