@@ -283,6 +283,39 @@ def test_label_smoothing_matches_reference_formula():
             assert np.allclose(p.grad.cpu().numpy(), g.numpy(), rtol=3e-4, atol=3e-6 * max(float(g.abs().max()), 1.0)), n
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_baseline_config0_matches_oracle(dtype):
+    """BASELINE.json configs[0] (the reference's CPU-runnable case): 2-layer encoder + CTC at the default
+    width (d_model 512, 8 x 64 heads, ff 1024), batch 4, 100 frames of 80 mels, 50-character vocabulary.
+    fp32: loss 1e-4 rel; gradients: 99.9 % of every tensor's elements within 1e-3 rel + 2e-5 of the
+    largest gradient, and no element off by more than 1 % of its tensor's maximum (typical agreement is
+    3e-5; with 409 600 ReLU inputs an input within rounding of zero can land on the other side of the
+    ReLU on the GPU, which moves a handful of w_1 gradient elements by ~4e-3 and everything upstream of
+    that layer by ~3e-4); bf16 MFMA path: loss 2e-2, gradient cosines > 0.99."""
+    over = dict(layer_num=2, use_decoder=False, ctc_weight=1.0)
+    cfg, sd, batch = oracle_case(4, 100, 80, 50, 12, over, seed=21)
+    ref = R.RefTrainer(sd, cfg, warmup=4000).iterate(batch)
+    model = build(cfg, 50, "TransformerCTC", dtype=dtype).cuda()
+    model.load_state_dict({k: v for k, v in sd.items()})
+    pack = to_pack(batch)
+    model._ensure_engine(DEV)
+    model.zero_flat_grads()
+    loss, _ = model.train_step(pack)
+    tol = 1e-4 if dtype == "fp32" else 2e-2
+    assert abs(float(loss[0]) - float(ref["loss"])) < tol * abs(float(ref["loss"]))
+    gmax = max(float(g.abs().max()) for g in ref["grads"].values())
+    for n, p in model.named_parameters():
+        g = ref["grads"][n]
+        if dtype == "fp32":
+            if n.endswith("w_ks.bias"):
+                continue
+            d = (p.grad.cpu() - g).abs()
+            assert float((d > 1e-3 * g.abs() + 2e-5 * max(gmax, 1.0)).float().mean()) < 1e-3, n
+            assert float(d.max()) < 1e-2 * float(g.abs().max()), n
+        elif float(g.abs().max()) > 1e-6 * gmax and not n.endswith("w_ks.bias"):
+            assert cos(p.grad.cpu(), g) > 0.99, n
+
+
 def test_padded_rows_are_exact_zero_and_ignore_garbage():
     """Post-LN pad zeroing (transformer_official.py:208, 211): encoder output rows t >= wave_len are
     exactly 0 and garbage in the padded input frames cannot change any valid output."""
