@@ -200,7 +200,9 @@ def ctc_case(seed, B, T, V, Lmax, repeat=False, dtype=torch.float32):
 @pytest.mark.parametrize("seed,B,T,V,Lmax,repeat", [(0, 4, 20, 12, 5, False), (1, 3, 33, 50, 7, True), (2, 2, 100, 4232, 22, False),
                                                     (3, 5, 64, 31, 40, True), (4, 2, 12, 9, 3, False),
                                                     # bf16 row-in-registers kernels (V % 8 == 0): repeated labels, 2 and 4 registers per lane
-                                                    (5, 3, 40, 64, 9, True), (6, 2, 160, 1024, 70, True), (7, 2, 300, 512, 130, True)])
+                                                    (5, 3, 40, 64, 9, True), (6, 2, 160, 1024, 70, True), (7, 2, 300, 512, 130, True),
+                                                    # long-form (BASELINE configs[4]): 2000 frames through the rescaled fp64 lattice
+                                                    (8, 2, 2000, 64, 60, True)])
 def test_ctc(K, ws, dtype, seed, B, T, V, Lmax, repeat):
     lt, in_len, labels, lab_len = ctc_case(seed, B, T, V, Lmax, repeat, dtype)
     # oracle: numpy float64 alpha/beta on the (rounded) logits + torch F.ctc_loss as second opinion
