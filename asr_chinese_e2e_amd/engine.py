@@ -240,6 +240,8 @@ class Engine:
         # on a side stream, concurrently with the dgrad chain on the main stream, so the short,
         # latency-bound kernels of both chains fill each other's idle CUs.
         self.side = torch.cuda.Stream(device=flat.device)
+        self._side_handle = self.side.cuda_stream
+        self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
         self.overlap_wgrad = True
         # dropout (reference default 0.1; sites: transformer_official.py:175, 306; attention.py:59, 83;
         # module.py:73): masks are regenerated in backward from (step seed, site id), never stored
@@ -261,6 +263,13 @@ class Engine:
             streams = [torch.cuda.current_stream()] + ([self.side] if self.overlap_wgrad else [])
             self.grad_ready(self.flat.index[name][0], streams)
 
+    def _event(self):
+        if torch.cuda.is_current_stream_capturing():      # events recorded in a capture belong to that graph
+            return torch.cuda.Event()
+        ev = self._events[self._ev_next]
+        self._ev_next = (self._ev_next + 1) & 63
+        return ev
+
     def join_side(self):
         """Main stream waits for every weight-gradient kernel issued so far."""
         if self.overlap_wgrad:
@@ -274,13 +283,23 @@ class Engine:
                 lin.bgrad(bias_from, self.ws_side)
             lin.wgrad(dy, x, with_bias=fused)
             return
-        ev = torch.cuda.Event()
+        ev = self._event()
         ev.record()
         self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
-            if bias_from is not None and not fused:
-                lin.bgrad(bias_from, self.ws_side)
-            lin.wgrad(dy, x, with_bias=fused)
+        own = dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+        if own:     # only own kernels run: hand them the side stream directly instead of switching torch's current stream
+            K.STREAM_OVERRIDE = self._side_handle
+            try:
+                if bias_from is not None and not fused:
+                    lin.bgrad(bias_from, self.ws_side)
+                lin.wgrad(dy, x, with_bias=fused)
+            finally:
+                K.STREAM_OVERRIDE = None
+        else:
+            with torch.cuda.stream(self.side):
+                if bias_from is not None and not fused:
+                    lin.bgrad(bias_from, self.ws_side)
+                lin.wgrad(dy, x, with_bias=fused)
         if not torch.cuda.is_current_stream_capturing():   # graph pools never recycle during capture
             for t in (dy, x):
                 t.record_stream(self.side)
