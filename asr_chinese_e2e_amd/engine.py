@@ -14,6 +14,7 @@ MultiHeadAttention / PositionwiseFeedForwardUseConv -> cal_performance -> loss.b
 (Predictor/Models/transformer_official.py:68-104 and what it calls).
 """
 import math
+import os
 
 import torch
 
@@ -404,7 +405,9 @@ class Engine:
         p0, s0 = cache["drop"]
         dz, _ = K.add_ln_bwd(dy, dy2, cache["xhat_in"], cache["rstd_in"], self.ln_in.g, None, self.ln_in.gg, self.ln_in.gb, self.lin_in.gb, B, T, self.ws,
                              drop_p=p0, drop_seed=s0, drop_mode=2)
-        self._wgrad(self.lin_in, dz, cache["x_in"])
+        # the last weight gradient runs on the MAIN stream: the side stream is still busy with layer 0,
+        # and a cross-stream hand-over costs ~20 us of latency that nothing would hide at this point
+        self.lin_in.wgrad(dz, cache["x_in"])      # A/B: 8.50 vs 8.45 k utt/s
         self.join_side()
         self._ready("encoder.linear_in.weight")
 
