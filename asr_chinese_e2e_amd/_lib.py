@@ -23,6 +23,13 @@ DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
 
+class TnProblem(ctypes.Structure):
+    """asr_tn_problem of include/asr_hip.h."""
+    _fields_ = [("dY", P), ("X", P), ("dW", P), ("dbias", P), ("M", I), ("N", I), ("K", I), ("ldy", I), ("ldx", I), ("ldw", I)]
+
+
+TN_GROUP_MAX = 8
+
 # name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
 SIGNATURES = {
     "asr_abi_version": (I, []),
@@ -59,6 +66,7 @@ SIGNATURES = {
     "asr_gemm_tn_workspace_bytes": (Z, [I, I, I]),
     "asr_gemm_tn_bf16": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "asr_gemm_tn_bias_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
+    "asr_gemm_tn_grouped_bf16": (I, [P, I, I, P]),
     "asr_logmel_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "asr_utt_norm_lfr_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
     "asr_utt_norm_augment_lfr_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),

@@ -859,6 +859,278 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
     }
 }
 
+template <int S>
+__device__ __forceinline__ bf16x8 tg_frag(unsigned addr) {   // tn_frag_swz through the builtin (compiler-counted lgkmcnt)
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(size_t)(addr + S * 4096));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(size_t)(addr + S * 4096 + 2048));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight-gradient GEMM: up to TG_MAX independent problems dW_p (+)= dY_p^T X_p in ONE
+// launch.  A single projection's gradient has only N*K/128^2 = 16..48 output tiles, so filling 256
+// CUs means 5..16 splits of the M = B*T reduction: every split pays N*K*4 bytes of atomics, a ring
+// prologue and an epilogue.  All projections of a layer together have enough tiles for 256 x 128
+// tiles (a third less LDS-DMA and LDS-read traffic per FLOP than 128 x 128: the texture path takes
+// 64 B/clk/CU, exactly what a 128 x 128 tile needs at the MFMA rate) with only ~4 splits.
+// Workgroup = 4 waves, tile 256 (n) x 128 (k), wave tile 128 x 64 (4 x 2 MFMA blocks, 128
+// accumulator registers); stage = 64 reduction rows = [dY cols 0..127 | dY cols 128..255 | X],
+// three 16-KiB panels in the layout of gemm_tn_dma_kernel; ring of 3 stages (144 KiB).
+constexpr int TG_MAX = 8;
+struct TnProb {
+    const bf16_t* dY;
+    const bf16_t* X;
+    float* dW;
+    float* dbias;
+    int M, N, K, ldy, ldx, ldw;
+    int tiles_k, tiles;            // 128-wide k-tiles; tiles = n-tiles(256) * tiles_k
+    int rows_per_split, block_begin;
+};
+struct TnGroup {
+    TnProb p[TG_MAX];
+    int nprob;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ROWS reduction rows per stage (64 or 32), RING stages of 3 * ROWS * 256 bytes.  The LDS footprint decides
+// what the main stream can run on the same CU beside this kernel (attention needs 18 KiB per workgroup):
+// a 16-KiB pad on the single-problem kernel cost the training step 6 %.
+// DBG: timing experiments (wrong results): 1 = no DMA in the main loop, 2 = no MFMA, 3 = no LDS reads
+template <int ROWS, int RING, int DBG>
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup grp, int accumulate, int no_atomic, const void* __restrict__ zero_page) {
+    constexpr int KS = ROWS / 16;          // k-sub-steps (one MFMA depth) per stage
+    constexpr int PPW = 3 * ROWS / 16;     // one-KiB DMA pieces per wave per stage
+    constexpr int PPP = ROWS / 4;          // pieces per panel
+    constexpr int PANEL = ROWS * 256;      // bytes per panel
+    constexpr int STAGE = 3 * PANEL;
+    constexpr int PART = 3 * (KS - 1);     // DMA instructions of the newest stage issued before the barrier of a stage
+    static_assert(KS == 2 || KS == 4, "stage = 32 or 64 rows");
+    static_assert(RING >= 3 && RING <= 5, "ring of 3..5 stages");
+    extern __shared__ __attribute__((aligned(16))) char smem_g[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    int pi = 0;
+    for (int i = 1; i < grp.nprob; ++i) pi = vid >= grp.p[i].block_begin ? i : pi;
+    const TnProb& pr = grp.p[pi];
+    const bf16_t* __restrict__ dY = pr.dY;
+    const bf16_t* __restrict__ X = pr.X;
+    const int M = pr.M, N = pr.N, K = pr.K, ldy = pr.ldy, ldx = pr.ldx;
+    const int local = vid - pr.block_begin;
+    const int split = local / pr.tiles, tile = local - split * pr.tiles;
+    const int tk = tile % pr.tiles_k, tn = tile / pr.tiles_k;
+    const int n0 = tn * 256, k0 = tk * 128;
+    const int mbeg = split * pr.rows_per_split, mend = min(M, mbeg + pr.rows_per_split);
+    const int nsteps = (mend - mbeg + ROWS - 1) / ROWS;
+    if (nsteps <= 0) return;
+    const int use_atomic = no_atomic ? 0 : (accumulate || pr.rows_per_split < M);
+    const int wn = w >> 1, wk = w & 1;
+
+    // 3 PPP one-KiB pieces per stage, PPW per wave: piece P = PPW w + j -> panel P / PPP, rows 4 (P % PPP)..+3
+    const int lrow = lane >> 4, slot = lane & 15;
+    const bf16_t* cur[PPW];
+    int prow[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int P = w * PPW + j, panel = P / PPP, g = P % PPP;
+        const int row = 4 * g + lrow;
+        const int col = (slot ^ (4 * (row & 3))) * 8;
+        prow[j] = row;
+        cur[j] = panel < 2 ? dY + (size_t)(mbeg + row) * ldy + min(n0 + panel * 128 + col, N - 8) : X + (size_t)(mbeg + row) * ldx + min(k0 + col, K - 8);
+    }
+    const size_t ystep = (size_t)ROWS * ldy, xstep = (size_t)ROWS * ldx;
+    const bool ragged = ((mend - mbeg) % ROWS) != 0;
+    int it = 0, it_slot = 0;
+    // rows past the end of the range read the zero page: only the last stage can be partial, and the
+    // pointers are redirected once, when the cursor reaches it (a uniform branch, not per DMA)
+    auto fix_last = [&]() {
+        if (ragged && it == nsteps - 1) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) cur[j] = (mbeg + it * ROWS + prow[j] < mend) ? cur[j] : (const bf16_t*)zero_page;
+        }
+    };
+    fix_last();
+    // The LDS-DMA goes through inline asm and the transposed reads through the builtin - the other way
+    // round than in gemm_tn_dma_kernel: the compiler then counts lgkmcnt for the reads itself (also
+    // in front of any register copy it makes of a fragment - with asm reads it copied a loop-carried
+    // fragment before the data had arrived), while the DMA it would order against every LDS read
+    // with vmcnt(0) stays invisible to it and is waited for by hand.
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_g;
+    const unsigned dma_base = __builtin_amdgcn_readfirstlane(lds_base + w * PPW * 1024);
+    auto dma = [&](int j) {
+        const unsigned dst = dma_base + it_slot * STAGE + j * 1024;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(cur[j]), "s"(dst) : "memory");   // m0: no compiler-generated user in this kernel (checked in the ISA)
+    };
+    auto advance = [&]() {
+        ++it;
+        it_slot = it_slot == RING - 1 ? 0 : it_slot + 1;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) cur[j] += (w * PPW + j < 2 * PPP) ? ystep : xstep;   // pieces below 2 PPP are dY
+        fix_last();
+    };
+
+    f32x16 acc[4][2];  // [ni][ki]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    unsigned y_off[4], x_off[2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) y_off[a] = wn * PANEL + tn_frag_off(a * 32, lane);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) x_off[b] = 2 * PANEL + tn_frag_off(wk * 64 + b * 32, lane);
+    // bias gradient = column sums of the dY panels, by the workgroups of the first k-tile (see gemm_tn_dma_kernel)
+    const bool do_bias = pr.dbias != nullptr && tk == 0;
+    float bsum[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bsum[e] = 0.f;
+    const unsigned b_off = (unsigned)((tid >> 4) * 256 + (((tid & 15) ^ (4 * ((tid >> 4) & 3))) << 4));
+
+    for (int p = 0; p < RING - 1 && p < nsteps; ++p) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) dma(j);
+        advance();
+    }
+    // Software pipeline of ONE wave per SIMD: a wave issues in order, so a burst of transposed reads or a
+    // DMA instruction the texture unit is not ready for stalls the MFMAs behind it.  Hence (1) the
+    // reads of the next k-sub-step and the DMA instructions are spread between the 8 MFMAs of the
+    // current one, and (2) the barrier for stage i + 1 sits BEFORE the last k-sub-step of stage i,
+    // whose MFMAs cover the first fragment reads of stage i + 1.
+    bf16x8 yf[2][4], xf[2][2];
+    if (DBG == 3) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) yf[u][a] = bf16x8{};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xf[u][b] = bf16x8{};
+        }
+    }
+#define TG_RDY(BUF, S, BASE, A) do { if (DBG != 3) yf[BUF][A] = tg_frag<S>((BASE) + y_off[A]); } while (0)
+#define TG_RDX(BUF, S, BASE, B) do { if (DBG != 3) xf[BUF][B] = tg_frag<S>((BASE) + x_off[B]); } while (0)
+#define TG_MFMA(BUF, Q) do { if (DBG != 2) acc[(Q) >> 1][(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[BUF][(Q) >> 1], xf[BUF][(Q) & 1], acc[(Q) >> 1][(Q) & 1], 0, 0, 0); } while (0)
+#define TG_SB() __builtin_amdgcn_sched_barrier(0)
+#define TG_DMA(J) do { if (more && DBG != 1) dma(J); } while (0)
+// one k-sub-step: 8 MFMAs on buffer BUF; in their shadow the 12 reads of (slot NBASE, sub-step NS) into
+// buffer 1 - BUF (if RD) and DMA instructions 3 KSI .. 3 KSI + 2 of the stage RING - 1 ahead
+#define TG_KSTEP(BUF, KSI, RD, NS, NBASE)                                                  \
+    do {                                                                                   \
+        TG_MFMA(BUF, 0); TG_SB();                                                          \
+        if (RD) { TG_RDY(1 - BUF, NS, NBASE, 0); TG_RDX(1 - BUF, NS, NBASE, 0); } TG_SB(); \
+        TG_MFMA(BUF, 1); TG_SB();                                                          \
+        if (RD) { TG_RDX(1 - BUF, NS, NBASE, 1); } TG_DMA(3 * (KSI)); TG_SB();             \
+        TG_MFMA(BUF, 2); TG_SB();                                                          \
+        if (RD) { TG_RDY(1 - BUF, NS, NBASE, 1); } TG_SB();                                \
+        TG_MFMA(BUF, 3); TG_SB();                                                          \
+        if (RD) { TG_RDY(1 - BUF, NS, NBASE, 2); } TG_SB();                                \
+        TG_MFMA(BUF, 4); TG_SB();                                                          \
+        if (RD) { TG_RDY(1 - BUF, NS, NBASE, 3); } TG_DMA(3 * (KSI) + 1); TG_SB();         \
+        TG_MFMA(BUF, 5); TG_SB();                                                          \
+        TG_MFMA(BUF, 6); TG_SB();                                                          \
+        TG_DMA(3 * (KSI) + 2); TG_SB();                                                    \
+        TG_MFMA(BUF, 7); TG_SB();                                                          \
+    } while (0)
+    {   // stage 0 landed: the other prologue stages (PPW instructions each) may still be in flight
+        const int younger = (nsteps < RING - 1 ? nsteps : RING - 1) - 1;
+        if (younger >= 3) wait_vmcnt<3 * PPW>();
+        else if (younger == 2) wait_vmcnt<2 * PPW>();
+        else if (younger == 1) wait_vmcnt<PPW>();
+        else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    TG_SB();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) TG_RDY(0, 0, lds_base, a);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) TG_RDX(0, 0, lds_base, b);
+    int c_slot = 0;
+    for (int i = 0; i < nsteps; ++i) {
+        const bool more = it < nsteps;          // stage i + RING - 1 exists: issue it during this stage
+        const bool next = i + 1 < nsteps;
+        const unsigned sbase = lds_base + c_slot * STAGE;
+        c_slot = c_slot == RING - 1 ? 0 : c_slot + 1;
+        const unsigned nbase = lds_base + c_slot * STAGE;
+        if (do_bias) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int qq = 0; qq < ROWS / 16; ++qq) {
+                    const u32x4 c8 = *(const u32x4*)(smem_g + (sbase - lds_base) + h * PANEL + b_off + qq * 16 * 256);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bsum[h * 8 + 2 * e] += __uint_as_float(c8[e] << 16);
+                        bsum[h * 8 + 2 * e + 1] += __uint_as_float(c8[e] & 0xffff0000u);
+                    }
+                }
+        }
+        TG_SB();
+        TG_KSTEP(0, 0, true, 1, sbase);
+        if constexpr (KS == 4) {
+            TG_KSTEP(1, 1, true, 2, sbase);
+            TG_KSTEP(0, 2, true, 3, sbase);
+        }
+        // every read of this stage's slot has completed (the slot is refilled during the next stage); stage
+        // i + 1 must have landed in all waves before its fragments are read.  Younger than its DMA
+        // instructions: the whole stages i + 2 .. i + RING - 2 and PART instructions of stage i + RING - 1.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (next) {
+            if (more) wait_vmcnt<(RING - 3) * PPW + PART>();
+            else {
+                const int full = nsteps - 2 - i;    // stages i + 2 .. nsteps - 1, all of them issued completely
+                if (RING >= 5 && full >= 2) wait_vmcnt<2 * PPW>();
+                else if (RING >= 4 && full >= 1) wait_vmcnt<PPW>();
+                else wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        TG_SB();
+        TG_KSTEP(1, KS - 1, next, 0, nbase);
+        if (more) advance();
+    }
+#undef TG_KSTEP
+#undef TG_DMA
+#undef TG_SB
+#undef TG_MFMA
+#undef TG_RDX
+#undef TG_RDY
+    // accumulator: row = n (registers), col = k (lane): 32 consecutive k per register -> 128-B segments
+    float* __restrict__ dW = pr.dW;
+    const int ldw = pr.ldw;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+            const int kc = k0 + wk * 64 + ki * 32 + (lane & 31);
+            if (kc >= K) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 128 + ni * 32 + acc_row(e, lane);
+                if (n >= N) continue;
+                float* dst = dW + (size_t)n * ldw + kc;
+                if (use_atomic) atomicAdd(dst, acc[ni][ki][e]);
+                else *dst = acc[ni][ki][e];
+            }
+        }
+    if (do_bias) {   // 16 row phases -> one sum per column, through the (now idle) ring memory
+        __syncthreads();
+        float* red = (float*)smem_g;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[(tid >> 4) * 256 + (e >> 3) * 128 + (tid & 15) * 8 + (e & 7)] = bsum[e];
+        __syncthreads();
+        if (n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < 16; ++ph) t += red[ph * 256 + tid];
+            atomicAdd(pr.dbias + n0 + tid, t);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int rows, int cols, int ld) {
     const size_t total = (size_t)rows * cols;
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -931,6 +1203,81 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     return ASR_OK;
 }
 
+extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, int accumulate, void* stream) {
+    if (!probs || nprob <= 0 || nprob > TG_MAX) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: 1..%d problems per call (got %d)", TG_MAX, nprob);
+    hipStream_t st = (hipStream_t)stream;
+    TnGroup g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = nprob;
+    long long work = 0;
+    int max_m = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const asr_tn_problem& q = probs[i];
+        if (!q.dY || !q.X || !q.dW) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: null pointer in problem %d", i);
+        if (q.M <= 0 || q.N <= 0 || q.K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: bad shape M=%d N=%d K=%d in problem %d", q.M, q.N, q.K, i);
+        if (q.N % 8 || q.K % 8 || q.ldy % 8 || q.ldx % 8 || q.ldy < q.N || q.ldx < q.K || q.ldw < q.K)
+            ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: N, K, ldy, ldx must be multiples of 8 (problem %d: N=%d K=%d ldy=%d ldx=%d)", i, q.N, q.K, q.ldy, q.ldx);
+        if (((uintptr_t)q.dY | (uintptr_t)q.X) % 16) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: misaligned pointer in problem %d", i);
+        TnProb& t = g.p[i];
+        t.dY = (const bf16_t*)q.dY; t.X = (const bf16_t*)q.X; t.dW = q.dW; t.dbias = q.dbias;
+        t.M = q.M; t.N = q.N; t.K = q.K; t.ldy = q.ldy; t.ldx = q.ldx; t.ldw = q.ldw;
+        t.tiles_k = ceil_div(q.K, 128);
+        t.tiles = ceil_div(q.N, 256) * t.tiles_k;
+        work += (long long)t.tiles * q.M;
+        if (q.M > max_m) max_m = q.M;
+    }
+    // rows per workgroup R (one value for the whole group = balanced work): the smallest multiple of 64
+    // with sum_p tiles_p * ceil(M_p / R) <= #CUs, i.e. one round of one workgroup per CU; >= 4 stages each
+    const int cus = cu_count();
+    int R = (int)((work + cus - 1) / cus);
+    R = (R + TM - 1) / TM * TM;
+    if (R < 4 * TM) R = 4 * TM;
+    int blocks = 0;
+    for (;; R += TM) {
+        blocks = 0;
+        for (int i = 0; i < nprob; ++i) blocks += g.p[i].tiles * ceil_div(g.p[i].M, R);
+        if (blocks <= cus || R >= max_m) break;
+    }
+    static const int tn_noatomic = getenv("ASR_GEMM_TN_NOATOMIC") ? atoi(getenv("ASR_GEMM_TN_NOATOMIC")) : 0;   // timing experiments only (wrong results)
+    int begin = 0;
+    for (int i = 0; i < nprob; ++i) {
+        TnProb& t = g.p[i];
+        t.rows_per_split = R < t.M ? R : t.M;
+        t.block_begin = begin;
+        const int nsplit = ceil_div(t.M, R);
+        begin += t.tiles * nsplit;
+        if (nsplit > 1 && !accumulate) {
+            size_t total = (size_t)t.N * t.K;
+            int zg = (int)((total + 255) / 256);
+            zero_f32_kernel<<<zg < 1024 ? zg : 1024, 256, 0, st>>>(t.dW, t.N, t.K, t.ldw);
+        }
+    }
+    static void* zero_page = nullptr;
+    if (!zero_page && (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page))
+        ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: zero page symbol not found");
+    // stage rows x ring: 64 x 3 = 144 KiB is the fastest alone (0.67 PFLOP/s on a config-2 layer), but this GEMM runs
+    // beside the main stream, whose attention / LayerNorm workgroups need the rest of the CU's LDS
+    static const int cfg = getenv("ASR_GEMM_TNG_CFG") ? atoi(getenv("ASR_GEMM_TNG_CFG")) : 324;
+    static const int dbg = getenv("ASR_GEMM_TNG_DBG") ? atoi(getenv("ASR_GEMM_TNG_DBG")) : 0;
+#define TNG_LAUNCH(ROWS_, RING_, DBG_)                                                                                                   \
+    do {                                                                                                                                   \
+        static bool attr = false;                                                                                                          \
+        constexpr int lds = RING_ * 3 * ROWS_ * 256;                                                                                       \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<ROWS_, RING_, DBG_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
+        gemm_tn_grouped_kernel<ROWS_, RING_, DBG_><<<begin, 256, lds, st>>>(g, accumulate, tn_noatomic, zero_page);                        \
+    } while (0)
+    if (dbg == 1) TNG_LAUNCH(64, 3, 1);
+    else if (dbg == 2) TNG_LAUNCH(64, 3, 2);
+    else if (dbg == 3) TNG_LAUNCH(64, 3, 3);
+    else if (cfg == 643) TNG_LAUNCH(64, 3, 0);
+    else if (cfg == 325) TNG_LAUNCH(32, 5, 0);
+    else if (cfg == 323) TNG_LAUNCH(32, 3, 0);
+    else TNG_LAUNCH(32, 4, 0);
+#undef TNG_LAUNCH
+    ASR_CHECK_LAUNCH("asr_gemm_tn_grouped_bf16");
+    return ASR_OK;
+}
+
 extern "C" size_t asr_gemm_tn_workspace_bytes(int M, int N, int K) {
     (void)M; (void)N; (void)K;
     return 0;  // partial tiles are combined with fp32 atomics; no scratch needed
@@ -997,6 +1344,20 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
             (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
             if (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: zero page symbol not found");
         }
+        // LDS footprint experiments: a 16-KiB pad (144 KiB) costs the training step 6 %, 30 KiB 12 % - the
+        // main stream's attention / LayerNorm workgroups no longer fit beside this kernel on a CU
+        static const int lds_pad = getenv("ASR_TN_LDS_PAD") ? atoi(getenv("ASR_TN_LDS_PAD")) : 0;
+        if (lds_pad && ring == 4 && !eight) {
+            static bool once = false;
+            if (!once) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE + lds_pad); once = true; }
+            gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE + lds_pad, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        } else if (tn_cfg == 2 && ring == 4) {   // 2-stage ring, 64 KiB, still one workgroup per CU
+            gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        } else if (tn_cfg != 4 && ring == 4 && !eight) {   // default: 3-stage ring, 96 KiB (step 3.74 vs 3.79 ms with 4 stages = 128 KiB, although the kernel alone is 1-5 % slower)
+            static bool once3 = false;
+            if (!once3) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); once3 = true; }
+            gemm_tn_dma_kernel<3, 1><<<grid, 256, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        } else
         if (ring == 4 && !eight) gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
         else if (ring == 4) gemm_tn_dma_kernel<2, 2><<<grid, 512, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
         else gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);

@@ -244,6 +244,15 @@ class Engine:
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
         self.overlap_wgrad = True
+        # ASR_WGRAD_GROUP: "0" (default) one weight-gradient launch per projection, as soon as its dY exists;
+        # "layer" / "block" / "hybrid": collect them and launch one grouped GEMM (asr_gemm_tn_grouped_bf16) per
+        # layer / per attention or feed-forward block.  The grouped kernel is 1.6x faster alone (98 vs 160 us
+        # per config-2 layer) but one 100-us launch filling every CU overlaps worse with the main stream than
+        # four short ones spread over the layer: step 3.84 (layer) / 3.96 (block) vs 3.79 ms, joint 6.27 vs 6.16.
+        self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "0")
+        self.group_wgrad = None if self.group_wgrad == "0" else self.group_wgrad
+        self._pending = []
+        self._block_flush = self.group_wgrad == "block"
         # dropout (reference default 0.1; sites: transformer_official.py:175, 306; attention.py:59, 83;
         # module.py:73): masks are regenerated in backward from (step seed, site id), never stored
         self.drop_p = float(getattr(cfg, "dropout", 0.0))
@@ -260,6 +269,7 @@ class Engine:
     def _ready(self, name):
         """Gradients at flat offsets >= this tensor's offset are final once the work queued so far
         on BOTH streams has run: the consumer (dist.GradBucketer) waits on events of the two."""
+        self.flush_wgrads()
         if self.grad_ready is not None:
             streams = [torch.cuda.current_stream()] + ([self.side] if self.overlap_wgrad else [])
             self.grad_ready(self.flat.index[name][0], streams)
@@ -273,12 +283,39 @@ class Engine:
 
     def join_side(self):
         """Main stream waits for every weight-gradient kernel issued so far."""
+        self.flush_wgrads()
         if self.overlap_wgrad:
             torch.cuda.current_stream().wait_stream(self.side)
+
+    def flush_wgrads(self):
+        """Launch the weight gradients collected since the last flush as ONE grouped GEMM
+        (asr_gemm_tn_grouped_bf16) - on the side stream when the overlap is on."""
+        if not self._pending:
+            return
+        probs, self._pending = self._pending, []
+        if not self.overlap_wgrad:
+            K.gemm_tn_grouped(probs, accumulate=True)
+            return
+        ev = self._event()
+        ev.record()
+        self.side.wait_event(ev)
+        K.STREAM_OVERRIDE = self._side_handle
+        try:
+            K.gemm_tn_grouped(probs, accumulate=True)
+        finally:
+            K.STREAM_OVERRIDE = None
+        if not torch.cuda.is_current_stream_capturing():   # graph pools never recycle during capture
+            for dy, x, _, _ in probs:
+                dy.record_stream(self.side)
+                x.record_stream(self.side)
 
     def _wgrad(self, lin, dy, x, bias_from=None):
         """lin.gw += dy^T x (and lin.gb += colsum(bias_from)) on the side stream."""
         fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
+        if self.group_wgrad and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
+                and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
+            self._pending.append((dy, x, lin.gw, lin.gb if fused else None))     # launched by flush_wgrads (end of the layer)
+            return
         if not self.overlap_wgrad:
             if bias_from is not None and not fused:
                 lin.bgrad(bias_from, self.ws_side)
@@ -355,6 +392,8 @@ class Engine:
             self._wgrad(m.kv, dkv, c["kv_src"], bias_from=dkv)
             dx = m.q.dgrad(dq)
             m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
+        if self._block_flush:
+            self.flush_wgrads()
         return dx, dz
 
     def _ffn_block_fwd(self, f, x, B, T, lens, site):
@@ -375,6 +414,8 @@ class Engine:
         K.relu_bwd_(dh, c["h"], None if fused else f.w1.gb, self.ws)
         self._wgrad(f.w1, dh, c["x"], bias_from=dh if fused else None)
         dx = f.w1.dgrad(dh)
+        if self._block_flush:
+            self.flush_wgrads()
         return dx, dz
 
     # ------------------------------------------------------------------ encoder
@@ -398,6 +439,8 @@ class Engine:
         for i in reversed(range(self.L)):
             mha, ffn = self.enc[i]
             c1, c2 = cache["layers"][i]
+            if i == 0 and self.group_wgrad == "hybrid":      # nothing left to hide a whole layer's launch behind
+                self._block_flush = True
             dx, dz = self._ffn_block_bwd(ffn, c2, dy, dy2)
             dx, dz = self._attn_block_bwd(mha, c1, dx, dz)
             dy, dy2 = dx, dz
@@ -408,6 +451,7 @@ class Engine:
         # the last weight gradient runs on the MAIN stream: the side stream is still busy with layer 0,
         # and a cross-stream hand-over costs ~20 us of latency that nothing would hide at this point
         self.lin_in.wgrad(dz, cache["x_in"])      # A/B: 8.50 vs 8.45 k utt/s
+        self._block_flush = self.group_wgrad == "block"
         self.join_side()
         self._ready("encoder.linear_in.weight")
 

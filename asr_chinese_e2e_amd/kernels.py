@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ASR_BF16, ASR_F32, ACT_NONE, ACT_RELU, check, lib
+from ._lib import ASR_BF16, ASR_F32, ACT_NONE, ACT_RELU, TN_GROUP_MAX, TnProblem, check, lib
 
 _DT = {torch.float32: ASR_F32, torch.bfloat16: ASR_BF16}
 
@@ -424,6 +424,27 @@ def gemm_tn(dy, x, dw, accumulate=True, dbias=None):
         lib.asr_gemm_tn_bias_bf16(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), None, 0,
                                   _stream()), "asr_gemm_tn_bias_bf16"))
     return dw
+
+
+def gemm_tn_grouped(problems, accumulate=True):
+    """problems: list of (dy (M,N) bf16, x (M,K) bf16, dw (N,K) f32, dbias (N) f32 or None);
+    dw_p (+)= dy_p^T @ x_p and dbias_p += column sums of dy_p for all of them, TN_GROUP_MAX per launch."""
+    for i in range(0, len(problems), TN_GROUP_MAX):
+        chunk = problems[i:i + TN_GROUP_MAX]
+        arr = (TnProblem * len(chunk))()
+        flops = 0.0
+        for q, (dy, x, dw, dbias) in zip(arr, chunk):
+            assert dy.dtype == x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+            M, N = dy.shape
+            Kd = x.shape[1]
+            assert x.shape[0] == M and dw.shape == (N, Kd) and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
+            _chk_f32(dbias)
+            assert dbias is None or dbias.numel() == N
+            q.dY, q.X, q.dW, q.dbias = _p(dy), _p(x), _p(dw), _p(dbias)
+            q.M, q.N, q.K, q.ldy, q.ldx, q.ldw = M, N, Kd, dy.stride(0), x.stride(0), dw.stride(0)
+            flops += 2.0 * M * N * Kd
+        timed("gemm_tn", flops, lambda: check(lib.asr_gemm_tn_grouped_bf16(ctypes.byref(arr), len(chunk), int(accumulate), _stream()),
+                                              "asr_gemm_tn_grouped_bf16"))
 
 
 # --------------------------------------------------------------------------------- front end

@@ -283,6 +283,20 @@ int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M, int N, int
 int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K,
                           int ldy, int ldx, int ldw, int accumulate, void* ws, size_t ws_bytes,
                           void* stream);
+/* Grouped form: nprob (<= 8) independent weight gradients dW_p (+)= dY_p^T X_p (+ bias gradients
+ * where dbias != NULL) in ONE launch - e.g. all projections of a Transformer layer, whose
+ * autograd weight-gradient GEMMs the reference runs one by one (torch.autograd through
+ * attention.py:43-59, module.py:70-71).  Together the problems fill the GPU with larger tiles and
+ * fewer splits of the M = B*T reduction than each would alone.  `probs` is a HOST array, read
+ * during the call.  Per problem: dY (M, N) ldy, X (M, K) ldx bf16; dW (N, K) ldw f32. */
+typedef struct asr_tn_problem {
+    const void* dY;
+    const void* X;
+    float* dW;
+    float* dbias;
+    int M, N, K, ldy, ldx, ldw;
+} asr_tn_problem;
+int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Log-mel front end on device.

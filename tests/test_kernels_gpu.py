@@ -526,6 +526,51 @@ def test_gemm_tn(K, M, N, K_):
     close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn bias gradient")
 
 
+def _tn_problem(M, N, K_, with_bias, seed, strided=False):
+    g = torch.Generator().manual_seed(seed)
+    dy = (torch.randn(M, N, generator=g) * 0.5 + 0.1).bfloat16().to(DEV)
+    x = torch.randn(M, K_, generator=g).bfloat16().to(DEV)
+    if strided:                                     # a column slice of a wider tensor (the K|V part of a Q|K|V gradient)
+        wide = torch.zeros(M, N + 64, dtype=torch.bfloat16, device=DEV)
+        wide[:, 64:] = dy
+        dy = wide[:, 64:]
+    dw = torch.full((N, K_), 1.0, device=DEV)
+    db = torch.full((N,), 2.0, device=DEV) if with_bias else None
+    return dy, x, dw, db
+
+
+@pytest.mark.parametrize("shapes", [
+    [(16000, 1536, 512, True), (16000, 512, 512, False), (16000, 1024, 512, True), (16000, 512, 1024, False)],   # one encoder layer of config 2
+    [(16000, 4232, 512, True)],                                                                                # one problem: the CTC output layer
+    [(1000, 1536, 512, True), (16000, 1024, 512, True), (1000, 512, 512, False), (1037, 1024, 512, True), (1037, 512, 1024, False)],  # decoder-like: different M per problem
+    [(70, 40, 24, True), (513, 264, 136, True), (8197, 512, 80, False), (300, 128, 128, True), (64, 8, 8, True),
+     (129, 256, 128, False), (4000, 520, 72, True), (999, 2048, 8, True), (77, 16, 512, False)],                 # ragged rows, clamped edge columns, > 8 problems (two launches)
+])
+def test_gemm_tn_grouped(K, shapes):
+    """All weight gradients of a layer in one launch == the fp32 GEMM of each, bias gradients included."""
+    probs = [_tn_problem(M, N, K_, wb, 31 * i + M, strided=(i % 2 == 1)) for i, (M, N, K_, wb) in enumerate(shapes)]
+    for rep in range(2):                            # second launch accumulates on top of the first
+        K.gemm_tn_grouped(probs, accumulate=True)
+    for (M, N, K_, wb), (dy, x, dw, db) in zip(shapes, probs):
+        ref = dy.float().t() @ x.float()
+        close(dw - 1, 2 * ref, rtol=2e-3, atol=4e-3 * math.sqrt(M), what=f"grouped gemm_tn {M}x{N}x{K_}")
+        if wb:
+            close(db - 2, 2 * dy.float().sum(0), rtol=1e-4, atol=2e-3 * math.sqrt(M), what=f"grouped bias gradient {M}x{N}")
+    for dy, x, dw, db in probs:
+        dw.fill_(float("nan"))
+    K.gemm_tn_grouped([(dy, x, dw, None) for dy, x, dw, db in probs], accumulate=False)
+    for (M, N, K_, wb), (dy, x, dw, db) in zip(shapes, probs):
+        close(dw, dy.float().t() @ x.float(), rtol=2e-3, atol=2e-3 * math.sqrt(M), what=f"grouped gemm_tn overwrite {M}x{N}x{K_}")
+
+
+def test_gemm_tn_grouped_rejects_bad_arguments(K):
+    dy, x, dw, db = _tn_problem(64, 16, 16, True, 0)
+    with pytest.raises(RuntimeError):
+        K.gemm_tn_grouped([(dy, x[:, :12], dw[:, :12], db)])          # K not a multiple of 8
+    with pytest.raises(RuntimeError):
+        K.gemm_tn_grouped([(dy[:, 1:9], x, dw[:8], None)])            # misaligned dY
+
+
 # ------------------------------------------------------------------------------------ front end
 @pytest.mark.parametrize("m,n", [(1, 1), (4, 3)])
 def test_spec_augment_in_front_end(K, m, n):

@@ -6,7 +6,7 @@ import torch
 from asr_chinese_e2e_amd import kernels as K
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
-M = 16000
+M = int(os.environ.get("BENCH_M", "16000"))
 SHAPES = [(1536, 512, "qkv"), (512, 512, "fc"), (1024, 512, "w1"), (512, 1024, "w2"), (4232, 512, "ctc_lo")]
 
 
@@ -24,7 +24,7 @@ def timeit(fn, reps=30):
 
 
 torch.manual_seed(0)
-for N, Kd, name in SHAPES:
+for N, Kd, name in (SHAPES if which != "grp" else []):
     x = torch.randn(M, Kd, device="cuda").bfloat16()
     w = (torch.randn(N, Kd, device="cuda") * 0.05).bfloat16()
     b = torch.randn(N, device="cuda")
@@ -49,3 +49,22 @@ for N, Kd, name in SHAPES:
             t = timeit(lambda: K.gemm_nn(dy, w, dx))
             line += f"  mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s"
     print(line, flush=True)
+
+if which in ("grp", "all"):
+    # one encoder layer's four weight gradients: four launches vs one grouped launch
+    probs = []
+    for N, Kd, name in SHAPES[:4]:
+        dy = torch.randn(M, N, device="cuda").bfloat16()
+        x = torch.randn(M, Kd, device="cuda").bfloat16()
+        probs.append((dy, x, torch.zeros(N, Kd, device="cuda"), torch.zeros(N, device="cuda") if name in ("qkv", "w1") else None))
+    fl = sum(2.0 * M * p[0].shape[1] * p[1].shape[1] for p in probs)
+    t1 = timeit(lambda: [K.gemm_tn(dy, x, dw, accumulate=True, dbias=db) for dy, x, dw, db in probs])
+    tg = timeit(lambda: K.gemm_tn_grouped(probs, accumulate=True))
+    print(f"layer wgrads: 4 launches {t1:7.1f} us {fl / t1 / 1e6:6.0f} TF/s | grouped {tg:7.1f} us {fl / tg / 1e6:6.0f} TF/s", flush=True)
+    N, Kd, _ = SHAPES[4]
+    dy = torch.randn(M, N, device="cuda").bfloat16(); x = torch.randn(M, Kd, device="cuda").bfloat16()
+    dw = torch.zeros(N, Kd, device="cuda"); db = torch.zeros(N, device="cuda")
+    fl = 2.0 * M * N * Kd
+    t1 = timeit(lambda: K.gemm_tn(dy, x, dw, accumulate=True, dbias=db))
+    tg = timeit(lambda: K.gemm_tn_grouped([(dy, x, dw, db)], accumulate=True))
+    print(f"ctc_lo wgrad: single {t1:7.1f} us {fl / t1 / 1e6:6.0f} TF/s | grouped kernel {tg:7.1f} us {fl / tg / 1e6:6.0f} TF/s", flush=True)
