@@ -24,7 +24,7 @@ import torch
 from .. import engine as E
 from .. import kernels as K
 from ..Bases import BaseConfig, BaseModel
-from ..Utils import Pack, calculate_cer
+from ..Utils import Pack
 
 SOS_ID, EOS_ID, PAD_ID = 2, 3, 0   # transformer_official.py:53-54, Utils/loss.py:5
 PE_MAXLEN = 5000                   # transformer_official.py:49, 65
@@ -246,14 +246,23 @@ class _SpeechTransformer(BaseModel):
             pack.add(ctc_logits=logits.view(B, T, self.V))
         return pack
 
+    def _tok_table(self, device):
+        if getattr(self, "_tok_tab", None) is None or self._tok_tab[0].device != torch.device(device):
+            self._tok_tab = K.token_table(self.vocab._id2token, device)
+        return self._tok_tab
+
+    def _cer_ids(self, ids, gold, hyp_len=None, ref_len=None):
+        """CER in percent of a batch as a 1-element DEVICE tensor: strings, edit distance and the mean stay on
+        the GPU (asr_cer) - the reference copies the ids to the host and loops over the batch every step
+        (transformer_official.py:87-91, score.py:4-13)."""
+        per = K.cer(ids.int().contiguous(), gold.int().contiguous(), self._tok_table(ids.device), self.vocab._token2id[self.vocab.PAD],
+                    hyp_len=hyp_len, ref_len=ref_len)
+        return (per.sum() * (100.0 / per.numel())).reshape(1)
+
     def _cer(self, pred, gold):
         """transformer_official.py:87-91.  Greedy ids by argmax (first index wins ties - the
         reference's topk(1) tie order at exactly-zero padded rows is implementation-defined)."""
-        ids = pred.argmax(-1).cpu()
-        gold = gold.cpu()
-        hyp = [self.vocab.convert_id2str(r.tolist()) for r in ids]
-        ref = [self.vocab.convert_id2str(r.tolist()) for r in gold]
-        return sum(calculate_cer(h, r) for h, r in zip(hyp, ref)) * 100 / len(hyp)
+        return self._cer_ids(pred.argmax(-1), gold)
 
     def cal_metrics(self, output, input):
         """transformer_official.py:83-94 on a forward() output (evaluation path)."""
@@ -272,11 +281,11 @@ class _SpeechTransformer(BaseModel):
         assert not torch.isinf(loss[0])
         pack.add(loss=loss[0])
         if self.use_decoder:
-            pack.add(cer=torch.Tensor([self._cer(output.pred, output.gold)]))
+            pack.add(cer=self._cer(output.pred, output.gold))
         if self.use_ctc:
             # best-path CTC decoding on the device; the label strings (no sos/eos) are the reference
             cer = self._ctc_cer(output.ctc_logits.contiguous(), input.wave_len.to(torch.int32), prep[2], prep[4])
-            pack.add(**({"ctc_cer": torch.Tensor([cer])} if self.use_decoder else {"cer": torch.Tensor([cer])}))
+            pack.add(**({"ctc_cer": cer} if self.use_decoder else {"cer": cer}))
         return pack
 
     def beam_search(self, input, beam_size=5, nbest=1, decode_max_len=0):
@@ -296,13 +305,7 @@ class _SpeechTransformer(BaseModel):
 
     def _ctc_cer(self, logits, wave_len, labels32, lab_len):
         ids, lens = K.ctc_greedy_decode(logits, wave_len, PAD_ID)
-        ids, lens, labels32, lab_len = ids.cpu(), lens.cpu(), labels32.cpu(), lab_len.cpu()
-        tot = 0.0
-        for b in range(ids.shape[0]):
-            hyp = self.vocab.convert_id2str(ids[b, : int(lens[b])].tolist())
-            ref = self.vocab.convert_id2str(labels32[b, : int(lab_len[b])].tolist())
-            tot += calculate_cer(hyp, ref)
-        return tot * 100 / ids.shape[0]
+        return self._cer_ids(ids, labels32, hyp_len=lens, ref_len=lab_len)
 
     def train_step(self, input, loss_scale=1.0, n_valid_override=None, ctc_batch=None):
         """Forward + backward into the flat gradient buffer (no optimizer).  Returns the metrics
@@ -358,10 +361,7 @@ class _SpeechTransformer(BaseModel):
         if self.use_decoder and self.use_ctc:
             metrics.add(ce=loss[1], ctc=loss[2])
         if pg is not None:
-            ids, gold = pg[0].cpu(), pg[1].cpu()
-            hyp = [self.vocab.convert_id2str(r.tolist()) for r in ids]
-            ref = [self.vocab.convert_id2str(r.tolist()) for r in gold]
-            metrics.add(cer=torch.Tensor([sum(calculate_cer(h, r) for h, r in zip(hyp, ref)) * 100 / len(hyp)]))
+            metrics.add(cer=self._cer_ids(pg[0], pg[1]))      # no device-to-host copy, no sync
         return metrics, None
 
     def greedy_search(self, input, decode_max_len=0):

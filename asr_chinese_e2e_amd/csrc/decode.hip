@@ -322,3 +322,109 @@ extern "C" int asr_cache_gather(const void* src, void* dst, const int32_t* paren
     ASR_CHECK_LAUNCH("asr_cache_gather");
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Character error rate on the device (Predictor/Utils/score.py:4-13 with the strings of
+// data_handler/vocab.py:75-79): one wave per utterance.  The two strings are assembled in LDS as code points
+// (ids != pad, token strings joined by one space), then the Levenshtein rows are computed 64 columns at
+// a time: with t[j] = min(prev[j] + 1, prev[j-1] + (a_i != b_j)) the recurrence cur[j] = min(t[j], cur[j-1] + 1)
+// is cur[j] - j = prefix-min of (t[k] - k), a wave scan.
+namespace {
+
+__device__ __forceinline__ int wave_incl_scan_add(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan_min(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v = min(v, u);
+    }
+    return v;
+}
+
+// writes " tok tok tok" (leading space) into s, returns its length
+__device__ int cer_build_string(const int32_t* ids, int n, int pad_id, int V, const int32_t* __restrict__ tok_cp, const int32_t* __restrict__ tok_off,
+                                int* s, int lane) {
+    int base = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        const int id = t < n ? ids[t] : pad_id;
+        const bool valid = t < n && id != pad_id && id >= 0 && id < V;
+        const int o0 = valid ? tok_off[id] : 0;
+        const int len = valid ? tok_off[id + 1] - o0 + 1 : 0;
+        const int incl = wave_incl_scan_add(len, lane);
+        int pos = base + incl - len;
+        if (valid) {
+            s[pos++] = ' ';
+            for (int c = 0; c < len - 1; ++c) s[pos + c] = tok_cp[o0 + c];
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    return base;
+}
+
+__global__ __launch_bounds__(64) void cer_kernel(const int32_t* __restrict__ hyp, const int32_t* __restrict__ hyp_len, int Lh, int ldh,
+                                                 const int32_t* __restrict__ ref, const int32_t* __restrict__ ref_len, int Lr, int ldr,
+                                                 const int32_t* __restrict__ tok_cp, const int32_t* __restrict__ tok_off, int V, int pad_id, int cap_a,
+                                                 int cap_b, float* __restrict__ per_utt) {
+    extern __shared__ int cer_smem[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int* sa = cer_smem;              // hypothesis, cap_a code points (with the leading space)
+    int* sb = sa + cap_a;            // reference, cap_b
+    int* row0 = sb + cap_b;          // cap_b + 1
+    int* row1 = row0 + cap_b + 1;
+    const int nh = hyp_len ? min(max(hyp_len[b], 0), Lh) : Lh, nr = ref_len ? min(max(ref_len[b], 0), Lr) : Lr;
+    int n = cer_build_string(hyp + (size_t)b * ldh, nh, pad_id, V, tok_cp, tok_off, sa, lane);
+    int m = cer_build_string(ref + (size_t)b * ldr, nr, pad_id, V, tok_cp, tok_off, sb, lane);
+    __syncthreads();
+    const int* a = sa + 1;           // drop the leading space
+    const int* bb = sb + 1;
+    n = n > 0 ? n - 1 : 0;
+    m = m > 0 ? m - 1 : 0;
+    int spaces = 0;
+    for (int j = lane; j < m; j += 64) spaces += bb[j] == ' ';
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) spaces += __shfl_xor(spaces, o, 64);
+    for (int j = lane; j <= m; j += 64) row0[j] = j;
+    __syncthreads();
+    int* prev = row0;
+    int* cur = row1;
+    for (int i = 1; i <= n; ++i) {
+        const int ca = a[i - 1];
+        int carry = i;               // cur[0] - 0
+        for (int j0 = 1; j0 <= m; j0 += 64) {
+            const int j = j0 + lane;
+            int v = 0x3fffffff;
+            if (j <= m) v = min(prev[j] + 1, prev[j - 1] + (ca != bb[j - 1])) - j;
+            v = min(wave_incl_scan_min(v, lane), carry);
+            if (j <= m) cur[j] = v + j;
+            carry = __shfl(v, 63, 64);
+        }
+        if (lane == 0) cur[0] = i;
+        __syncthreads();
+        int* t = prev; prev = cur; cur = t;
+    }
+    if (lane == 0) per_utt[b] = (float)prev[m] / (float)(spaces + 1);
+}
+
+}  // namespace
+
+extern "C" int asr_cer(const int32_t* hyp, const int32_t* hyp_len, int Lh, int ldh, const int32_t* ref, const int32_t* ref_len, int Lr, int ldr,
+                       const int32_t* tok_cp, const int32_t* tok_off, int V, int max_tok_len, int pad_id, int B, float* per_utt, void* stream) {
+    if (!hyp || !ref || !tok_cp || !tok_off || !per_utt) ASR_FAIL(ASR_EINVAL, "asr_cer: null pointer");
+    if (B <= 0 || Lh < 0 || Lr < 0 || ldh < Lh || ldr < Lr || V <= 0 || max_tok_len < 0) ASR_FAIL(ASR_EINVAL, "asr_cer: bad shape B=%d Lh=%d Lr=%d V=%d", B, Lh, Lr, V);
+    const long long cap_a = (long long)Lh * (max_tok_len + 1) + 1, cap_b = (long long)Lr * (max_tok_len + 1) + 1;
+    const long long bytes = (cap_a + cap_b + 2 * (cap_b + 1)) * 4;
+    if (bytes > 150 * 1024) ASR_FAIL(ASR_EINVAL, "asr_cer: strings of up to %lld + %lld code points do not fit the LDS", cap_a, cap_b);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)cer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    cer_kernel<<<B, 64, (size_t)bytes, (hipStream_t)stream>>>(hyp, hyp_len, Lh, ldh, ref, ref_len, Lr, ldr, tok_cp, tok_off, V, pad_id, (int)cap_a, (int)cap_b, per_utt);
+    ASR_CHECK_LAUNCH("asr_cer");
+    return ASR_OK;
+}

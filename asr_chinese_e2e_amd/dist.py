@@ -130,13 +130,16 @@ class DataParallel:
         self.bucketer.begin()
         B = input.wave.shape[0]
         # the token count only normalises the CE term: the CTC-only model needs no count exchange
-        loss, _ = model.train_step(input, n_valid_override=self._global_count if model.use_decoder else None,
-                                   ctc_batch=B * self.world)
+        loss, pg = model.train_step(input, n_valid_override=self._global_count if model.use_decoder else None,
+                                    ctc_batch=B * self.world)
         self.bucketer.finish()
         optimizer.fused_step(model._flat, CLIP_NORM)
+        cer = model._cer_ids(pg[0], pg[1]) if pg is not None else None      # of this rank's utterances, computed on the device
         if not self.reduce_loss:      # rank-local loss estimate (no extra collective per step)
             metrics = Pack()
             metrics.add(loss=loss[0])
+            if cer is not None:
+                metrics.add(cer=cer)
             return metrics, None
         # CE was normalised by the GLOBAL token count (sum over ranks = global CE); the CTC term
         # reported by the kernel is per local batch (mean over ranks = global CTC)
@@ -148,4 +151,6 @@ class DataParallel:
             total = total + lam * ctc
         metrics = Pack()
         metrics.add(loss=total)
+        if cer is not None:
+            metrics.add(cer=cer)
         return metrics, None

@@ -447,6 +447,29 @@ def gemm_tn_grouped(problems, accumulate=True):
                                               "asr_gemm_tn_grouped_bf16"))
 
 
+def token_table(id2token, device):
+    """(tok_cp, tok_off, max_tok_len) for cer(): code points of every token string, back to back."""
+    cps, off = [], [0]
+    for tok in id2token:
+        cps.extend(ord(c) for c in tok)
+        off.append(len(cps))
+    mx = max((off[i + 1] - off[i] for i in range(len(id2token))), default=0)
+    return (torch.tensor(cps if cps else [0], dtype=torch.int32, device=device), torch.tensor(off, dtype=torch.int32, device=device), mx)
+
+
+def cer(hyp, ref, table, pad_id, hyp_len=None, ref_len=None):
+    """Per-utterance character error rate (B,) f32 on the device, reference string convention
+    (score.py:4-13 over vocab.py:75-79 strings).  hyp (B, Lh), ref (B, Lr) int32 ids."""
+    tok_cp, tok_off, mx = table
+    _chk_i32(hyp, ref, hyp_len, ref_len)
+    assert hyp.dim() == 2 and ref.dim() == 2 and hyp.shape[0] == ref.shape[0] and hyp.stride(1) == 1 and ref.stride(1) == 1
+    B = hyp.shape[0]
+    out = torch.empty(B, dtype=torch.float32, device=hyp.device)
+    check(lib.asr_cer(_p(hyp), _p(hyp_len), hyp.shape[1], hyp.stride(0), _p(ref), _p(ref_len), ref.shape[1], ref.stride(0), _p(tok_cp), _p(tok_off),
+                      tok_off.numel() - 1, mx, int(pad_id), B, _p(out), _stream()), "asr_cer")
+    return out
+
+
 # --------------------------------------------------------------------------------- front end
 def logmel(wav, wav_len, window, melfb, Tmax, feat=None):
     _chk_f32(wav, window, melfb)

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.0)
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step instead of eager launches "
                     "(measured SLOWER on MI355X/ROCm 7: 5.21 vs 4.88 ms CTC-only, 8.81 vs 8.42 ms joint - the step is GPU-bound)")
+    ap.add_argument("--cer", action="store_true", help="joint config: character error rate of the greedy ids in every training step, as the "
+                    "reference's iterate does (on the device: asr_cer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
@@ -137,7 +139,7 @@ def main():
     Model = Models.TransformerOffical if joint else Models.TransformerCTC
     cfg = Model.get_default_config()()
     cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=args.dropout, layer_num=args.layers, ctc_weight=0.3 if joint else 1.0, dtype="bf16",
-                      attn_window=args.window, cer_in_iterate=False, warm_up=4000))
+                      attn_window=args.window, cer_in_iterate=args.cer, warm_up=4000))
     torch.manual_seed(0)
     model = Model(cfg, Vocab.synthetic(args.vocab)).to(dev)
     adam = FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9)

@@ -187,6 +187,19 @@ int asr_beam_step(const float* top_vals, const int32_t* top_ids, float* score, i
 int asr_cache_gather(const void* src, void* dst, const int32_t* parent, int L, int R, int beam,
                      int Lcap, int n_pos, int row_bytes, void* stream);
 
+/* Character error rate per utterance on the device.
+ * Replaces: calculate_cer (Predictor/Utils/score.py:4-13) over Vocab.convert_id2str strings
+ *           (data_handler/vocab.py:75-79), called per step from cal_metrics
+ *           (transformer_official.py:87-91) after a device-to-host copy of the greedy ids.
+ * Convention kept: ids equal to pad_id are dropped, the token strings are joined by ONE space, the edit
+ * distance runs over code points (spaces included) and is divided by (spaces in the reference string + 1).
+ * hyp (B, Lh) ldh, ref (B, Lr) ldr: int32 ids; hyp_len / ref_len (B) or NULL = whole rows.
+ * tok_cp: code points of all V token strings back to back; tok_off (V + 1): start of each;
+ * max_tok_len: longest token string.  per_utt (B) f32 = distance / words of each utterance. */
+int asr_cer(const int32_t* hyp, const int32_t* hyp_len, int Lh, int ldh, const int32_t* ref,
+            const int32_t* ref_len, int Lr, int ldr, const int32_t* tok_cp, const int32_t* tok_off,
+            int V, int max_tok_len, int pad_id, int B, float* per_utt, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Softmax cross-entropy with ignore_index, forward + gradient in one pass over the logits.
  * Replaces:  F.cross_entropy(pred, gold, ignore_index=0, reduction='mean')  Utils/loss.py:47-49

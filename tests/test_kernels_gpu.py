@@ -571,6 +571,49 @@ def test_gemm_tn_grouped_rejects_bad_arguments(K):
         K.gemm_tn_grouped([(dy[:, 1:9], x, dw[:8], None)])            # misaligned dY
 
 
+# ------------------------------------------------------------------------------------ CER on the device
+def test_cer_matches_host_convention(K):
+    """asr_cer == calculate_cer(convert_id2str(hyp), convert_id2str(ref)) (score.py:4-13 over vocab.py:75-79
+    strings): pads dropped anywhere in the row, multi-character tokens, empty strings, rows longer than one
+    64-lane chunk, explicit lengths."""
+    from asr_chinese_e2e_amd.Utils import calculate_cer
+    from asr_chinese_e2e_amd.data_handler import Vocab
+    v = Vocab.synthetic(60)
+    for tok in ("<unk>", "ab", "a", "b", "abc", " x"):          # multi-character tokens, one even containing a space
+        v._token2id[tok] = len(v._token2id)
+    v._id2token = list(v._token2id)
+    V = len(v._id2token)
+    table = K.token_table(v._id2token, DEV)
+    rng = np.random.RandomState(5)
+    B, Lh, Lr = 24, 150, 140
+    hyp = rng.randint(0, V, size=(B, Lh)).astype(np.int32)
+    ref = rng.randint(0, V, size=(B, Lr)).astype(np.int32)
+    hyp[rng.rand(B, Lh) < 0.2] = 0                               # pads anywhere (argmax rows of the reference contain them)
+    ref[rng.rand(B, Lr) < 0.2] = 0
+    for b in range(0, B, 3):                                     # related strings: small distances
+        n = min(Lh, Lr)
+        hyp[b, :n] = ref[b, :n]
+        hyp[b, rng.randint(0, n, 7)] = rng.randint(1, V, 7)
+    hl = rng.randint(0, Lh + 1, B).astype(np.int32)
+    rl = rng.randint(1, Lr + 1, B).astype(np.int32)
+    hl[0], hl[1], rl[1] = 0, 0, 1
+    hyp[2], ref[3] = 0, 0                                         # all pad: empty strings ("".split(" ") has one word)
+    ref[1, 0] = 0
+    hd, rd = torch.from_numpy(hyp).to(DEV), torch.from_numpy(ref).to(DEV)
+
+    def host(h, r):
+        return calculate_cer(v.convert_id2str(h.tolist()), v.convert_id2str(r.tolist()))
+
+    got = K.cer(hd, rd, table, 0).cpu().numpy()
+    want = np.array([host(hyp[b], ref[b]) for b in range(B)])
+    assert np.allclose(got, want, rtol=1e-6, atol=0), (got, want)
+    got = K.cer(hd, rd, table, 0, hyp_len=torch.from_numpy(hl).to(DEV), ref_len=torch.from_numpy(rl).to(DEV)).cpu().numpy()
+    want = np.array([host(hyp[b, :hl[b]], ref[b, :rl[b]]) for b in range(B)])
+    assert np.allclose(got, want, rtol=1e-6, atol=0), (got, want)
+    with pytest.raises(RuntimeError):                            # strings that cannot fit the LDS are refused, not truncated
+        K.cer(torch.zeros(1, 9000, dtype=torch.int32, device=DEV), torch.zeros(1, 9000, dtype=torch.int32, device=DEV), table, 0)
+
+
 # ------------------------------------------------------------------------------------ front end
 @pytest.mark.parametrize("m,n", [(1, 1), (4, 3)])
 def test_spec_augment_in_front_end(K, m, n):
