@@ -24,7 +24,7 @@ def timeit(fn, reps=30):
 
 
 torch.manual_seed(0)
-for N, Kd, name in (SHAPES if which != "grp" else []):
+for N, Kd, name in (SHAPES if which not in ("grp", "grp1") else []):
     x = torch.randn(M, Kd, device="cuda").bfloat16()
     w = (torch.randn(N, Kd, device="cuda") * 0.05).bfloat16()
     b = torch.randn(N, device="cuda")
@@ -68,3 +68,13 @@ if which in ("grp", "all"):
     t1 = timeit(lambda: K.gemm_tn(dy, x, dw, accumulate=True, dbias=db))
     tg = timeit(lambda: K.gemm_tn_grouped([(dy, x, dw, db)], accumulate=True))
     print(f"ctc_lo wgrad: single {t1:7.1f} us {fl / t1 / 1e6:6.0f} TF/s | grouped kernel {tg:7.1f} us {fl / tg / 1e6:6.0f} TF/s", flush=True)
+
+if which == "grp1":
+    # every projection alone: per-projection kernel (128 x 128 tiles) vs the grouped kernel's 256 x 128 tiles with one problem
+    for N, Kd, name in SHAPES:
+        dy = torch.randn(M, N, device="cuda").bfloat16(); x = torch.randn(M, Kd, device="cuda").bfloat16()
+        dw = torch.zeros(N, Kd, device="cuda"); db = torch.zeros(N, device="cuda")
+        fl = 2.0 * M * N * Kd
+        t1 = timeit(lambda: K.gemm_tn(dy, x, dw, accumulate=True, dbias=db))
+        tg = timeit(lambda: K.gemm_tn_grouped([(dy, x, dw, db)], accumulate=True))
+        print(f"{name:7s} single {t1:7.1f} us {fl / t1 / 1e6:6.0f} TF/s | 256x128 kernel {tg:7.1f} us {fl / tg / 1e6:6.0f} TF/s", flush=True)
