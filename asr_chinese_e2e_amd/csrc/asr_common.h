@@ -128,17 +128,20 @@ static __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const floa
     __shared__ float red[32][33];
     const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
     const int col = blockIdx.x * 32 + cg;
+    // gridDim.y > 1 (accumulating calls only): the partial rows are split between gridDim.y workgroups, each
+    // adds its share with one atomic per column - one batch of loads per thread instead of four in series
+    const int per = (P + gridDim.y - 1) / gridDim.y, pbeg = blockIdx.y * per, pend = min(P, pbeg + per);
     float s = 0.f;
     if (col < ncols) {
-        int p = pg;
-        for (; p + 7 * 32 < P; p += 8 * 32) {   // 8 independent loads in flight (the pass is latency-bound)
+        int p = pbeg + pg;
+        for (; p + 7 * 32 < pend; p += 8 * 32) {   // 8 independent loads in flight (the pass is latency-bound)
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u * 32) * pstride + col];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; p < P; p += 32) s += part[(size_t)p * pstride + col];
+        for (; p < pend; p += 32) s += part[(size_t)p * pstride + col];
     }
     red[pg][cg] = s;
     __syncthreads();
@@ -148,7 +151,8 @@ static __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const floa
         for (int i = 0; i < 32; ++i) t += red[i][cg];
         const int k = col / d, c = col - k * d;
         float* out = k == 0 ? out0 : (k == 1 ? out1 : out2);
-        out[c] = accumulate ? out[c] + t : t;
+        if (gridDim.y > 1) atomicAdd(out + c, t);
+        else out[c] = accumulate ? out[c] + t : t;
     }
 }
 

@@ -306,7 +306,9 @@ extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat,
 #undef LN_BWD_D
     const int P = ln_grid(rows);
     const int ncols = dbias ? 3 * d : 2 * d;
-    colsum_finalize_kernel<<<ceil_div(ncols, 32), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
+    // the partial rows are split between 4 workgroups per column group (atomic adds): 3.806 vs 3.830 ms per step
+    static const int fsplit = getenv("ASR_LN_FSPLIT") ? atoi(getenv("ASR_LN_FSPLIT")) : 4;
+    colsum_finalize_kernel<<<dim3(ceil_div(ncols, 32), P >= 256 * fsplit ? fsplit : 1), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
     ASR_CHECK_LAUNCH("asr_add_ln_bwd");
     return ASR_OK;
 }

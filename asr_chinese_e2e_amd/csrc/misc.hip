@@ -354,7 +354,7 @@ static int colsum_impl(void* x, const void* a, float* out, void* ws, size_t ws_b
     if (dtype == ASR_F32) colsum_partial_kernel<float, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((float*)x, (const float*)a, (float*)ws, rows, cols, ld, slots);
     else if (dtype == ASR_BF16) colsum_partial_kernel<bf16_t, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((bf16_t*)x, (const bf16_t*)a, (float*)ws, rows, cols, ld, slots);
     else ASR_FAIL(ASR_EDTYPE, "%s: dtype %d", name, dtype);
-    if (want_sum) colsum_finalize_kernel<<<ceil_div(cols, 32), 1024, 0, st>>>((const float*)ws, slots, (size_t)cols, cols, cols, out, nullptr, nullptr, accumulate);
+    if (want_sum) colsum_finalize_kernel<<<dim3(ceil_div(cols, 32), accumulate && slots >= 1024 ? 4 : 1), 1024, 0, st>>>((const float*)ws, slots, (size_t)cols, cols, cols, out, nullptr, nullptr, accumulate);
     ASR_CHECK_LAUNCH(name);
     return ASR_OK;
 }
