@@ -705,16 +705,24 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
     const size_t stage_step = (size_t)SR * (is_y ? ldy : ldx);   // elements per stage (wave-uniform)
     const bool ragged = ((mend - mbeg) % SR) != 0;
     int it = 0, it_slot = 0;   // next stage to issue
+    // rows past the end of the range read the zero page: only the last stage can be partial, and the pointers
+    // are redirected once, when the cursor reaches it (a uniform branch per stage instead of selects per DMA)
+    auto fix_last = [&]() {
+        if (ragged && it == nsteps - 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[j] = (mbeg + it * SR + prow[j] < mend) ? cur[j] : (const bf16_t*)zero_page;
+        }
+    };
+    fix_last();
     auto dma = [&](int j) {
-        const void* q = cur[j];
-        if (ragged && it == nsteps - 1) q = (mbeg + it * SR + prow[j] < mend) ? q : zero_page;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)q, (lds_void_t*)(smem_t + it_slot * SBYTES + (w * 8 + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)cur[j], (lds_void_t*)(smem_t + it_slot * SBYTES + (w * 8 + j) * 1024), 16, 0, 0);
     };
     auto advance = [&]() {
         ++it;
         it_slot = it_slot == TRING - 1 ? 0 : it_slot + 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) cur[j] += stage_step;
+        fix_last();
     };
 
     f32x16 acc[2][2];  // [ni][ki]
