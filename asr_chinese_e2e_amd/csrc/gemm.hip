@@ -492,12 +492,17 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
                         store4<bf16_t>((bf16_t*)(epi + (m2 * 32 + r) * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
                     }
             __builtin_amdgcn_wave_barrier();
+            u32x4 v[4 * RM];   // all LDS reads first: with the read inside the bounds test each store waited for its own read
 #pragma unroll
             for (int q = 0; q < 4 * RM; ++q) {
                 const int row = q * 8 + srow, ch = lane & 7;
-                const u32x4 v = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                v[q] = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 4 * RM; ++q) {
+                const int row = q * 8 + srow, ch = lane & 7;
                 const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
-                if (m < M && n + 8 <= N) *(u32x4*)(C + (size_t)m * ldc + n) = v;
+                if (m < M && n + 8 <= N) *(u32x4*)(C + (size_t)m * ldc + n) = v[q];
             }
             __builtin_amdgcn_wave_barrier();
         }
