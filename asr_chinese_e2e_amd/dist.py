@@ -41,14 +41,17 @@ def init(backend=None):
     return rank, world
 
 
-def make_buckets(block_ranges, numel, bucket_elems):
+def make_buckets(block_ranges, numel, bucket_elems, force_cuts=()):
     """Contiguous (start, end) slices of a flat buffer, built from the END backwards (the order in
-    which backward completes gradients), cut only at block starts.  Covers [0, numel) exactly."""
+    which backward completes gradients), cut only at block starts.  Covers [0, numel) exactly.
+    force_cuts: offsets (block starts) where a bucket must begin whatever its size - used to keep
+    the LAST bucket, whose all-reduce nothing overlaps, small."""
     starts = sorted({s for s, _ in block_ranges} | {0})
+    force = {int(o) for o in force_cuts}
+    assert force <= set(starts), "forced cuts must be block starts"
     buckets, end = [], numel
-    cur = numel
     for s in reversed(starts):
-        if end - s >= bucket_elems or s == 0:
+        if end - s >= bucket_elems or s == 0 or (s in force and s < end):
             buckets.append((s, end))
             end = s
     assert buckets and buckets[-1][0] == 0 and sum(e - s for s, e in buckets) == numel
@@ -58,10 +61,10 @@ def make_buckets(block_ranges, numel, bucket_elems):
 class GradBucketer:
     """All-reduces `flat_g` bucket by bucket as `ready(offset)` marks move down."""
 
-    def __init__(self, flat_g, block_ranges, bucket_bytes=32 << 20, group=None):
+    def __init__(self, flat_g, block_ranges, bucket_bytes=32 << 20, group=None, force_cuts=()):
         self.g = flat_g
         self.group = group
-        self.buckets = make_buckets(block_ranges, flat_g.numel(), max(1, bucket_bytes // flat_g.element_size()))
+        self.buckets = make_buckets(block_ranges, flat_g.numel(), max(1, bucket_bytes // flat_g.element_size()), force_cuts)
         self.cuda = flat_g.is_cuda
         # NORMAL priority: a high-priority HIP stream (priority=-1) next to the two compute streams
         # doubled the step time on MI355X / ROCm 7 (11.0 vs 5.2 ms, measured with one rank)
@@ -113,7 +116,11 @@ class DataParallel:
         flat = model._flat
         dist.broadcast(flat.p, src=0)          # identical replicas
         flat.refresh_lowp()
-        self.bucketer = GradBucketer(flat.g, flat.block_range, bucket_bytes)
+        # The all-reduce of the last bucket (lowest offsets = first encoder layer + input projection) starts when
+        # backward ends and is fully exposed: cut it at the feed-forward block of encoder layer 0, whose gradients
+        # are final one block earlier (the engine raises a mark there), so only ~4 MB remain for the very end.
+        tail = eng.tail_mark_name()
+        self.bucketer = GradBucketer(flat.g, flat.block_range, bucket_bytes, force_cuts=[flat.index[tail][0]] if tail else ())
         eng.grad_ready = self.bucketer.ready
 
     def _global_count(self, n_valid):

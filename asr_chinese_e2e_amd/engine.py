@@ -274,6 +274,10 @@ class Engine:
             streams = [torch.cuda.current_stream()] + ([self.side] if self.overlap_wgrad else [])
             self.grad_ready(self.flat.index[name][0], streams)
 
+    def tail_mark_name(self):
+        """First tensor of the block that encoder_bwd marks final in the middle of layer 0 (see dist.DataParallel)."""
+        return "encoder.layer_stack.0.pos_ffn.w_1.weight"
+
     def _event(self):
         if torch.cuda.is_current_stream_capturing():      # events recorded in a capture belong to that graph
             return torch.cuda.Event()
@@ -442,6 +446,8 @@ class Engine:
             if i == 0 and self.group_wgrad == "hybrid":      # nothing left to hide a whole layer's launch behind
                 self._block_flush = True
             dx, dz = self._ffn_block_bwd(ffn, c2, dy, dy2)
+            if i == 0:      # finer mark inside the last layer: its feed-forward gradients can leave while attention runs
+                self._ready(self.tail_mark_name())
             dx, dz = self._attn_block_bwd(mha, c1, dx, dz)
             dy, dy2 = dx, dz
             self._ready(f"encoder.layer_stack.{i}.slf_attn.w_qs.weight")

@@ -120,6 +120,11 @@ def pmc_traffic(family):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that write to file descriptor 1 (RCCL prints a
+    # version banner when its first communicator is created) are sent to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -225,7 +230,8 @@ def main():
                                               "share_of_step": v["total_ms"] / n_inst / (1e3 * dt / args.steps)} for k, v in fam.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

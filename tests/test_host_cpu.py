@@ -170,6 +170,12 @@ def test_flat_layout_and_buckets():
         bk = make_buckets(f.block_range, f.numel, max(1, nbytes // 4))
         assert bk[-1][0] == 0 and bk[0][1] == f.numel
         assert all(bk[i][0] == bk[i + 1][1] for i in range(len(bk) - 1))      # contiguous, descending
+    # a forced cut (the data-parallel tail: dist.DataParallel) starts a bucket at that block whatever the bucket size
+    cut = f.index["f.w_1.weight"][0]
+    bk = make_buckets(f.block_range, f.numel, 1 << 30, force_cuts=[cut])
+    assert [b[0] for b in bk] == [cut, 0] and bk[0][1] == f.numel and bk[1][1] == cut
+    with pytest.raises(AssertionError):
+        make_buckets(f.block_range, f.numel, 1 << 30, force_cuts=[cut + 1])      # not a block start
 
 
 def test_bucketed_batches_and_wav_reader(tmp_path):
