@@ -168,16 +168,27 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict
     }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* __restrict__ logits, const int32_t* __restrict__ in_len,
+// WRITE: the wave that holds the row also writes scale * softmax(row) to dlogits (zeros for padded frames) - the
+// bulk of the CTC gradient, which does not depend on the lattice; ctc_label_fix_kernel later corrects the
+// (at most L + 1) classes that occur in the label sequence.  One pass over the logits less than with a
+// separate gradient kernel (270 instead of 406 MB at config 2).  dlogits may alias logits (no __restrict__:
+// the gathers below must stay in front of the stores).
+template <int NV, bool WRITE>
+__global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* logits, const int32_t* __restrict__ in_len,
                                                                   const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
                                                                   double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int Lmax,
-                                                                  int W, int blank) {
+                                                                  int W, int blank, bf16_t* dlogits, float scale) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_, nvec = V >> 3;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
         const int b = row / T_, t = row - b * T_;
-        if (t >= in_len[b]) continue;
+        if (t >= in_len[b]) {
+            if (WRITE) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                for (int i = lane; i < nvec; i += 64) *(u32x4*)(dlogits + (size_t)row * V + (size_t)i * 8) = z;
+            }
+            continue;
+        }
         const bf16_t* x = logits + (size_t)row * V;
         u32x4 xv[NV];
         wave_row_load<NV>(x, nvec, lane, xv);
@@ -192,6 +203,21 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* 
         const float xb = (float)x[blank];
         const float lse = wave_row_lse_regs<NV>(xv, nvec, lane);
         if (lane == 0) lse_out[row] = lse;
+        if (WRITE) {
+            bf16_t* dl = dlogits + (size_t)row * V;
+            const float lb = lse * LOG2E;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = lane + 64 * k;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[2 * j] = scale * __builtin_amdgcn_exp2f(fmaf(bf16_lo(xv[k][j]), LOG2E, -lb));
+                    v[2 * j + 1] = scale * __builtin_amdgcn_exp2f(fmaf(bf16_hi(xv[k][j]), LOG2E, -lb));
+                }
+                if (i < nvec) store8<bf16_t>(dl + (size_t)i * 8, v);
+            }
+        }
         double* out = lp + (size_t)row * 2 * W;
         const double yb = exp((double)(xb - lse));   // y_t(blank): linear domain, fp64
 #pragma unroll
@@ -598,6 +624,73 @@ __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const bf16_t* __rest
     }
 }
 
+// Second half of the split gradient: the row already holds scale * softmax (ctc_lse_gather_rows_kernel<.., true>);
+// one wave per frame subtracts the posterior mass of the classes that occur in the label sequence by
+// overwriting those few elements, and zeroes the rows of infeasible utterances (nll = +inf).
+__global__ __launch_bounds__(256) void ctc_label_fix_kernel(bf16_t* __restrict__ dlogits, const double* __restrict__ lp, const double* __restrict__ alpha,
+                                                            const double* __restrict__ beta, const int32_t* __restrict__ in_len,
+                                                            const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
+                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank, float scale) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rows = B * T_, nvec = V >> 3;
+    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+        const int b = row / T_, t = row - b * T_;
+        if (t >= in_len[b]) continue;           // already zero
+        bf16_t* dl = dlogits + (size_t)row * V;
+        if (nll_raw[b] == INFINITY) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int i = lane; i < nvec; i += 64) *(u32x4*)(dl + (size_t)i * 8) = z;
+            continue;
+        }
+        const int L = lab_len[b];
+        // posterior of a state at this frame, up to a per-frame constant: alpha * beta / y; normalising over the
+        // states is exact (see ctc_grad_rows_kernel)
+        const size_t o = (size_t)row * 2 * W;
+        double pb = 0.0, pl[4], yl[4];
+        int lab[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + 64 * j;
+            pl[j] = 0.0;
+            yl[j] = 0.0;
+            lab[j] = -1;
+            if (i <= L && i < W) {
+                const double yb = lp[o + i];
+                pb += yb > 0.0 ? alpha[o + i] * beta[o + i] / yb : 0.0;
+                if (i < L) {
+                    yl[j] = lp[o + W + i];
+                    pl[j] = yl[j] > 0.0 ? alpha[o + W + i] * beta[o + W + i] / yl[j] : 0.0;
+                    lab[j] = labels[(size_t)b * Lmax + i];
+                }
+            }
+        }
+        double sum = pb + pl[0] + pl[1] + pl[2] + pl[3];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += __shfl_xor(sum, off, 64);
+            pb += __shfl_xor(pb, off, 64);
+        }
+        const double inv = sum > 0.0 ? 1.0 / sum : 0.0;
+        float occ[4] = {0.f, 0.f, 0.f, 0.f};   // occupancy of each label's class = sum over the positions that carry the same label
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (64 * jj >= L) break;
+            const int cnt = min(64, L - 64 * jj);
+            const float pj_all = (float)(pl[jj] * inv);
+            for (int q = 0; q < cnt; ++q) {
+                const int lq = __shfl(lab[jj], q, 64);
+                const float pq = __shfl(pj_all, q, 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) occ[j] += (lab[j] == lq) ? pq : 0.f;
+            }
+        }
+        if (lane == 0) dl[blank] = (bf16_t)(scale * ((float)lp[o] - (float)(pb * inv)));   // every blank state has the same y
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lab[j] >= 0) dl[lab[j]] = (bf16_t)(scale * ((float)yl[j] - occ[j]));       // positions with equal labels write equal values
+    }
+}
+
 // ---------------------------------------------------------------------------------- xent
 template <typename T>
 __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits, const int32_t* __restrict__ gold, const float* __restrict__ n_valid,
@@ -709,6 +802,7 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     if (g1 > 4096) g1 = 4096;
     // bf16 rows of whole 16-byte vectors that fit a wave's registers take the row-in-registers kernels
     const int need = ceil_div(V / 8, 64);
+    static const int ctc_split = getenv("ASR_CTC_SPLIT") ? atoi(getenv("ASR_CTC_SPLIT")) : 1;
     const bool rows_path = dtype == ASR_BF16 && V % 8 == 0 && need <= 16 && ((uintptr_t)logits % 16) == 0 && (!dlogits || ((uintptr_t)dlogits % 16) == 0);
 #define ROWS_DISPATCH(CALL)           \
     do {                              \
@@ -720,9 +814,17 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
         else { CALL(16); }            \
     } while (0)
     if (rows_path) {
-#define K1(NV) ctc_lse_gather_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank)
-        ROWS_DISPATCH(K1);
+        // with a gradient: the softmax part of it is written by the same wave that reduces the row (one pass over
+        // the logits less); ASR_CTC_SPLIT=0 keeps the separate gradient kernel (A/B runs)
+        if (dlogits && ctc_split) {
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, (bf16_t*)dlogits, grad_scale)
+            ROWS_DISPATCH(K1);
 #undef K1
+        } else {
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, nullptr, 0.f)
+            ROWS_DISPATCH(K1);
+#undef K1
+        }
     } else if (dtype == ASR_F32) ctc_lse_gather_kernel<float><<<g1, 256, 0, st>>>((const float*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
     else ctc_lse_gather_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
 #define AB(N) ctc_alpha_beta_kernel<N><<<B, 128, 0, st>>>(lp, alpha, beta, in_len, labels, lab_len, nll, nll_raw, T, Lmax, blank, zero_infinity)
@@ -733,7 +835,9 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
 #undef AB
     if (dlogits) {
         int g3 = rows < 2048 ? rows : 2048;
-        if (rows_path) {
+        if (rows_path && ctc_split) {
+            ctc_label_fix_kernel<<<g1, 256, 0, st>>>((bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
+        } else if (rows_path) {
 #define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale)
             ROWS_DISPATCH(K3);
 #undef K3

@@ -16,4 +16,4 @@ e0.record()
 for _ in range(20): K.ctc_fwd_bwd(x, il, lab, ll, ws, dlogits=dl)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 20 * 1e3
-print(f"ctc fwd+bwd (3 kernels) {t:.1f} us  {3 * x.numel() * 2 / t / 1e6:.2f} TB/s algorithmic")
+print(f"ctc fwd+bwd (3 launches) {t:.1f} us  {3 * x.numel() * 2 / t / 1e6:.2f} TB/s algorithmic")
