@@ -244,15 +244,19 @@ class Engine:
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
         self.overlap_wgrad = True
-        # ASR_WGRAD_GROUP: "0" (default) one weight-gradient launch per projection, as soon as its dY exists;
-        # "layer" / "block" / "hybrid": collect them and launch one grouped GEMM (asr_gemm_tn_grouped_bf16) per
-        # layer / per attention or feed-forward block.  The grouped kernel is 1.6x faster alone (98 vs 160 us
+        # ASR_WGRAD_GROUP: "decoder" (default): the seven weight gradients of a DECODER layer (self-attention, cross
+        # attention incl. the K|V projection of all encoder frames, feed-forward) go out as ONE grouped GEMM
+        # (asr_gemm_tn_grouped_bf16) - the decoder's main stream is a chain of small launches (B*To rows) that
+        # leaves the GPU to the side stream: joint config 6.19 -> 6.02 ms; the ENCODER keeps one launch per
+        # projection, as soon as its dY exists.  "0": never group; "layer" / "block" / "hybrid": group everywhere,
+        # per layer / per attention or feed-forward block.  The grouped kernel is 1.6x faster alone (98 vs 160 us
         # per config-2 layer) but one 100-us launch filling every CU overlaps worse with the main stream than
         # four short ones spread over the layer: step 3.84 (layer) / 3.96 (block) vs 3.79 ms, joint 6.27 vs 6.16.
-        self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "0")
+        self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "decoder")
         self.group_wgrad = None if self.group_wgrad == "0" else self.group_wgrad
         self._pending = []
         self._block_flush = self.group_wgrad == "block"
+        self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
         # dropout (reference default 0.1; sites: transformer_official.py:175, 306; attention.py:59, 83;
         # module.py:73): masks are regenerated in backward from (step seed, site id), never stored
         self.drop_p = float(getattr(cfg, "dropout", 0.0))
@@ -316,7 +320,7 @@ class Engine:
     def _wgrad(self, lin, dy, x, bias_from=None):
         """lin.gw += dy^T x (and lin.gb += colsum(bias_from)) on the side stream."""
         fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
-        if self.group_wgrad and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
+        if self.group_wgrad and (self.group_wgrad != "decoder" or self._in_decoder) and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
                 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
             self._pending.append((dy, x, lin.gw, lin.gb if fused else None))     # launched by flush_wgrads (end of the layer)
             return
@@ -499,6 +503,7 @@ class Engine:
 
     def decoder_bwd(self, cache, dpred, d_enc):
         """dpred (B*To, V); accumulates the encoder-output gradient into d_enc (B*T, d) in place."""
+        self._in_decoder = True
         self._wgrad(self.prj, dpred, cache["x_last"])
         dy, dy2 = self.prj.dgrad(dpred), None
         for i in reversed(range(self.L)):
@@ -511,6 +516,7 @@ class Engine:
             self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
         dx = dy + dy2  # gradient wrt the embedding output
         K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1])
+        self._in_decoder = False
         self._ready("decoder.tgt_word_emb.weight")
         if self.use_ctc:
             self._ready("ctc_lo.weight")      # final since ctc_fwd_bwd, which ran before this function
