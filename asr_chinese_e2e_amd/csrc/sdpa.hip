@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 3) void sdpa_bwd_dq_bf16_kernel(const bf16_t* 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(st[i], sc2, -lse2));
-                st[i] = p * (dp[i] - dl) * scale;  // dS^T
+                st[i] = p * (dp[i] - dl);  // dS^T / scale: the factor is applied once, when dQ is stored
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, 3) void sdpa_bwd_dq_bf16_kernel(const bf16_t* 
             }
         }
     }
-    store_rows_T(acc, 1.f, dq + (size_t)b * Tq * ldq + h * DK, ldq, q0, Tq, lane);
+    store_rows_T(acc, scale, dq + (size_t)b * Tq * ldq + h * DK, ldq, q0, Tq, lane);
 }
 
 // ---------------------------------------------------------------- backward: dK, dV
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t*
                         keepf = drop_keep_at(el, dseed, dthr) ? dscale : 0.f;
                     }
                     st[i] = p * keepf;                               // dropped probabilities feed dV
-                    ds[i] = p * (dp[i] * keepf - d4[e]) * scale;
+                    ds[i] = p * (dp[i] * keepf - d4[e]);             // dS / scale: applied once, when dK is stored
                 }
             }
 #pragma unroll
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t*
             }
         }
     }
-    store_rows_T(dka, 1.f, dk_ + (size_t)b * Tk * ldk + h * DK, ldk, kk0, Tk, lane);
+    store_rows_T(dka, scale, dk_ + (size_t)b * Tk * ldk + h * DK, ldk, kk0, Tk, lane);
     store_rows_T(dva, 1.f, dv + (size_t)b * Tk * ldv + h * DK, ldv, kk0, Tk, lane);
 }
 
