@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="ctc", choices=["ctc", "joint"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=500)
