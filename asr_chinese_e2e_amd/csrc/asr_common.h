@@ -47,6 +47,14 @@ template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
     f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     return r;
 }
+// Non-temporal ("nt") store for LARGE outputs that the next kernel will not find in L2 anyway: a plain store leaves
+// the lines dirty in the XCD's L2, and the write-back of everything still dirty is serialised at the END of the kernel
+// (the eight L2s are not coherent with each other, so a kernel's results must reach memory before the next kernel
+// starts).  Used by the NT GEMM store tail (fc 17.0 -> 15.3 us; step -1.4 % on one box, -0.1 % on another, never
+// worse).  NOT used for LayerNorm / CTC rows (faster alone, 12.6 -> 11.4 us, but the step gets 0.7 % slower on
+// some boxes: their consumer then misses L2; the CTC softmax rows, 135 MB: 110 -> 104 us alone, step unchanged) and
+// never for 8-byte pieces (attention outputs: 36 -> 49 us).
+template <typename V> __device__ __forceinline__ void stream_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
             for (int q = 0; q < 4 * RM; ++q) {
                 const int row = q * 8 + srow, ch = lane & 7;
                 const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
-                if (m < M && n + 8 <= N) *(u32x4*)(C + (size_t)m * ldc + n) = v[q];
+                if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
             }
             __builtin_amdgcn_wave_barrier();
         }
