@@ -30,6 +30,14 @@ class TnProblem(ctypes.Structure):
 
 TN_GROUP_MAX = 8
 
+
+class LnReduceItem(ctypes.Structure):
+    """asr_ln_reduce_item of include/asr_hip.h."""
+    _fields_ = [("ws", P), ("dgamma", P), ("dbeta", P), ("dbias", P), ("rows", I)]
+
+
+LN_REDUCE_MAX = 16
+
 # name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
 SIGNATURES = {
     "asr_abi_version": (I, []),
@@ -37,6 +45,7 @@ SIGNATURES = {
     "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, U, I, I, P]),
     "asr_add_ln_bwd_workspace_bytes": (Z, [I, I]),
     "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, F, U, I, I, P]),
+    "asr_add_ln_bwd_reduce_batched": (I, [P, I, I, P]),
     "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
     "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
     "asr_dropout_mask": (I, [P, I, I, F, U, P]),

@@ -288,7 +288,7 @@ extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat,
                               const float* gamma, const int32_t* lens, void* dz, void* dx, float* dgamma,
                               float* dbeta, float* dbias, void* ws, size_t ws_bytes, int B, int T,
                               int d, float drop_p, uint32_t drop_seed, int drop_mode, int dtype, void* stream) {
-    if (!dy || !xhat || !rstd || !gamma || !dz || !dgamma || !dbeta || !ws) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: null pointer");
+    if (!dy || !xhat || !rstd || !gamma || !dz || !ws || (!dgamma != !dbeta)) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: null pointer");
     if (B <= 0 || T <= 0 || d <= 0 || d > 2048) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd: bad shape B=%d T=%d d=%d", B, T, d);
     const int rows = B * T;
     if (ws_bytes < asr_add_ln_bwd_workspace_bytes(rows, d)) ASR_FAIL(ASR_EWORKSPACE, "asr_add_ln_bwd: workspace %zu < %zu", ws_bytes, asr_add_ln_bwd_workspace_bytes(rows, d));
@@ -306,9 +306,76 @@ extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat,
 #undef LN_BWD_D
     const int P = ln_grid(rows);
     const int ncols = dbias ? 3 * d : 2 * d;
-    // the partial rows are split between 4 workgroups per column group (atomic adds): 3.806 vs 3.830 ms per step
-    static const int fsplit = getenv("ASR_LN_FSPLIT") ? atoi(getenv("ASR_LN_FSPLIT")) : 4;
-    colsum_finalize_kernel<<<dim3(ceil_div(ncols, 32), P >= 256 * fsplit ? fsplit : 1), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
+    if (dgamma) {   // dgamma == dbeta == NULL: the partial sums stay in ws for asr_add_ln_bwd_reduce_batched
+        // the partial rows are split between 4 workgroups per column group (atomic adds): 3.806 vs 3.830 ms per step
+        static const int fsplit = getenv("ASR_LN_FSPLIT") ? atoi(getenv("ASR_LN_FSPLIT")) : 4;
+        colsum_finalize_kernel<<<dim3(ceil_div(ncols, 32), P >= 256 * fsplit ? fsplit : 1), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
+    }
     ASR_CHECK_LAUNCH("asr_add_ln_bwd");
+    return ASR_OK;
+}
+
+// One launch for the parameter-gradient reductions of several LayerNorm sites (blockIdx.z = site): every launch
+// costs ~4-5 us of dispatch and drain on top of its work, and backward has 13 of these reductions per step.
+namespace {
+struct LnReduceBatch {
+    const float* part[ASR_LN_REDUCE_MAX];
+    float* dgamma[ASR_LN_REDUCE_MAX];
+    float* dbeta[ASR_LN_REDUCE_MAX];
+    float* dbias[ASR_LN_REDUCE_MAX];
+    int P[ASR_LN_REDUCE_MAX];
+};
+__global__ __launch_bounds__(1024) void ln_reduce_batched_kernel(const LnReduceBatch bt, int d) {
+    __shared__ float red[32][33];
+    const int it = blockIdx.z, P = bt.P[it];
+    const float* __restrict__ part = bt.part[it];
+    const int ncols = bt.dbias[it] ? 3 * d : 2 * d;
+    const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cg;
+    const int ns = P >= 1024 ? (int)gridDim.y : 1;   // few partial rows: one workgroup per column group, plain (deterministic) adds
+    if (blockIdx.x * 32 >= ncols || (int)blockIdx.y >= ns) return;
+    const int per = (P + ns - 1) / ns, pbeg = blockIdx.y * per, pend = min(P, pbeg + per);
+    const size_t pstride = (size_t)3 * d;
+    float s = 0.f;
+    if (col < ncols) {
+        int p = pbeg + pg;
+        for (; p + 7 * 32 < pend; p += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u * 32) * pstride + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < pend; p += 32) s += part[(size_t)p * pstride + col];
+    }
+    red[pg][cg] = s;
+    __syncthreads();
+    if (pg == 0 && col < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][cg];
+        const int k = col / d, c = col - k * d;
+        float* out = k == 0 ? bt.dgamma[it] : (k == 1 ? bt.dbeta[it] : bt.dbias[it]);
+        if (ns > 1) atomicAdd(out + c, t);
+        else out[c] += t;
+    }
+}
+}  // namespace
+
+extern "C" int asr_add_ln_bwd_reduce_batched(const asr_ln_reduce_item* items, int n, int d, void* stream) {
+    if (!items || n <= 0 || n > ASR_LN_REDUCE_MAX) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd_reduce_batched: 1..%d items per call (got %d)", ASR_LN_REDUCE_MAX, n);
+    if (d <= 0 || d > 2048) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd_reduce_batched: bad d=%d", d);
+    LnReduceBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].ws || !items[i].dgamma || !items[i].dbeta || items[i].rows <= 0) ASR_FAIL(ASR_EINVAL, "asr_add_ln_bwd_reduce_batched: bad item %d", i);
+        bt.part[i] = (const float*)items[i].ws;
+        bt.dgamma[i] = items[i].dgamma;
+        bt.dbeta[i] = items[i].dbeta;
+        bt.dbias[i] = items[i].dbias;
+        bt.P[i] = ln_grid(items[i].rows);
+    }
+    ln_reduce_batched_kernel<<<dim3(ceil_div(3 * d, 32), 4, n), 1024, 0, (hipStream_t)stream>>>(bt, d);
+    ASR_CHECK_LAUNCH("asr_add_ln_bwd_reduce_batched");
     return ASR_OK;
 }

@@ -255,6 +255,8 @@ class Engine:
         self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "decoder")
         self.group_wgrad = None if self.group_wgrad == "0" else self.group_wgrad
         self._pending = []
+        self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
+        self._ln_part, self._ln_pending = {}, []
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
         # dropout (reference default 0.1; sites: transformer_official.py:175, 306; attention.py:59, 83;
@@ -275,8 +277,30 @@ class Engine:
         on BOTH streams has run: the consumer (dist.GradBucketer) waits on events of the two."""
         self.flush_wgrads()
         if self.grad_ready is not None:
+            self.flush_ln_reduce()
             streams = [torch.cuda.current_stream()] + ([self.side] if self.overlap_wgrad else [])
             self.grad_ready(self.flat.index[name][0], streams)
+
+    def _ln_bwd(self, ln, dbias, dy, dy2, xhat, rstd, lens, B, T, **kw):
+        """Backward of residual + LayerNorm.  The reduction of the per-workgroup partial parameter gradients is not
+        launched per site: the partial sums go to a buffer owned by the site and ONE batched launch reduces all
+        pending sites (flush_ln_reduce: per layer when gradients are all-reduced as they become final, otherwise once
+        at the end of backward) - each of the 13 small launches cost ~5 us of dispatch and drain."""
+        if not self.batch_ln_reduce:
+            return K.add_ln_bwd(dy, dy2, xhat, rstd, ln.g, lens, ln.gg, ln.gb, dbias, B, T, self.ws, **kw)
+        d = xhat.shape[-1]
+        need = K.add_ln_bwd_workspace_bytes(B * T, d)
+        part = self._ln_part.get(id(ln))
+        if part is None or part.numel() < need:
+            part = self._ln_part[id(ln)] = torch.empty(need, dtype=torch.uint8, device=xhat.device)
+        out = K.add_ln_bwd(dy, dy2, xhat, rstd, ln.g, lens, ln.gg, ln.gb, dbias, B, T, self.ws, partials=part, **kw)
+        self._ln_pending.append((part, ln.gg, ln.gb, dbias, B * T))
+        return out
+
+    def flush_ln_reduce(self):
+        if self._ln_pending:
+            items, self._ln_pending = self._ln_pending, []
+            K.add_ln_bwd_reduce_batched(items, self.d)
 
     def tail_mark_name(self):
         """First tensor of the block that encoder_bwd marks final in the middle of layer 0 (see dist.DataParallel)."""
@@ -379,8 +403,7 @@ class Engine:
         H, dk, hd = self.H, self.dk, self.H * self.dk
         B, Tq, Tk = c["dims"]
         pa, sa, pf, sf = c["drop"]
-        dz, dxg = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], m.ln.g, c["q_lens"], m.ln.gg, m.ln.gb, m.fc.gb, B, Tq, self.ws,
-                               drop_p=pf, drop_seed=sf, drop_mode=1)
+        dz, dxg = self._ln_bwd(m.ln, m.fc.gb, dy, dy2, c["xhat"], c["rstd"], c["q_lens"], B, Tq, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(m.fc, dxg, c["ctx"])
         dctx = m.fc.dgrad(dxg)
         if not c["cross"]:
@@ -414,8 +437,7 @@ class Engine:
     def _ffn_block_bwd(self, f, c, dy, dy2):
         B, T = c["dims"]
         pf, sf = c["drop"]
-        dz, dxg = K.add_ln_bwd(dy, dy2, c["xhat"], c["rstd"], f.ln.g, c["lens"], f.ln.gg, f.ln.gb, f.w2.gb, B, T, self.ws,
-                               drop_p=pf, drop_seed=sf, drop_mode=1)
+        dz, dxg = self._ln_bwd(f.ln, f.w2.gb, dy, dy2, c["xhat"], c["rstd"], c["lens"], B, T, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(f.w2, dxg, c["h"])
         dh = f.w2.dgrad(dxg)
         fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
@@ -456,12 +478,12 @@ class Engine:
             dy, dy2 = dx, dz
             self._ready(f"encoder.layer_stack.{i}.slf_attn.w_qs.weight")
         p0, s0 = cache["drop"]
-        dz, _ = K.add_ln_bwd(dy, dy2, cache["xhat_in"], cache["rstd_in"], self.ln_in.g, None, self.ln_in.gg, self.ln_in.gb, self.lin_in.gb, B, T, self.ws,
-                             drop_p=p0, drop_seed=s0, drop_mode=2)
+        dz, _ = self._ln_bwd(self.ln_in, self.lin_in.gb, dy, dy2, cache["xhat_in"], cache["rstd_in"], None, B, T, drop_p=p0, drop_seed=s0, drop_mode=2)
         # the last weight gradient runs on the MAIN stream: the side stream is still busy with layer 0,
         # and a cross-stream hand-over costs ~20 us of latency that nothing would hide at this point
         self.lin_in.wgrad(dz, cache["x_in"])      # A/B: 8.50 vs 8.45 k utt/s
         self._block_flush = self.group_wgrad == "block"
+        self.flush_ln_reduce()
         self.join_side()
         self._ready("encoder.linear_in.weight")
 

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ASR_BF16, ASR_F32, ACT_NONE, ACT_RELU, TN_GROUP_MAX, TnProblem, check, lib
+from ._lib import ASR_BF16, ASR_F32, ACT_NONE, ACT_RELU, LN_REDUCE_MAX, TN_GROUP_MAX, LnReduceItem, TnProblem, check, lib
 
 _DT = {torch.float32: ASR_F32, torch.bfloat16: ASR_BF16}
 
@@ -133,9 +133,13 @@ def add_ln_fwd(x, res, gamma, beta, pe, lens, B, T, y=None, xhat=None, rstd=None
     return y, xhat, rstd
 
 
-def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws, dz=None, drop_p=0.0, drop_seed=0, drop_mode=0):
+def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws, dz=None, drop_p=0.0, drop_seed=0, drop_mode=0,
+               partials=None):
     """Returns (dz, dx): dz = gradient wrt the residual input; dx = gradient wrt x (the same tensor
-    unless pre-residual dropout is active, then dz * keep / (1-p))."""
+    unless pre-residual dropout is active, then dz * keep / (1-p)).
+    partials: a uint8 buffer of add_ln_bwd_workspace_bytes(B * T, d) that receives the per-workgroup partial sums of
+    the parameter gradients INSTEAD of their reduction into dgamma / dbeta / dbias; the caller reduces several
+    sites at once with add_ln_bwd_reduce_batched."""
     d = dy.shape[-1]
     assert dy.is_contiguous() and xhat.is_contiguous() and dy.numel() == B * T * d == xhat.numel()
     assert xhat.dtype == dy.dtype and (dy2 is None or (dy2.dtype == dy.dtype and dy2.is_contiguous() and dy2.numel() == dy.numel()))
@@ -145,11 +149,32 @@ def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws,
     dz = torch.empty_like(dy) if dz is None else dz
     dx = torch.empty_like(dy) if (drop_p > 0 and drop_mode == 1) else None
     nbytes = lib.asr_add_ln_bwd_workspace_bytes(B * T, d)
-    w = ws.get(nbytes)
+    if partials is not None:
+        assert partials.dtype == torch.uint8 and partials.numel() >= nbytes
+        w, dgamma, dbeta = partials, None, None
+    else:
+        w = ws.get(nbytes)
     check(lib.asr_add_ln_bwd(_p(dy), _p(dy2), _p(xhat), _p(rstd), _p(gamma), _p(lens), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
                              _p(dbias), _p(w), w.numel(), B, T, d, float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_mode),
                              _dt(dy), _stream()), "asr_add_ln_bwd")
     return dz, (dx if dx is not None else dz)
+
+
+def add_ln_bwd_workspace_bytes(rows, d):
+    return lib.asr_add_ln_bwd_workspace_bytes(rows, d)
+
+
+def add_ln_bwd_reduce_batched(items, d):
+    """items: list of (partials, dgamma, dbeta, dbias or None, rows) left by add_ln_bwd(partials=...)."""
+    for i in range(0, len(items), LN_REDUCE_MAX):
+        chunk = items[i:i + LN_REDUCE_MAX]
+        arr = (LnReduceItem * len(chunk))()
+        for q, (part, dg, db, dbias, rows) in zip(arr, chunk):
+            _chk_f32(dg, db, dbias)
+            assert dg.numel() == d and db.numel() == d and (dbias is None or dbias.numel() == d)
+            assert part.numel() >= lib.asr_add_ln_bwd_workspace_bytes(rows, d)
+            q.ws, q.dgamma, q.dbeta, q.dbias, q.rows = _p(part), _p(dg), _p(db), _p(dbias), rows
+        check(lib.asr_add_ln_bwd_reduce_batched(ctypes.byref(arr), len(chunk), d, _stream()), "asr_add_ln_bwd_reduce_batched")
 
 
 # --------------------------------------------------------------------------------- attention

@@ -89,6 +89,19 @@ int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat, const floa
                    const float* gamma, const int32_t* lens, void* dz, void* dx, float* dgamma,
                    float* dbeta, float* dbias, void* ws, size_t ws_bytes, int B, int T, int d,
                    float drop_p, uint32_t drop_seed, int drop_mode, int dtype, void* stream);
+/* With dgamma == dbeta == NULL asr_add_ln_bwd leaves the per-workgroup partial sums of the parameter gradients in
+ * `ws` (which the caller then keeps); this call adds the partial sums of up to ASR_LN_REDUCE_MAX such sites into
+ * their dgamma / dbeta / dbias in ONE launch (the 13 LayerNorm sites of an encoder backward would otherwise cost
+ * 13 small launches).  `items` is a host array, read during the call; rows = B*T of the site's asr_add_ln_bwd. */
+#define ASR_LN_REDUCE_MAX 16
+typedef struct asr_ln_reduce_item {
+    const void* ws;
+    float* dgamma;
+    float* dbeta;
+    float* dbias; /* or NULL */
+    int rows;
+} asr_ln_reduce_item;
+int asr_add_ln_bwd_reduce_batched(const asr_ln_reduce_item* items, int n, int d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked scaled-dot-product attention, flash style (scores never materialised).

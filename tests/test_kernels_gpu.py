@@ -86,6 +86,37 @@ def test_add_ln(K, ws, dtype, d, use_res, use_pe, use_len):
     close(dbias, xr.grad.sum(0), rtol=gt["rtol"], atol=gt["atol"] * 4, what="ln dbias")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_add_ln_bwd_batched_reduce(K, ws, dtype):
+    """Parameter gradients of several LayerNorm sites reduced by ONE asr_add_ln_bwd_reduce_batched launch ==
+    the per-site reduction inside asr_add_ln_bwd: a small site (one workgroup per column group, plain adds), a
+    site with > 1024 partial rows (split + atomic adds), one without a bias gradient, accumulate semantics."""
+    d = 512
+    sites = [(2, 40, True), (8, 700, True), (3, 37, False)]
+    items, want = [], []
+    for i, (B, T, with_bias) in enumerate(sites):
+        g = torch.Generator().manual_seed(100 + i)
+        x = torch.randn(B * T, d, generator=g).to(dtype).to(DEV)
+        res = torch.randn(B * T, d, generator=g).to(dtype).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+        dy = torch.randn(B * T, d, generator=g).to(dtype).to(DEV)
+        y, xhat, rstd = K.add_ln_fwd(x, res, gamma, beta, None, None, B, T)
+        ref = [torch.full((d,), 0.5, device=DEV) for _ in range(3)]
+        K.add_ln_bwd(dy, None, xhat, rstd, gamma, None, ref[0], ref[1], ref[2] if with_bias else None, B, T, ws)
+        got = [torch.full((d,), 0.5, device=DEV) for _ in range(3)]
+        part = torch.empty(K.add_ln_bwd_workspace_bytes(B * T, d), dtype=torch.uint8, device=DEV)
+        dz, _ = K.add_ln_bwd(dy, None, xhat, rstd, gamma, None, got[0], got[1], got[2] if with_bias else None, B, T, ws, partials=part)
+        assert all(float((t - 0.5).abs().max()) == 0.0 for t in got)       # nothing reduced yet
+        items.append((part, got[0], got[1], got[2] if with_bias else None, B * T))
+        want.append((ref, got, with_bias))
+    K.add_ln_bwd_reduce_batched(items, d)
+    for ref, got, with_bias in want:
+        for k in range(3 if with_bias else 2):
+            close(got[k], ref[k], rtol=1e-5, atol=1e-4, what=f"batched LN reduce, vector {k}")
+        if not with_bias:
+            assert float((got[2] - 0.5).abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------ attention
 def sdpa_ref(q, k, v, klen, causal, window, scale):
     """q (B,Tq,H,dk) etc., fp64 dense reference with autograd."""
