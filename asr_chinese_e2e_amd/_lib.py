@@ -76,6 +76,7 @@ SIGNATURES = {
     "asr_gemm_tn_bf16": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "asr_gemm_tn_bias_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "asr_gemm_tn_grouped_bf16": (I, [P, I, I, P]),
+    "asr_transpose_batched_bf16": (I, [P, P, P, I, P]),
     "asr_cer": (I, [P, P, I, I, P, P, I, I, P, P, I, I, I, I, P, P]),
     "asr_logmel_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "asr_utt_norm_lfr_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),

@@ -323,6 +323,35 @@ extern "C" int asr_relu_fwd(void* x, size_t n, int dtype, void* stream) {
     return ASR_OK;
 }
 
+// Batched 2-D transposes inside one flat bf16 buffer: tile t of `tiles` = {element offset of the matrix,
+// rows N, cols K, (tile row << 16) | tile col}; dst[off + k * N + n] = src[off + n * K + k].
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int32_t* __restrict__ tiles) {
+    __shared__ bf16_t tile[64][66];
+    const int32_t* e = tiles + 4 * (size_t)blockIdx.x;
+    const size_t off = (size_t)(uint32_t)e[0];
+    const int N = e[1], K = e[2], r0 = (e[3] >> 16) * 64, c0 = (e[3] & 0xffff) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        if (r < N && c < K) tile[ty + 4 * i][tx] = src[off + (size_t)r * K + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (r < N && c < K) dst[off + (size_t)c * N + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+extern "C" int asr_transpose_batched_bf16(const void* src, void* dst, const int32_t* tiles, int ntiles, void* stream) {
+    if (!src || !dst || !tiles) ASR_FAIL(ASR_EINVAL, "asr_transpose_batched_bf16: null pointer");
+    if (ntiles <= 0) ASR_FAIL(ASR_EINVAL, "asr_transpose_batched_bf16: ntiles=%d", ntiles);
+    transpose_batched_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)dst, tiles);
+    ASR_CHECK_LAUNCH("asr_transpose_batched_bf16");
+    return ASR_OK;
+}
+
 extern "C" int asr_cast(const void* src, void* dst, size_t n, int sd, int dd, void* stream) {
     if (!src || !dst) ASR_FAIL(ASR_EINVAL, "asr_cast: null pointer");
     hipStream_t st = (hipStream_t)stream;

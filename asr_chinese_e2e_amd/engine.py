@@ -65,6 +65,7 @@ class FlatParams:
         z = lambda dt: torch.zeros(self.numel, dtype=dt, device=self.device)
         self.p, self.g, self.m, self.v = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
         self.lp = z(torch.bfloat16) if lowp else None
+        self.lpT = None      # transposed copies of the projection weights (engine.refresh_transposes), same offsets as lp
 
     def view(self, buf, name):
         off, shape = self.index[name]
@@ -102,6 +103,8 @@ class Linear:
         self.w32 = flat.span(flat.p, w_names[0], w_names[-1], (N, Kdim))
         self.gw = flat.span(flat.g, w_names[0], w_names[-1], (N, Kdim))
         self.wlp = flat.span(flat.lp, w_names[0], w_names[-1], (N, Kdim)) if flat.lp is not None else None
+        self.w_off = flat.index[w_names[0]][0]
+        self.wlpT = None     # (K, N) bf16 view of flat.lpT when the engine keeps transposed copies
         if b_names:
             self.b32 = flat.span(flat.p, b_names[0], b_names[-1], (N,))
             self.gb = flat.span(flat.g, b_names[0], b_names[-1], (N,))
@@ -116,6 +119,7 @@ class Linear:
         sub.wlp = self.wlp[lo:hi] if self.wlp is not None else None
         sub.b32 = self.b32[lo:hi] if self.b32 is not None else None
         sub.gb = self.gb[lo:hi] if self.gb is not None else None
+        sub.wlpT, sub.w_off = None, self.w_off + lo * self.K
         return sub
 
     # ---- forward
@@ -139,6 +143,11 @@ class Linear:
         """dx = dy W, or out += dy W when accumulate."""
         w = self.wlp if dy.dtype == torch.bfloat16 else self.w32
         flops = 2.0 * dy.shape[0] * self.N * self.K
+        if (self.wlpT is not None and not accumulate and dy.shape[0] >= 4096 and dy.dtype == torch.bfloat16 and self.N % 64 == 0
+                and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0):
+            # dX = dY W as an NT product with the transposed weight copy: own MFMA kernel instead of the library GEMM
+            out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
+            return K.gemm_nt(dy, self.wlpT, None, out, family="lib_gemm_dgrad")
         if accumulate:
             return K.timed("lib_gemm_dgrad", flops, lambda: out.addmm_(dy, w))
         if out is None:
@@ -237,6 +246,24 @@ class Engine:
         if use_ctc:
             self.ctc_lo = Linear(flat, ["ctc_lo.weight"], ["ctc_lo.bias"], vocab_size, d)
         self.grad_ready = None  # callback(offset): gradients at flat offsets >= offset are final
+        # Input gradients dX = dY W of the encoder projections run on the own persistent NT kernel, as NT products with
+        # transposed bf16 weight copies (one batched transpose launch per step on the side stream, idle during the forward
+        # pass), instead of the library GEMM: with the streaming store tail the own kernel is the faster one
+        # (step 3.505 -> 3.428 ms; before that change the two were at parity).  ASR_DGRAD_OWN=0: library GEMM.
+        self._tr_tiles = None
+        if os.environ.get("ASR_DGRAD_OWN", "1") != "0" and flat.lp is not None:
+            # encoder projections only: the decoder's B*To ~ 500 rows are better served by the library's small tiles
+            # (joint config 5.93 ms with its projections on the persistent kernel too, 5.74 with the library)
+            lins = [l for mha, ffn in self.enc for l in (mha.qkv, mha.fc, ffn.w1, ffn.w2)]
+            lins = [l for l in lins if l.N % 64 == 0 and l.K % 8 == 0]
+            flat.lpT = torch.zeros_like(flat.lp)
+            tiles = []
+            for l in lins:
+                l.wlpT = flat.lpT[l.w_off:l.w_off + l.N * l.K].view(l.K, l.N)
+                tiles += [[l.w_off, l.N, l.K, (r << 16) | c] for r in range((l.N + 63) // 64) for c in range((l.K + 63) // 64)]
+            self._tr_tiles = torch.tensor(tiles, dtype=torch.int32, device=flat.device)
+            self._tr_event = torch.cuda.Event()
+            self._tr_pending = False
         # Weight/bias gradients are off the critical path (only the optimizer reads them): they run
         # on a side stream, concurrently with the dgrad chain on the main stream, so the short,
         # latency-bound kernels of both chains fill each other's idle CUs.
@@ -312,6 +339,25 @@ class Engine:
         ev = self._events[self._ev_next]
         self._ev_next = (self._ev_next + 1) & 63
         return ev
+
+    def refresh_transposes(self):
+        """W^T copies for the own-kernel input gradients: one launch on the side stream, which is idle during the
+        forward pass; the backward pass waits for it (wait_transposes) before its first input-gradient GEMM."""
+        ev = self._event()
+        ev.record()
+        self.side.wait_event(ev)
+        K.STREAM_OVERRIDE = self._side_handle
+        try:
+            K.transpose_batched(self.flat.lp, self.flat.lpT, self._tr_tiles)
+        finally:
+            K.STREAM_OVERRIDE = None
+        self._tr_event.record(self.side)
+        self._tr_pending = True
+
+    def wait_transposes(self):
+        if self._tr_tiles is not None and self._tr_pending:
+            torch.cuda.current_stream().wait_event(self._tr_event)
+            self._tr_pending = False
 
     def join_side(self):
         """Main stream waits for every weight-gradient kernel issued so far."""
@@ -452,6 +498,8 @@ class Engine:
     def encoder_fwd(self, wave, wave_len, window=-1):
         """wave (B,T,F) in the compute dtype, wave_len (B) int32.  transformer_official.py:158-189."""
         B, T, F = wave.shape
+        if self._tr_tiles is not None and self.training:
+            self.refresh_transposes()
         x_in = wave.reshape(B * T, F)
         e0 = self.lin_in.fwd(x_in)
         p0, s0 = self._drop(1)             # dropout(LN(linear_in(x)) + PE)  (transformer_official.py:175-177)
@@ -466,6 +514,7 @@ class Engine:
     def encoder_bwd(self, cache, d_enc):
         B, T = cache["B"], cache["T"]
         dy, dy2 = d_enc, None
+        self.wait_transposes()
         for i in reversed(range(self.L)):
             mha, ffn = self.enc[i]
             c1, c2 = cache["layers"][i]
@@ -526,6 +575,7 @@ class Engine:
     def decoder_bwd(self, cache, dpred, d_enc):
         """dpred (B*To, V); accumulates the encoder-output gradient into d_enc (B*T, d) in place."""
         self._in_decoder = True
+        self.wait_transposes()
         self._wgrad(self.prj, dpred, cache["x_last"])
         dy, dy2 = self.prj.dgrad(dpred), None
         for i in reversed(range(self.L)):

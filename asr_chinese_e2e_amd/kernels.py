@@ -422,7 +422,14 @@ def gemm_nt_supported(M, N, K, lda, ldb, ldc):
     return K % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and ldc % 4 == 0
 
 
-def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None):
+def transpose_batched(src, dst, tiles):
+    """Transposed copies of the matrices listed in `tiles` (int32 (ntiles, 4), see include/asr_hip.h) from the flat
+    bf16 buffer src into dst (same offsets)."""
+    assert src.dtype == dst.dtype == torch.bfloat16 and src.numel() == dst.numel() and tiles.dtype == torch.int32 and tiles.is_contiguous()
+    check(lib.asr_transpose_batched_bf16(_p(src), _p(dst), _p(tiles), tiles.shape[0], _stream()), "asr_transpose_batched_bf16")
+
+
+def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None, family="gemm_nt"):
     """out (M,N) = act(a (M,K) @ w (N,K)^T + bias) (+ res); bf16 operands, MFMA kernel."""
     assert a.dtype == w.dtype == out.dtype == torch.bfloat16
     M, K = a.shape
@@ -431,7 +438,7 @@ def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None):
     _chk_f32(bias)
     if res is not None:
         assert res.dtype == torch.bfloat16 and res.shape == out.shape and res.stride() == out.stride()
-    timed("gemm_nt", 2.0 * M * N * K, lambda: check(
+    timed(family, 2.0 * M * N * K, lambda: check(
         lib.asr_gemm_nt_bf16(_p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), int(act),
                              _stream()), "asr_gemm_nt_bf16"))
     return out

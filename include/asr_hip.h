@@ -265,6 +265,11 @@ int asr_colsum(const void* x, float* out, void* ws, size_t ws_bytes, int rows, i
                int accumulate, int dtype, void* stream);
 /* dst (n) `dst_dtype` = src (n) `src_dtype`  (f32 <-> bf16 conversion / copy) */
 int asr_cast(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, void* stream);
+/* Transposed copies of many matrices that live in one flat bf16 buffer, one launch: for tile t,
+ * tiles[4t..4t+3] = {element offset of its matrix, rows N, cols K, (tile row << 16) | tile col} (64 x 64
+ * tiles); dst[off + k * N + n] = src[off + n * K + k].  Used for the W^T copies the input-gradient GEMMs
+ * (dX = dY W as an NT product, replacing autograd's mm backward of nn.Linear, attention.py:43-59, module.py:70-71) read. */
+int asr_transpose_batched_bf16(const void* src, void* dst, const int32_t* tiles, int ntiles, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimizer over the flat parameter / gradient buffers.
