@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
 ABI_VERSION = 2
 DROP_PRE, DROP_POST = 1, 2
 

@@ -332,7 +332,7 @@ template <int NW> struct PCfg {                    // NW waves as (NW/2) x 2; wa
 template <int ACT, int NW, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                                      bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                                     int tiles_n, int ntiles) {
+                                                                     int tiles_n, int ntiles, const bf16_t* __restrict__ mask) {
     using Cfg = PCfg<NW>;
     constexpr int MI = Cfg::MI, PPW = Cfg::PPW, RM = Cfg::RM, PEPI = Cfg::PEPI, PSTORES = Cfg::PSTORES;
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
@@ -493,10 +493,31 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
                     }
             __builtin_amdgcn_wave_barrier();
             u32x4 v[4 * RM];   // all LDS reads first: with the read inside the bounds test each store waited for its own read
+            u32x4 hm[4 * RM];  // ACT_RELU_MASK: the activations whose sign gates this gradient (ReLU backward in the store tail)
+            if (ACT == ASR_ACT_RELU_MASK) {
+#pragma unroll
+                for (int q = 0; q < 4 * RM; ++q) {
+                    const int row = q * 8 + srow, ch = lane & 7;
+                    const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    hm[q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4 * RM; ++q) {
                 const int row = q * 8 + srow, ch = lane & 7;
                 v[q] = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+            if (ACT == ASR_ACT_RELU_MASK) {
+#pragma unroll
+                for (int q = 0; q < 4 * RM; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // bf16 pair: keep where the activation is > 0 (not zero, sign clear)
+                        const uint32_t h = hm[q][e];
+                        const uint32_t lo = ((h & 0x7fffu) != 0u && !(h & 0x8000u)) ? 0x0000ffffu : 0u;
+                        const uint32_t hi = ((h & 0x7fff0000u) != 0u && !(h & 0x80000000u)) ? 0xffff0000u : 0u;
+                        v[q][e] &= lo | hi;
+                    }
             }
 #pragma unroll
             for (int q = 0; q < 4 * RM; ++q) {
@@ -518,7 +539,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
 }
 
 template <int ACT, int NW, int DBG = 0>
-static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st) {
+static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st,
+                              const bf16_t* mask = nullptr) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<ACT, NW, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
@@ -526,7 +548,7 @@ static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bia
     }
     const int t_n = ceil_div(N, PBN), t_m = ceil_div(M, PBM), ntiles = t_n * t_m;
     const int grid = ntiles < cu_count() ? ntiles : cu_count();
-    gemm_nt_persist_kernel<ACT, NW, DBG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles);
+    gemm_nt_persist_kernel<ACT, NW, DBG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask);
 }
 
 // ---------------------------------------------------------------------------------------- TN
@@ -1170,7 +1192,14 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     if (K % 8 || lda % 8 || ldb % 8 || ldc % 4 || lda < K || ldb < K || ldc < N) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: K, lda, ldb must be multiples of 8 and ldc of 4 (K=%d lda=%d ldb=%d ldc=%d)", K, lda, ldb, ldc);
     if ((((uintptr_t)A | (uintptr_t)W) % 16) || ((uintptr_t)C % 8) || (res && (uintptr_t)res % 8) || (bias && (uintptr_t)bias % 16)) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (act != ASR_ACT_RELU && act != ASR_ACT_NONE) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
+    if (act != ASR_ACT_RELU && act != ASR_ACT_NONE && act != ASR_ACT_RELU_MASK) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
+    if (act == ASR_ACT_RELU_MASK) {   // C = (A W^T + bias) where res > 0, else 0: persistent kernel only
+        if (!res || (uintptr_t)res % 16 || K % DBK || K < 2 * PBK || N % 8 || ldc % 8 || ((uintptr_t)C % 16))
+            ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: ASR_ACT_RELU_MASK needs the mask in `res`, K %% 64 == 0, K >= 128, N, ldc %% 8 == 0 and 16-byte aligned pointers");
+        launch_nt_persist<ASR_ACT_RELU_MASK, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+        ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
+        return ASR_OK;
+    }
     if (K % DBK == 0 && !res && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {   // LDS-DMA kernel: whole 64-wide k-tiles, 16-B row stores
         static const int dbg = getenv("ASR_GEMM_DBG") ? atoi(getenv("ASR_GEMM_DBG")) : 0;
         static const int cfg = getenv("ASR_GEMM_CFG") ? atoi(getenv("ASR_GEMM_CFG")) : 0;   // tuning experiments

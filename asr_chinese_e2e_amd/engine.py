@@ -19,7 +19,7 @@ import os
 import torch
 
 from . import kernels as K
-from ._lib import ACT_NONE, ACT_RELU
+from ._lib import ACT_NONE, ACT_RELU, ACT_RELU_MASK
 
 ALIGN = 64  # elements; keeps every block 256-byte (fp32) / 128-byte (bf16) aligned
 
@@ -139,15 +139,23 @@ class Linear:
         return out
 
     # ---- backward pieces
-    def dgrad(self, dy, out=None, accumulate=False):
-        """dx = dy W, or out += dy W when accumulate."""
+    def own_dgrad(self, dy, accumulate=False):
+        """True when dgrad takes the own NT kernel (transposed weight copy) for this dy."""
+        return (self.wlpT is not None and not accumulate and dy.shape[0] >= 4096 and dy.dtype == torch.bfloat16 and self.N % 64 == 0
+                and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0)
+
+    def dgrad(self, dy, out=None, accumulate=False, relu_mask=None):
+        """dx = dy W, or out += dy W when accumulate.  relu_mask (own-kernel path only, see own_dgrad): the activations
+        of the ReLU in front of this projection - their backward mask is applied in the GEMM's store tail."""
         w = self.wlp if dy.dtype == torch.bfloat16 else self.w32
         flops = 2.0 * dy.shape[0] * self.N * self.K
-        if (self.wlpT is not None and not accumulate and dy.shape[0] >= 4096 and dy.dtype == torch.bfloat16 and self.N % 64 == 0
-                and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0):
+        if self.own_dgrad(dy, accumulate):
             # dX = dY W as an NT product with the transposed weight copy: own MFMA kernel instead of the library GEMM
             out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
+            if relu_mask is not None:
+                return K.gemm_nt(dy, self.wlpT, None, out, act=ACT_RELU_MASK, res=relu_mask, family="lib_gemm_dgrad")
             return K.gemm_nt(dy, self.wlpT, None, out, family="lib_gemm_dgrad")
+        assert relu_mask is None, "relu_mask needs the own-kernel path (check own_dgrad first)"
         if accumulate:
             return K.timed("lib_gemm_dgrad", flops, lambda: out.addmm_(dy, w))
         if out is None:
@@ -282,6 +290,7 @@ class Engine:
         self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "decoder")
         self.group_wgrad = None if self.group_wgrad == "0" else self.group_wgrad
         self._pending = []
+        self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
         self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
         self._ln_part, self._ln_pending = {}, []
         self._block_flush = self.group_wgrad == "block"
@@ -485,9 +494,13 @@ class Engine:
         pf, sf = c["drop"]
         dz, dxg = self._ln_bwd(f.ln, f.w2.gb, dy, dy2, c["xhat"], c["rstd"], c["lens"], B, T, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(f.w2, dxg, c["h"])
-        dh = f.w2.dgrad(dxg)
+        fused_relu = self.fuse_relu_bwd and f.w2.own_dgrad(dxg) and c["h"].is_contiguous() and c["h"].data_ptr() % 16 == 0
+        dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)     # ReLU backward in the GEMM's store tail
         fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
-        K.relu_bwd_(dh, c["h"], None if fused else f.w1.gb, self.ws)
+        if not fused_relu:
+            K.relu_bwd_(dh, c["h"], None if fused else f.w1.gb, self.ws)
+        elif not fused:
+            f.w1.bgrad(dh, self.ws)
         self._wgrad(f.w1, dh, c["x"], bias_from=dh if fused else None)
         dx = f.w1.dgrad(dh)
         if self._block_flush:

@@ -430,7 +430,9 @@ def transpose_batched(src, dst, tiles):
 
 
 def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None, family="gemm_nt"):
-    """out (M,N) = act(a (M,K) @ w (N,K)^T + bias) (+ res); bf16 operands, MFMA kernel."""
+    """out (M,N) = act(a (M,K) @ w (N,K)^T + bias) (+ res); bf16 operands, MFMA kernel.
+    act = ACT_RELU_MASK: out = (a @ w^T + bias) where res > 0 else 0 (res = the activations of a ReLU whose backward
+    this is)."""
     assert a.dtype == w.dtype == out.dtype == torch.bfloat16
     M, K = a.shape
     N = w.shape[0]

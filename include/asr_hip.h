@@ -46,6 +46,8 @@ typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
 #define ASR_ACT_NONE 0
 #define ASR_ACT_RELU 1
+#define ASR_ACT_RELU_MASK 2 /* asr_gemm_nt_bf16 only: C = (A W^T + bias) where res > 0, else 0 - the ReLU backward of
+                               module.py:70-71 applied in the store tail of the input-gradient GEMM (res = the activations) */
 
 int asr_abi_version(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */

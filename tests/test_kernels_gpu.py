@@ -482,6 +482,24 @@ def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     close(out, ref, rtol=1e-2, atol=1e-2, what="gemm_nt")
 
 
+@pytest.mark.parametrize("M,N,K_", [(16000, 1024, 512), (777, 264, 128), (4100, 512, 1536)])
+def test_gemm_nt_relu_mask_epilogue(K, M, N, K_):
+    """ACT_RELU_MASK: C = (A W^T) where the mask tensor is > 0, else exactly 0 (the ReLU backward folded into the
+    input-gradient GEMM's store tail); masks with +0, -0, negative and positive entries."""
+    from asr_chinese_e2e_amd._lib import ACT_RELU_MASK
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K_, device=DEV).bfloat16()
+    w = (torch.randn(N, K_, device=DEV) * 0.05).bfloat16()
+    h = torch.relu(torch.randn(M, N, device=DEV)).bfloat16()
+    h[::7, ::5] = -0.0
+    h[1::9, 1::3] = -1.5            # never produced by a ReLU; must be masked all the same
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(a, w, None, out, ACT_RELU_MASK, h)
+    ref = (a.float() @ w.float().t()) * (h.float() > 0)
+    close(out, ref, rtol=1e-2, atol=1e-2, what="relu-mask epilogue")
+    assert bool((out[h.float() <= 0] == 0).all())
+
+
 def test_gemm_tn_eight_wave_form():
     """The 8-wave (intra-workgroup split) form of the wgrad kernel, selected by ASR_GEMM_TN_CFG=8 in a
     child process (the library reads the variable once): same results as the fp32 GEMM on the GPU."""
