@@ -153,8 +153,8 @@ class Linear:
             # dX = dY W as an NT product with the transposed weight copy: own MFMA kernel instead of the library GEMM
             out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
             if relu_mask is not None:
-                return K.gemm_nt(dy, self.wlpT, None, out, act=ACT_RELU_MASK, res=relu_mask, family="lib_gemm_dgrad")
-            return K.gemm_nt(dy, self.wlpT, None, out, family="lib_gemm_dgrad")
+                return K.gemm_nt(dy, self.wlpT, None, out, act=ACT_RELU_MASK, res=relu_mask)
+            return K.gemm_nt(dy, self.wlpT, None, out)
         assert relu_mask is None, "relu_mask needs the own-kernel path (check own_dgrad first)"
         if accumulate:
             return K.timed("lib_gemm_dgrad", flops, lambda: out.addmm_(dy, w))

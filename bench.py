@@ -220,7 +220,7 @@ def main():
             if dom:
                 a = fam[dom]["work_per_s"] / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": {"gemm_nt": "gemm_nt_persist_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
-                                                               "lib_gemm_dgrad": "hipBLASLt dgrad GEMM"}[dom],
+                                                               "lib_gemm_dgrad": "hipBLASLt GEMM (input gradients not on the own kernel)"}[dom],
                                    "achieved": a, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_BF16_PEAK_TFLOPS,
                                    "traffic": pmc_traffic(dom), "traffic_source": "profiles/round1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command (separate runs), bytes per launch averaged over the family's launches, FETCH_SIZE x2 (gfx950 correction)",
                                    "avg_launch_us": fam[dom]["avg_us"], "launches": fam[dom]["launches"],
