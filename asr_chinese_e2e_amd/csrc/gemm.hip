@@ -423,6 +423,20 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
         // takes a 1-KiB DMA instruction every 16 cycles per CU, so a block of 48 of them in front
         // of the MFMAs kept the matrix pipes idle for as long as the MFMAs themselves take (in-kernel
         // stamps: 0.52 us DMA-only + 0.82 us MFMA-only = 1.28 us per k-step, i.e. no overlap at all).
+        // ACT_RELU_MASK: the activations whose sign gates this gradient, fetched at the start of the tile's LAST k-step
+        // so that their latency hides behind its MFMAs (loaded in the store tail they cost 8.8 us per launch, 36 %)
+        u32x4 hm[MI / RM][4 * RM];
+        auto load_masks = [&]() {
+#pragma unroll
+            for (int round = 0; round < MI / RM; ++round)
+#pragma unroll
+                for (int q = 0; q < 4 * RM; ++q) {
+                    const int row = q * 8 + srow, ch = lane & 7;
+                    const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    hm[round][q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
+                }
+        };
         auto k_step = [&](const bool more) {   // more (wave-uniform): a stage is left to be issued
             const char* sb = smem_p + c_slot * PSTAGE;
             c_slot = c_slot == PRING - 1 ? 0 : c_slot + 1;
@@ -463,6 +477,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
             }
             __builtin_amdgcn_s_barrier();   // every wave's part of item i landed; nobody still reads the slot refilled during this step
             if (DBG == 5 && tid == 0 && i < 12) stamps[1 + i] = __builtin_amdgcn_s_memrealtime();
+            if (ACT == ASR_ACT_RELU_MASK && c_k == nk - 1) load_masks();
             k_step(issued < total);
         }
         // ---- store tail of tile c_tile: activation in registers, transpose through wave-private LDS
@@ -493,16 +508,6 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
                     }
             __builtin_amdgcn_wave_barrier();
             u32x4 v[4 * RM];   // all LDS reads first: with the read inside the bounds test each store waited for its own read
-            u32x4 hm[4 * RM];  // ACT_RELU_MASK: the activations whose sign gates this gradient (ReLU backward in the store tail)
-            if (ACT == ASR_ACT_RELU_MASK) {
-#pragma unroll
-                for (int q = 0; q < 4 * RM; ++q) {
-                    const int row = q * 8 + srow, ch = lane & 7;
-                    const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
-                    const u32x4 z = {0u, 0u, 0u, 0u};
-                    hm[q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
-                }
-            }
 #pragma unroll
             for (int q = 0; q < 4 * RM; ++q) {
                 const int row = q * 8 + srow, ch = lane & 7;
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
                 for (int q = 0; q < 4 * RM; ++q)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {   // bf16 pair: keep where the activation is > 0 (not zero, sign clear)
-                        const uint32_t h = hm[q][e];
+                        const uint32_t h = hm[round][q][e];
                         const uint32_t lo = ((h & 0x7fffu) != 0u && !(h & 0x8000u)) ? 0x0000ffffu : 0u;
                         const uint32_t hi = ((h & 0x7fff0000u) != 0u && !(h & 0x80000000u)) ? 0xffff0000u : 0u;
                         v[q][e] &= lo | hi;
