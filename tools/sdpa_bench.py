@@ -7,7 +7,7 @@ from asr_chinese_e2e_amd import kernels as K
 B, H, T, dk = 32, 8, int(os.environ.get("T", "500")), 64
 window = int(os.environ.get("WINDOW", "-1"))
 d = H * dk
-def timeit(fn, reps=20):
+def timeit(fn, reps=int(os.environ.get("REPS", "20"))):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
