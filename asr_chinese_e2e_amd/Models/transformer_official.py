@@ -313,6 +313,7 @@ class _SpeechTransformer(BaseModel):
         eng, x, wave_len, prep = self._prepare(input, training=self.training)
         B, T, _ = x.shape
         lam = self.ctc_weight
+        eng.refresh_transposes()      # W^T copies for this step's input-gradient GEMMs (side stream, beside the forward pass)
         enc, ecache = eng.encoder_fwd(x, wave_len, self.attn_window)
         ys_in, ys_out, labels32, dec_len, lab_len, n_valid = prep
         if n_valid_override is not None:

@@ -99,6 +99,7 @@ class NoamOpt:
         K.grad_sumsq(flat.g, sumsq, ws)
         K.noam_hyper(step, hyper, self.model_size, self.warmup, self.factor, 0.0, b1, b2)
         K.adam_step(flat.p, flat.g, flat.m, flat.v, flat.lp, hyper, sumsq, max_norm, b1, b2, g["eps"], write_clipped=True)
+        flat.version += 1               # the bf16 weights changed: transposed copies (engine.refresh_transposes) are stale
         self._step += 1                 # host mirror of the device counter (no sync)
         self._rate = self.rate()
         for gr in self.optimizer.param_groups:

@@ -66,6 +66,8 @@ class FlatParams:
         self.p, self.g, self.m, self.v = z(torch.float32), z(torch.float32), z(torch.float32), z(torch.float32)
         self.lp = z(torch.bfloat16) if lowp else None
         self.lpT = None      # transposed copies of the projection weights (engine.refresh_transposes), same offsets as lp
+        self.version = 0     # bumped whenever lp is rewritten (refresh_lowp, fused optimizer step)
+        self.lpT_version = -1   # value of `version` the transposed copies were made from
 
     def view(self, buf, name):
         off, shape = self.index[name]
@@ -90,6 +92,7 @@ class FlatParams:
     def refresh_lowp(self):
         if self.lp is not None:
             K.cast(self.p, self.lp)
+            self.version += 1
 
 
 class Linear:
@@ -141,7 +144,8 @@ class Linear:
     # ---- backward pieces
     def own_dgrad(self, dy, accumulate=False):
         """True when dgrad takes the own NT kernel (transposed weight copy) for this dy."""
-        return (self.wlpT is not None and not accumulate and dy.shape[0] >= 4096 and dy.dtype == torch.bfloat16 and self.N % 64 == 0
+        return (self.wlpT is not None and self.flat.lpT_version == self.flat.version      # stale copies (no refresh since the last update): library GEMM
+                and not accumulate and dy.shape[0] >= 4096 and dy.dtype == torch.bfloat16 and self.N % 64 == 0
                 and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0)
 
     def dgrad(self, dy, out=None, accumulate=False, relu_mask=None):
@@ -351,7 +355,11 @@ class Engine:
 
     def refresh_transposes(self):
         """W^T copies for the own-kernel input gradients: one launch on the side stream, which is idle during the
-        forward pass; the backward pass waits for it (wait_transposes) before its first input-gradient GEMM."""
+        forward pass; the backward pass waits for it (wait_transposes) before its first input-gradient GEMM.
+        Called by the model at the start of every step that will run a backward pass (train_step), whatever the
+        module's train / eval flag says."""
+        if self._tr_tiles is None:
+            return
         ev = self._event()
         ev.record()
         self.side.wait_event(ev)
@@ -362,6 +370,7 @@ class Engine:
             K.STREAM_OVERRIDE = None
         self._tr_event.record(self.side)
         self._tr_pending = True
+        self.flat.lpT_version = self.flat.version
 
     def wait_transposes(self):
         if self._tr_tiles is not None and self._tr_pending:
@@ -511,8 +520,6 @@ class Engine:
     def encoder_fwd(self, wave, wave_len, window=-1):
         """wave (B,T,F) in the compute dtype, wave_len (B) int32.  transformer_official.py:158-189."""
         B, T, F = wave.shape
-        if self._tr_tiles is not None and self.training:
-            self.refresh_transposes()
         x_in = wave.reshape(B * T, F)
         e0 = self.lin_in.fwd(x_in)
         p0, s0 = self._drop(1)             # dropout(LN(linear_in(x)) + PE)  (transformer_official.py:175-177)

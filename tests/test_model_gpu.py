@@ -353,6 +353,38 @@ def test_full_config_step_is_finite_and_learns():
     assert losses[-1] < losses[0], losses
 
 
+def test_transposed_weight_copies_track_the_weights():
+    """The own-kernel input gradients read W^T copies made once per step: after every step the copies used by the NEXT
+    backward must equal the updated weights, also when the module is in eval mode while training (dropout off), and a
+    stale copy (weights changed without a refresh) must send dgrad to the library GEMM instead."""
+    from asr_chinese_e2e_amd.data_handler import synthetic_pack
+    cfg = R.default_cfg(n_mels=80, lfr_m=1, use_decoder=False, ctc_weight=1.0)
+    cfg.layer_num = 2
+    model = build(cfg, 200, "TransformerCTC", dtype="bf16").cuda()
+    opt = make_opt(model, cfg, 20)
+    pack = synthetic_pack(16, 300, 80, 200, device=DEV)          # 4800 rows: the own-kernel path is active
+    model.eval()                                                  # training with the module in eval mode: still refreshed
+    for _ in range(3):
+        model.iterate(pack, optimizer=opt, is_train=True)
+    eng, flat = model._engine, model._flat
+    lin = eng.enc[1][1].w2
+    assert lin.wlpT is not None
+    dy = torch.randn(4800, lin.N, device=DEV).bfloat16()
+    assert not lin.own_dgrad(dy)                                  # the optimizer has just rewritten the weights: copies are stale
+    torch.cuda.synchronize()
+    stale = lin.wlpT.clone()
+    assert not torch.equal(stale.t().contiguous(), lin.wlp)      # ... and they really differ from the current weights
+    ref = (dy.float() @ lin.wlp.float())
+    out = lin.dgrad(dy)                                           # library path on the CURRENT weights
+    assert float((out.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-2
+    eng.refresh_transposes()
+    eng.wait_transposes()
+    torch.cuda.synchronize()
+    assert lin.own_dgrad(dy) and torch.equal(lin.wlpT.t().contiguous(), lin.wlp)
+    out2 = lin.dgrad(dy)                                          # own kernel on the fresh copy: same result
+    assert float((out2.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-2
+
+
 def test_no_cpu_fallback():
     cfg, sd, batch = oracle_case(2, 10, 16, 20, 3, dict(d_model=32, hidden_size=8, num_head=4, ff_size=64, layer_num=1))
     model = build(cfg, 20)
