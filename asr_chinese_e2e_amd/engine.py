@@ -520,6 +520,8 @@ class Engine:
     def encoder_fwd(self, wave, wave_len, window=-1):
         """wave (B,T,F) in the compute dtype, wave_len (B) int32.  transformer_official.py:158-189."""
         B, T, F = wave.shape
+        self._pending.clear()        # work queued by a step that did not finish (an exception between backward and
+        self._ln_pending.clear()     # its flush) must not be launched into this step's gradients
         x_in = wave.reshape(B * T, F)
         e0 = self.lin_in.fwd(x_in)
         p0, s0 = self._drop(1)             # dropout(LN(linear_in(x)) + PE)  (transformer_official.py:175-177)
