@@ -166,6 +166,7 @@ class _SpeechTransformer(BaseModel):
         if ok:
             self._views_checked = True
             return self._engine
+        K.bind_device(device)
         old = {name: p.detach().to(device=device, dtype=torch.float32) for name, p in self._named_flat_params()}
         old_mv = (f.m.to(device), f.v.to(device)) if f.m is not None else None   # keep Adam state across a device move
         f.allocate(device, self.lowp)
@@ -307,17 +308,22 @@ class _SpeechTransformer(BaseModel):
         ids, lens = K.ctc_greedy_decode(logits, wave_len, PAD_ID)
         return self._cer_ids(ids, labels32, hyp_len=lens, ref_len=lab_len)
 
-    def train_step(self, input, loss_scale=1.0, n_valid_override=None, ctc_batch=None):
+    def train_step(self, input, loss_scale=1.0, count_hook=None):
         """Forward + backward into the flat gradient buffer (no optimizer).  Returns the metrics
-        tensor [loss, ce, ctc] (device) and, for CER, (pred, gold) or None."""
+        tensor [loss, ce, ctc] (device) and, for CER, (pred, gold) or None.
+        count_hook (data parallelism, dist.DataParallel): called as count_hook(n_valid, B) right after the label
+        preprocessing; it starts the all-reduce of [non-pad token count, batch size] and returns an object whose wait()
+        yields the two GLOBAL values as 1-element device tensors - the loss kernels then normalise by those."""
         eng, x, wave_len, prep = self._prepare(input, training=self.training)
         B, T, _ = x.shape
         lam = self.ctc_weight
+        ys_in, ys_out, labels32, dec_len, lab_len, n_valid = prep
+        pending = count_hook(n_valid, B) if count_hook is not None else None
         eng.refresh_transposes()      # W^T copies for this step's input-gradient GEMMs (side stream, beside the forward pass)
         enc, ecache = eng.encoder_fwd(x, wave_len, self.attn_window)
-        ys_in, ys_out, labels32, dec_len, lab_len, n_valid = prep
-        if n_valid_override is not None:
-            n_valid = n_valid_override(n_valid)
+        batch_div = None
+        if pending is not None:
+            n_valid, batch_div = pending.wait()
         row_nll = nll = None
         d_enc = None
         pg = None
@@ -329,8 +335,10 @@ class _SpeechTransformer(BaseModel):
             w_ce = (1.0 - lam) if self.use_ctc else 1.0
             row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, smoothing=self.label_smoothing, grad_scale=w_ce * loss_scale, dlogits=pred)
         if self.use_ctc:
-            nb = float(ctc_batch if ctc_batch is not None else B)
-            nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale=lam * loss_scale / nb)
+            if batch_div is not None:     # global batch size, on the device
+                nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale=lam * loss_scale, grad_scale_div=batch_div)
+            else:
+                nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale=lam * loss_scale / float(B))
         if self.use_decoder:
             if d_enc is None:
                 d_enc = torch.zeros_like(enc)
@@ -348,6 +356,10 @@ class _SpeechTransformer(BaseModel):
                 return self.cal_metrics(output, input), None
         self._ensure_engine(input.wave.device)
         optimizer.zero_grad()
+        if getattr(optimizer, "fused_step", None) is None or not getattr(optimizer, "keeps_grad_views", False):
+            # a stock torch.optim optimizer (or the reference's own NoamOpt) sets every .grad to None in zero_grad():
+            # re-attach the views of the flat gradient buffer, or clip / step would see no gradients at all
+            self._grads_checked = False
         self.zero_flat_grads()
         loss, pg = self.train_step(input)
         fused = getattr(optimizer, "fused_step", None)

@@ -1,2 +1,3 @@
 from .optimizer import FusedAdam, NoamOpt
 from .trainer11 import Trainer11
+from .base_trainer import BaseTrainer

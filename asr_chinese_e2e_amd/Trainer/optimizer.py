@@ -46,6 +46,7 @@ class FusedAdam(torch.optim.Optimizer):
 
 class NoamOpt:
     "Optim wrapper that implements rate (Trainer/optimizer.py:4-31)."
+    keeps_grad_views = True    # zero_grad() never sets .grad to None (the model re-checks the views otherwise)
 
     def __init__(self, model_size, factor, warmup, optimizer):
         self.optimizer = optimizer
@@ -56,6 +57,7 @@ class NoamOpt:
         self._rate = 0
         self._dev = None   # (step int32[1], hyper f32[4], sumsq f32[1]) on the flat buffers' device
         self._flat = None
+        self._pending_state = None   # opt_state loaded before the model allocated its flat buffers
 
     def rate(self, step=None):
         if step is None:
@@ -94,6 +96,9 @@ class NoamOpt:
             flat.refresh_lowp()
             return
         step, hyper, sumsq, ws = self._device_state(flat)
+        if self._pending_state is not None:          # checkpoint loaded before the flat buffers existed
+            self._apply_adam_state(flat, self._pending_state)
+            self._pending_state = None
         g = self.optimizer.param_groups[0]
         b1, b2 = g["betas"]
         K.grad_sumsq(flat.g, sumsq, ws)
@@ -106,12 +111,78 @@ class NoamOpt:
             gr["lr"] = self._rate
         self.last_grad_sumsq = sumsq
 
-    # ---- checkpoint (Trainer/optimizer.py:33-46; file layout: dict with the same keys) -----------
+    # ---- checkpoint (Trainer/optimizer.py:33-46): the SAME file layout as the reference --------------------
+    # {'opt_state': torch.optim.Adam.state_dict(), 'step', 'factor', 'model_size', 'rate'}: a reference-trained .opt
+    # loads here and a file written here loads into the reference's NoamOpt(torch.optim.Adam).  The fused path keeps
+    # Adam's moments in the model's flat buffers; they are sliced into / filled from the per-parameter
+    # exp_avg / exp_avg_sq entries, keyed by parameter order (= model.parameters() order, as torch does).
+    def _flat_slices(self, flat):
+        """[(offset, numel, shape)] of the optimizer's parameters inside the flat buffers, in param_groups order."""
+        out = []
+        base = flat.p.data_ptr()
+        for g in self.optimizer.param_groups:
+            for p in g["params"]:
+                off = (p.data_ptr() - base) // 4
+                if p.device != flat.p.device or off < 0 or off + p.numel() > flat.p.numel() or (p.data_ptr() - base) % 4:
+                    raise RuntimeError("the optimizer's parameters are not views of the model's flat buffer "
+                                       "(build the optimizer from model.parameters() of the model it steps)")
+                out.append((off, p.numel(), tuple(p.shape)))
+        return out
+
+    def _adam_state_dict(self, flat):
+        """torch.optim.Adam.state_dict() of the fused state (moments on the CPU)."""
+        template = torch.optim.Adam([torch.zeros(1)], lr=self._rate or self.optimizer.param_groups[0]["lr"],
+                                    betas=self.optimizer.param_groups[0]["betas"], eps=self.optimizer.param_groups[0]["eps"])
+        groups, state, k = [], {}, 0
+        m, v = flat.m.cpu(), flat.v.cpu()
+        slices = self._flat_slices(flat)
+        for g in self.optimizer.param_groups:
+            d = dict(template.state_dict()["param_groups"][0])
+            d.update({key: val for key, val in g.items() if key != "params"})
+            d["params"] = list(range(k, k + len(g["params"])))
+            groups.append(d)
+            k += len(g["params"])
+        if self._step > 0:
+            for i, (off, n, shape) in enumerate(slices):
+                state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": m[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": v[off:off + n].view(shape).clone()}
+        return {"state": state, "param_groups": groups}
+
+    def _apply_adam_state(self, flat, os_):
+        """Fill the flat moments from a torch.optim.Adam.state_dict() (or this package's round-1 flat layout)."""
+        if "flat_m" in os_:                      # round-1 files: whole flat buffers + their index
+            idx = os_.get("index")
+            if idx is not None and {k: list(v[1]) + [v[0]] for k, v in flat.index.items()} != {k: list(v) for k, v in idx.items()}:
+                raise RuntimeError("optimizer checkpoint was written for a different parameter layout")
+            flat.m.copy_(os_["flat_m"])
+            flat.v.copy_(os_["flat_v"])
+            return
+        slices = self._flat_slices(flat)
+        state = os_["state"]
+        n_saved = sum(len(g["params"]) for g in os_["param_groups"])
+        if n_saved != len(slices):
+            raise RuntimeError(f"optimizer checkpoint holds {n_saved} parameters, the model has {len(slices)}")
+        flat.m.zero_()
+        flat.v.zero_()
+        for i, (off, n, shape) in enumerate(slices):
+            st = state.get(i, state.get(str(i)))
+            if st is None:                       # no step taken yet for this parameter (torch omits the entry)
+                continue
+            if tuple(st["exp_avg"].shape) != shape:
+                raise RuntimeError(f"optimizer checkpoint: parameter {i} has shape {tuple(st['exp_avg'].shape)}, the model {shape}")
+            flat.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            flat.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+
     def save(self, path):
         state = {"step": self._step, "factor": self.factor, "model_size": self.model_size, "rate": self._rate}
-        if self._flat is not None and isinstance(self.optimizer, FusedAdam):
-            state["opt_state"] = {"flat_m": self._flat.m.cpu(), "flat_v": self._flat.v.cpu(),
-                                  "index": {k: list(v[1]) + [v[0]] for k, v in self._flat.index.items()}}
+        if isinstance(self.optimizer, FusedAdam) and self._pending_state is not None:
+            state["opt_state"] = self._pending_state         # loaded but never stepped: pass it through
+        elif self._flat is not None and isinstance(self.optimizer, FusedAdam):
+            state["opt_state"] = self._adam_state_dict(self._flat)
+        elif isinstance(self.optimizer, FusedAdam):          # never stepped, nothing loaded
+            state["opt_state"] = torch.optim.Adam([torch.zeros(1)], lr=self.optimizer.param_groups[0]["lr"], betas=self.optimizer.param_groups[0]["betas"],
+                                                  eps=self.optimizer.param_groups[0]["eps"]).state_dict()
+            state["opt_state"]["param_groups"][0]["params"] = list(range(sum(len(g["params"]) for g in self.optimizer.param_groups)))
         else:
             state["opt_state"] = self.optimizer.state_dict()
         torch.save(state, path)
@@ -122,12 +193,15 @@ class NoamOpt:
         self._step, self.factor = state["step"], state["factor"]
         self.model_size, self._rate = state["model_size"], state["rate"]
         os_ = state["opt_state"]
-        flat = flat if flat is not None else self._flat
-        if isinstance(os_, dict) and "flat_m" in os_:
-            if flat is None:
-                raise RuntimeError("pass the model's flat buffers (model._flat) to load a fused optimizer state")
-            flat.m.copy_(os_["flat_m"])
-            flat.v.copy_(os_["flat_v"])
+        if isinstance(self.optimizer, FusedAdam):
+            flat = flat if flat is not None else self._flat
+            if flat is not None and flat.m is not None:
+                self._apply_adam_state(flat, os_)
+                self._pending_state = None
+            else:
+                # the model has not allocated its flat buffers yet (fresh Model(...).cuda() before the first step):
+                # the moments are applied by the first fused_step, which receives the buffers
+                self._pending_state = os_
         else:
             self.optimizer.load_state_dict(os_)
         if self._dev is not None:

@@ -70,7 +70,14 @@ class Trainer11:
         prefix = f"e{epoch}_s{step}"
         self.global_step, self.global_epoch = step, epoch
         self.model.load(os.path.join(self.ckpt_root, exp_name, prefix + ".model"))
+        # a fresh model allocates its flat HBM buffers at the first step: allocate them now when it already sits on
+        # the GPU, so that Adam's moments land in them (otherwise NoamOpt keeps the state until the first fused step)
+        ensure = getattr(self.model, "_ensure_engine", None)
+        dev = next(self.model.parameters()).device
+        if ensure is not None and dev.type == "cuda":
+            ensure(dev)
         self.optimizer.load(os.path.join(self.ckpt_root, exp_name, prefix + ".opt"), getattr(self.model, "_flat", None))
+        self.config = self.model.config
 
     def save_ckpt(self):
         prefix = f"e{self.global_epoch}_s{self.global_step}"

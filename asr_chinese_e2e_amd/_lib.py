@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -42,6 +42,8 @@ LN_REDUCE_MAX = 16
 SIGNATURES = {
     "asr_abi_version": (I, []),
     "asr_last_error": (I, [c_char_p, Z]),
+    "asr_get_deterministic": (I, []),
+    "asr_set_deterministic": (I, [I]),
     "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, U, I, I, P]),
     "asr_add_ln_bwd_workspace_bytes": (Z, [I, I]),
     "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, F, U, I, I, P]),
@@ -51,7 +53,7 @@ SIGNATURES = {
     "asr_dropout_mask": (I, [P, I, I, F, U, P]),
     "asr_sdpa_dropout_mask": (I, [P, I, I, I, I, F, U, P]),
     "asr_ctc_workspace_bytes": (Z, [I, I, I]),
-    "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, P, Z, I, P]),
+    "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P, I, P, Z, I, P]),
     "asr_ctc_greedy_decode": (I, [P, P, P, P, I, I, I, I, I, P]),
     "asr_decode_attn": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
     "asr_logsoftmax_topk": (I, [P, P, P, I, I, I, I, I, P]),

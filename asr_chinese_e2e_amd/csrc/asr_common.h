@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // ---- error reporting (host) -----------------------------------------------------------------
 void asr_set_error(const char* fmt, ...);
+int asr_deterministic(void);   // 1: fixed-order reductions everywhere (asr_set_deterministic / ASR_DETERMINISTIC=1)
 #define ASR_FAIL(code, ...)        \
     do {                           \
         asr_set_error(__VA_ARGS__); \

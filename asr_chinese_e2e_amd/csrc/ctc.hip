@@ -177,7 +177,8 @@ template <int NV, bool WRITE>
 __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* logits, const int32_t* __restrict__ in_len,
                                                                   const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
                                                                   double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int Lmax,
-                                                                  int W, int blank, bf16_t* dlogits, float scale) {
+                                                                  int W, int blank, bf16_t* dlogits, float scale_in, const float* __restrict__ scale_div) {
+    const float scale = scale_div ? scale_in / *scale_div : scale_in;     // scale_div: a device scalar (global batch under data parallelism)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_, nvec = V >> 3;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const float* __restrict__ lse_in, const int32_t* __restrict__ in_len,
                                                        const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
                                                        const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank,
-                                                       float scale) {
+                                                       float scale_in, int det, const float* __restrict__ scale_div) {
+    const float scale = scale_div ? scale_in / *scale_div : scale_in;
     extern __shared__ __attribute__((aligned(16))) float occ[];  // V floats: posterior mass per label
     constexpr int N = Vec<T>::N;
     const int rows = B * T_;
@@ -508,6 +510,13 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
             const double sum = sum_b + sum_l;
             if (sum > 0.0) {
                 if (threadIdx.x == 0) occ[blank] = (float)(sum_b / sum);      // all blank states share one class
+                if (det) {   // repeated labels share a class: add their states in label order (fixed order)
+                    if (threadIdx.x == 0)
+                        for (int i = 0; i < L; ++i) {
+                            const double yl = lp[o + W + i];
+                            if (yl > 0.0) occ[labels[(size_t)b * Lmax + i]] += (float)(alpha[o + W + i] * beta[o + W + i] / yl / sum);
+                        }
+                } else
                 for (int i = threadIdx.x; i < L; i += 64) {
                     const double yl = lp[o + W + i];
                     if (yl > 0.0) atomicAdd(&occ[labels[(size_t)b * Lmax + i]], (float)(alpha[o + W + i] * beta[o + W + i] / yl / sum));
@@ -542,7 +551,8 @@ __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const bf16_t* __rest
                                                             const float* __restrict__ lse_in, const int32_t* __restrict__ in_len,
                                                             const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
                                                             const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank,
-                                                            float scale) {
+                                                            float scale_in, const float* __restrict__ scale_div) {
+    const float scale = scale_div ? scale_in / *scale_div : scale_in;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_, nvec = V >> 3;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
@@ -630,7 +640,8 @@ __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256) void ctc_label_fix_kernel(bf16_t* __restrict__ dlogits, const double* __restrict__ lp, const double* __restrict__ alpha,
                                                             const double* __restrict__ beta, const int32_t* __restrict__ in_len,
                                                             const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank, float scale) {
+                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank, float scale_in, const float* __restrict__ scale_div) {
+    const float scale = scale_div ? scale_in / *scale_div : scale_in;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_, nvec = V >> 3;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
@@ -781,8 +792,8 @@ extern "C" size_t asr_ctc_workspace_bytes(int B, int T, int Lmax) {
 }
 
 extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len, const int32_t* labels, const int32_t* lab_len,
-                               float* nll, int B, int T, int V, int Lmax, int blank, float grad_scale, int zero_infinity, void* ws,
-                               size_t ws_bytes, int dtype, void* stream) {
+                               float* nll, int B, int T, int V, int Lmax, int blank, float grad_scale, const float* grad_scale_div,
+                               int zero_infinity, void* ws, size_t ws_bytes, int dtype, void* stream) {
     if (!logits || !in_len || !labels || !lab_len || !nll || !ws) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: null pointer");
     if (B <= 0 || T <= 0 || V <= 1 || Lmax <= 0 || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: bad shape B=%d T=%d V=%d Lmax=%d blank=%d", B, T, V, Lmax, blank);
     if (Lmax > 255) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: Lmax = %d: label sequences longer than 255 are not supported", Lmax);
@@ -817,11 +828,11 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
         // with a gradient: the softmax part of it is written by the same wave that reduces the row (one pass over
         // the logits less); ASR_CTC_SPLIT=0 keeps the separate gradient kernel (A/B runs)
         if (dlogits && ctc_split) {
-#define K1(NV) ctc_lse_gather_rows_kernel<NV, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, (bf16_t*)dlogits, grad_scale)
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, (bf16_t*)dlogits, grad_scale, grad_scale_div)
             ROWS_DISPATCH(K1);
 #undef K1
         } else {
-#define K1(NV) ctc_lse_gather_rows_kernel<NV, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, nullptr, 0.f)
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, nullptr, 0.f, nullptr)
             ROWS_DISPATCH(K1);
 #undef K1
         }
@@ -836,13 +847,13 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     if (dlogits) {
         int g3 = rows < 2048 ? rows : 2048;
         if (rows_path && ctc_split) {
-            ctc_label_fix_kernel<<<g1, 256, 0, st>>>((bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
+            ctc_label_fix_kernel<<<g1, 256, 0, st>>>((bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, grad_scale_div);
         } else if (rows_path) {
-#define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale)
+#define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, grad_scale_div)
             ROWS_DISPATCH(K3);
 #undef K3
-        } else if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
-        else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale);
+        } else if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
+        else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
     }
     ASR_CHECK_LAUNCH("asr_ctc_fwd_bwd");
     return ASR_OK;

@@ -586,7 +586,7 @@ __device__ __forceinline__ bf16x8 tn_frag(const bf16_t* tile, int col0, int s, i
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N, int K,
-                                                      int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split, int use_atomic) {
+                                                      int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split, int use_atomic, size_t split_stride) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TM * TSW];
     bf16_t* Ys = smem;
     bf16_t* Xs = smem + TM * TSW;
@@ -599,6 +599,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     const int tk = tile % tiles_k, tn = tile / tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
     const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    dW += (size_t)split * split_stride;     // deterministic mode: every split owns a slab (summed by tn_slab_reduce_kernel)
     const int wn = w >> 1, wk = w & 1;
     f32x16 acc[2][2];  // [ni][ki]
 #pragma unroll
@@ -699,7 +700,8 @@ __device__ __forceinline__ bf16x8 tn_frag_swz(unsigned addr) {
 template <int TRING, int G>
 __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
                                                              int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
-                                                             int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias) {
+                                                             int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias, size_t split_stride,
+                                                             int bias_split_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = tiles_k * tiles_n;
@@ -712,6 +714,7 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
     constexpr int SBYTES = TSTAGE * G;         // bytes per ring slot: [dY SR x 256 B | X SR x 256 B]
     const int nsteps = (mend - mbeg + SR - 1) / SR;
     if (nsteps <= 0) return;
+    dW += (size_t)split * split_stride;     // deterministic mode: every split owns a slab (summed by tn_slab_reduce_kernel)
     const int grp = w >> 2, wl = w & 3;
     const int wn = wl >> 1, wk = wl & 1;
 
@@ -894,7 +897,8 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
             float t = 0.f;
 #pragma unroll
             for (int ph = 0; ph < 16 * G; ++ph) t += red[ph * 128 + tid];
-            atomicAdd(dbias + n0 + tid, t);
+            if (bias_split_stride) dbias[(size_t)split * bias_split_stride + n0 + tid] = t;   // deterministic mode: slab per split
+            else atomicAdd(dbias + n0 + tid, t);
         }
     }
 }
@@ -1179,6 +1183,34 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int rows, int c
     }
 }
 
+// Deterministic mode, second pass: dW[n][k] (+)= slab[0][n][k] + slab[1][n][k] + ... in split order; the same for the
+// bias slabs (dbias[n] += ...).  blockIdx.y == 1 handles the bias.
+__global__ __launch_bounds__(256) void tn_slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int N, int K, float* __restrict__ dW, int ldw,
+                                                             int accumulate, const float* __restrict__ bslab, float* __restrict__ dbias) {
+    if (blockIdx.y == 1) {
+        if (!dbias) return;
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+            float t = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) t += bslab[(size_t)sp * N + n];
+            dbias[n] += t;
+        }
+        return;
+    }
+    const size_t total4 = (size_t)N * K / 4, plane = (size_t)N * K;   // K % 8 == 0
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        f32x4 t = *(const f32x4*)(slab + i * 4);
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const f32x4 v = *(const f32x4*)(slab + sp * plane + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += v[e];
+        }
+        const size_t n = (i * 4) / K, k = i * 4 - n * K;
+        float* dst = dW + n * ldw + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = accumulate ? dst[e] + t[e] : t[e];
+    }
+}
+
 static int tn_splits(int M, int N, int K) {
     const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
     int s = ceil_div(256, tiles);            // ~one workgroup per CU: every extra split adds N*K*4 B of atomics
@@ -1252,6 +1284,7 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
 
 extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, int accumulate, void* stream) {
     if (!probs || nprob <= 0 || nprob > TG_MAX) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: 1..%d problems per call (got %d)", TG_MAX, nprob);
+    if (asr_deterministic()) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: the grouped kernel combines splits with fp32 atomics - in deterministic mode call asr_gemm_tn_bias_bf16 per problem");
     hipStream_t st = (hipStream_t)stream;
     TnGroup g;
     memset(&g, 0, sizeof(g));
@@ -1325,34 +1358,15 @@ extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, 
     return ASR_OK;
 }
 
-extern "C" size_t asr_gemm_tn_workspace_bytes(int M, int N, int K) {
-    (void)M; (void)N; (void)K;
-    return 0;  // partial tiles are combined with fp32 atomics; no scratch needed
-}
-
-extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy, int ldx, int ldw,
-                                     int accumulate, void* ws, size_t ws_bytes, void* stream);
-
-extern "C" int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* ws,
-                                size_t ws_bytes, void* stream) {
-    return asr_gemm_tn_bias_bf16(dY, X, dW, nullptr, M, N, K, ldy, ldx, ldw, accumulate, ws, ws_bytes, stream);
-}
-
-extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy, int ldx, int ldw,
-                                     int accumulate, void* ws, size_t ws_bytes, void* stream) {
-    (void)ws; (void)ws_bytes;
-    if (!dY || !X || !dW) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: null pointer");
-    if (M <= 0 || N <= 0 || K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: bad shape M=%d N=%d K=%d", M, N, K);
-    if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ldw < K) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: N, K, ldy, ldx must be multiples of 8 (N=%d K=%d ldy=%d ldx=%d)", N, K, ldy, ldx);
-    if (((uintptr_t)dY | (uintptr_t)X) % 16) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: misaligned pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const int tiles_n = ceil_div(N, 128), tiles_k = ceil_div(K, 128), tiles = tiles_n * tiles_k;
+namespace {
+struct TnPlan { int tn_cfg, ring, rows_per_split, nsplit; bool eight; };
+// M-splits: every split adds N*K*4 bytes of atomics, every workgroup beyond what is resident at
+// once adds a whole second round.  The DMA kernel holds one 8-wave workgroup per CU (two wave
+// groups splitting each 128-row ring slot); if that leaves more than ~20 % of the CUs idle it
+// runs two 4-wave workgroups per CU instead.
+static TnPlan tn_plan(int M, int N, int K) {
     static const int tn_cfg = getenv("ASR_GEMM_TN_CFG") ? atoi(getenv("ASR_GEMM_TN_CFG")) : 0;   // 1 = register-staged kernel (A/B runs)
-    static const int tn_noatomic = getenv("ASR_GEMM_TN_NOATOMIC") ? atoi(getenv("ASR_GEMM_TN_NOATOMIC")) : 0;   // timing experiments only (wrong results)
-    // M-splits: every split adds N*K*4 bytes of atomics, every workgroup beyond what is resident at
-    // once adds a whole second round.  The DMA kernel holds one 8-wave workgroup per CU (two wave
-    // groups splitting each 128-row ring slot); if that leaves more than ~20 % of the CUs idle it
-    // runs two 4-wave workgroups per CU instead.
+    const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
     const int cus = cu_count();
     const int max_s = ceil_div(M, 4 * TM);   // at least 4 reduction stages per workgroup
     int splits = tn_splits(M, N, K), ring = 0;
@@ -1369,12 +1383,62 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
     // runs on the side stream BESIDE the dgrad / attention / LayerNorm chain, and two of its waves per
     // SIMD take issue slots from that chain: the whole step is 2 % slower with it (A/B in one process:
     // 8.10 vs 8.28 k utterances/s).  The step time decides.
-    const bool eight = ring == 4 && tn_cfg == 8;
-    const int gran = eight ? 2 * TM : TM;          // rows per ring slot
-    const int rows_per_split = ceil_div(ceil_div(M, splits), gran) * gran;
-    const int nsplit = ceil_div(M, rows_per_split);
-    const int use_atomic = tn_noatomic ? 0 : ((nsplit > 1) || accumulate);
-    if (nsplit > 1 && !accumulate) {
+    TnPlan pl;
+    pl.tn_cfg = tn_cfg;
+    pl.ring = ring;
+    pl.eight = ring == 4 && tn_cfg == 8;
+    const int gran = pl.eight ? 2 * TM : TM;          // rows per ring slot
+    pl.rows_per_split = ceil_div(ceil_div(M, splits), gran) * gran;
+    pl.nsplit = ceil_div(M, pl.rows_per_split);
+    return pl;
+}
+}  // namespace
+
+extern "C" size_t asr_gemm_tn_workspace_bytes(int M, int N, int K) {
+    // default mode: partial tiles are combined with fp32 atomics, no scratch.  Deterministic mode: one (N, K) fp32
+    // slab and one N-vector (bias gradient) per M-split.
+    if (!asr_deterministic() || M <= 0 || N <= 0 || K <= 0) return 0;
+    const TnPlan pl = tn_plan(M, N, K);
+    return ((size_t)pl.nsplit * N * K + (size_t)pl.nsplit * N) * sizeof(float);
+}
+
+extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy, int ldx, int ldw,
+                                     int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+extern "C" int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy, int ldx, int ldw, int accumulate, void* ws,
+                                size_t ws_bytes, void* stream) {
+    return asr_gemm_tn_bias_bf16(dY, X, dW, nullptr, M, N, K, ldy, ldx, ldw, accumulate, ws, ws_bytes, stream);
+}
+
+extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias, int M, int N, int K, int ldy, int ldx, int ldw,
+                                     int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (!dY || !X || !dW) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ldw < K) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: N, K, ldy, ldx must be multiples of 8 (N=%d K=%d ldy=%d ldx=%d)", N, K, ldy, ldx);
+    if (((uintptr_t)dY | (uintptr_t)X) % 16) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_n = ceil_div(N, 128), tiles_k = ceil_div(K, 128), tiles = tiles_n * tiles_k;
+    static const int tn_noatomic = getenv("ASR_GEMM_TN_NOATOMIC") ? atoi(getenv("ASR_GEMM_TN_NOATOMIC")) : 0;   // timing experiments only (wrong results)
+    const TnPlan pl = tn_plan(M, N, K);
+    const int tn_cfg = pl.tn_cfg, ring = pl.ring, rows_per_split = pl.rows_per_split, nsplit = pl.nsplit;
+    const bool eight = pl.eight;
+    // Deterministic mode: no atomics - each split stores its partial tile into its own slab of the workspace and
+    // tn_slab_reduce_kernel adds the slabs in split order (also for a single split when accumulating into dW).
+    const bool det = asr_deterministic() != 0;
+    float* dW_k = dW;
+    float* dbias_k = dbias;
+    int ldw_k = ldw, bias_split_stride = 0;
+    size_t split_stride = 0;
+    if (det) {
+        const size_t need = asr_gemm_tn_workspace_bytes(M, N, K);
+        if (!ws || ws_bytes < need || ((uintptr_t)ws % 16)) ASR_FAIL(ASR_EWORKSPACE, "asr_gemm_tn_bf16: deterministic mode needs a 16-byte aligned workspace of %zu bytes (got %zu)", need, ws_bytes);
+        dW_k = (float*)ws;
+        ldw_k = K;
+        split_stride = (size_t)N * K;
+        if (dbias) { dbias_k = (float*)ws + (size_t)nsplit * N * K; bias_split_stride = N; }
+    }
+    const int use_atomic = (tn_noatomic || det) ? 0 : ((nsplit > 1) || accumulate);
+    if (nsplit > 1 && !accumulate && !det) {
         size_t total = (size_t)N * K;
         int g = (int)((total + 255) / 256);
         zero_f32_kernel<<<g < 1024 ? g : 1024, 256, 0, st>>>(dW, N, K, ldw);
@@ -1382,7 +1446,7 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
     const int grid = tiles * nsplit;
     if (tn_cfg == 1) {
         if (dbias) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bias_bf16: the register-staged kernel (ASR_GEMM_TN_CFG=1) has no bias path");
-        gemm_tn_kernel<<<grid, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic);
+        gemm_tn_kernel<<<grid, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, split_stride);
     } else {
         static void* zero_page = nullptr;
         if (!zero_page) {
@@ -1397,17 +1461,22 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
         if (lds_pad && ring == 4 && !eight) {
             static bool once = false;
             if (!once) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE + lds_pad); once = true; }
-            gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE + lds_pad, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+            gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE + lds_pad, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
         } else if (tn_cfg == 2 && ring == 4) {   // 2-stage ring, 64 KiB, still one workgroup per CU
-            gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+            gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
         } else if (tn_cfg != 4 && ring == 4 && !eight) {   // default: 3-stage ring, 96 KiB (step 3.74 vs 3.79 ms with 4 stages = 128 KiB, although the kernel alone is 1-5 % slower)
             static bool once3 = false;
             if (!once3) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); once3 = true; }
-            gemm_tn_dma_kernel<3, 1><<<grid, 256, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+            gemm_tn_dma_kernel<3, 1><<<grid, 256, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
         } else
-        if (ring == 4 && !eight) gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
-        else if (ring == 4) gemm_tn_dma_kernel<2, 2><<<grid, 512, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
-        else gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW, M, N, K, ldy, ldx, ldw, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias);
+        if (ring == 4 && !eight) gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
+        else if (ring == 4) gemm_tn_dma_kernel<2, 2><<<grid, 512, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
+        else gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
+    }
+    if (det) {
+        const size_t total4 = (size_t)N * K / 4;
+        int g = (int)((total4 + 255) / 256);
+        tn_slab_reduce_kernel<<<dim3(g < 1024 ? g : 1024, dbias ? 2 : 1), 256, 0, st>>>((const float*)ws, nsplit, N, K, dW, ldw, accumulate, dbias_k, dbias);
     }
     ASR_CHECK_LAUNCH("asr_gemm_tn_bf16");
     return ASR_OK;

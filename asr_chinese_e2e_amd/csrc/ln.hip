@@ -309,7 +309,7 @@ extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat,
     if (dgamma) {   // dgamma == dbeta == NULL: the partial sums stay in ws for asr_add_ln_bwd_reduce_batched
         // the partial rows are split between 4 workgroups per column group (atomic adds): 3.806 vs 3.830 ms per step
         static const int fsplit = getenv("ASR_LN_FSPLIT") ? atoi(getenv("ASR_LN_FSPLIT")) : 4;
-        colsum_finalize_kernel<<<dim3(ceil_div(ncols, 32), P >= 256 * fsplit ? fsplit : 1), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
+        colsum_finalize_kernel<<<dim3(ceil_div(ncols, 32), (P >= 256 * fsplit && !asr_deterministic()) ? fsplit : 1), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
     }
     ASR_CHECK_LAUNCH("asr_add_ln_bwd");
     return ASR_OK;
@@ -375,7 +375,7 @@ extern "C" int asr_add_ln_bwd_reduce_batched(const asr_ln_reduce_item* items, in
         bt.dbias[i] = items[i].dbias;
         bt.P[i] = ln_grid(items[i].rows);
     }
-    ln_reduce_batched_kernel<<<dim3(ceil_div(3 * d, 32), 4, n), 1024, 0, (hipStream_t)stream>>>(bt, d);
+    ln_reduce_batched_kernel<<<dim3(ceil_div(3 * d, 32), asr_deterministic() ? 1 : 4, n), 1024, 0, (hipStream_t)stream>>>(bt, d);
     ASR_CHECK_LAUNCH("asr_add_ln_bwd_reduce_batched");
     return ASR_OK;
 }

@@ -1,6 +1,7 @@
 // Error reporting, element-wise glue, column sums, decoder target preparation, embedding,
 // and the fused clip + Noam + Adam optimizer over the flat parameter buffer.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "asr_common.h"
 
@@ -14,6 +15,24 @@ void asr_set_error(const char* fmt, ...) {
 }
 
 extern "C" int asr_abi_version(void) { return ASR_ABI_VERSION; }
+
+// Deterministic mode: every cross-workgroup floating-point reduction runs in a fixed order (weight-gradient split
+// sums through partial slabs + an ordered second pass instead of fp32 atomics, single-workgroup column-sum
+// finalisation, serial embedding scatter).  Slower; meant for reproducibility runs and equivalence tests.
+static int g_deterministic = -1;
+int asr_deterministic(void) {
+    if (g_deterministic < 0) {
+        const char* e = getenv("ASR_DETERMINISTIC");
+        g_deterministic = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return g_deterministic;
+}
+extern "C" int asr_get_deterministic(void) { return asr_deterministic(); }
+extern "C" int asr_set_deterministic(int on) {
+    const int old = asr_deterministic();
+    g_deterministic = on ? 1 : 0;
+    return old;
+}
 
 extern "C" int asr_last_error(char* buf, size_t n) {
     if (buf && n) {
@@ -195,6 +214,22 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
         float g = to_f32<T>(dy[(size_t)row * d + c]) * scale;
         if (thr) g = drop_keep_at((uint32_t)row * (uint32_t)d + c, seed, thr) ? g * dscale : 0.f;
         if (g != 0.f) atomicAdd(&demb[(size_t)id * d + c], g);
+    }
+}
+
+// Deterministic form: thread = one column, tokens in order (rows of the same id are added in a fixed order).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_serial_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dy,
+                                                               float* demb, float scale, int rows, int d, int V, uint32_t seed, uint32_t thr,
+                                                               float dscale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    for (int row = 0; row < rows; ++row) {
+        const int id = ids[row];
+        if (id < 0 || id >= V) continue;
+        float g = to_f32<T>(dy[(size_t)row * d + c]) * scale;
+        if (thr) g = drop_keep_at((uint32_t)row * (uint32_t)d + c, seed, thr) ? g * dscale : 0.f;
+        if (g != 0.f) demb[(size_t)id * d + c] += g;
     }
 }
 
@@ -383,7 +418,7 @@ static int colsum_impl(void* x, const void* a, float* out, void* ws, size_t ws_b
     if (dtype == ASR_F32) colsum_partial_kernel<float, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((float*)x, (const float*)a, (float*)ws, rows, cols, ld, slots);
     else if (dtype == ASR_BF16) colsum_partial_kernel<bf16_t, RELU_BWD><<<grid, CS_WAVES * WAVE, 0, st>>>((bf16_t*)x, (const bf16_t*)a, (float*)ws, rows, cols, ld, slots);
     else ASR_FAIL(ASR_EDTYPE, "%s: dtype %d", name, dtype);
-    if (want_sum) colsum_finalize_kernel<<<dim3(ceil_div(cols, 32), accumulate && slots >= 1024 ? 4 : 1), 1024, 0, st>>>((const float*)ws, slots, (size_t)cols, cols, cols, out, nullptr, nullptr, accumulate);
+    if (want_sum) colsum_finalize_kernel<<<dim3(ceil_div(cols, 32), accumulate && slots >= 1024 && !asr_deterministic() ? 4 : 1), 1024, 0, st>>>((const float*)ws, slots, (size_t)cols, cols, cols, out, nullptr, nullptr, accumulate);
     ASR_CHECK_LAUNCH(name);
     return ASR_OK;
 }
@@ -433,9 +468,12 @@ extern "C" int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, fl
     hipStream_t st = (hipStream_t)stream;
     const uint32_t thr = drop_thr16(drop_p);
     const float ds = 1.f / (1.f - drop_p);
-    if (dtype == ASR_F32) embed_bwd_kernel<float><<<rows, 256, 0, st>>>(ids, (const float*)dy, demb, scale, d, V, drop_seed, thr, ds);
-    else if (dtype == ASR_BF16) embed_bwd_kernel<bf16_t><<<rows, 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, d, V, drop_seed, thr, ds);
-    else ASR_FAIL(ASR_EDTYPE, "asr_embed_bwd: dtype %d", dtype);
+    if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_embed_bwd: dtype %d", dtype);
+    if (asr_deterministic()) {
+        if (dtype == ASR_F32) embed_bwd_serial_kernel<float><<<ceil_div(d, 256), 256, 0, st>>>(ids, (const float*)dy, demb, scale, rows, d, V, drop_seed, thr, ds);
+        else embed_bwd_serial_kernel<bf16_t><<<ceil_div(d, 256), 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, rows, d, V, drop_seed, thr, ds);
+    } else if (dtype == ASR_F32) embed_bwd_kernel<float><<<rows, 256, 0, st>>>(ids, (const float*)dy, demb, scale, d, V, drop_seed, thr, ds);
+    else embed_bwd_kernel<bf16_t><<<rows, 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, d, V, drop_seed, thr, ds);
     ASR_CHECK_LAUNCH("asr_embed_bwd");
     return ASR_OK;
 }

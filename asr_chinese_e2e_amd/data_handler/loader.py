@@ -94,12 +94,27 @@ def bucket_batches(lengths, batch_size, bucket_size=None, shuffle=True, drop_las
     return batches
 
 
+def shard_batches(batches, rank, world):
+    """Data-parallel shard of a batch list that every rank builds identically: the ragged tail of len % world is
+    dropped (every rank must take the same number of steps) and rank r takes batches[r::world]."""
+    if world <= 1:
+        return batches
+    return batches[: len(batches) // world * world][rank::world]
+
+
 class BucketedWaveLoader:
     """Iterating yields Packs on `device`; one batch is prepared ahead on a side stream."""
 
     def __init__(self, dataset, batch_size, parser=None, augment=False, shuffle=True, drop_last=False, seed=0, bucket_size=None,
-                 device="cuda", dtype=torch.bfloat16):
+                 device="cuda", dtype=torch.bfloat16, rank=0, world=1):
+        """rank / world: data-parallel sharding.  Every rank draws the SAME batch list (same seed), keeps only the full
+        batches when world > 1 (dist.DataParallel normalises by world x local batch and every rank must take the same
+        number of steps), drops the ragged tail of len(batches) % world and takes batches[rank::world]."""
         self.ds, self.batch_size, self.augment, self.shuffle, self.drop_last = dataset, batch_size, augment, shuffle, drop_last
+        self.rank, self.world = int(rank), int(world)
+        assert 0 <= self.rank < self.world
+        if self.world > 1:
+            self.drop_last = True
         self.device, self.dtype = torch.device(device), dtype
         if self.device.type != "cuda":
             raise RuntimeError("the feature front end runs on the GPU only (no CPU fallback)")
@@ -111,7 +126,13 @@ class BucketedWaveLoader:
 
     def __len__(self):
         n = len(self.ds)
+        if self.world > 1:      # full batches only (per bucket), the same count on every rank
+            return len(self._batches(random.Random(0)))
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _batches(self, rng):
+        batches = bucket_batches(self.lengths, self.batch_size, self.bucket_size, self.shuffle, self.drop_last, rng)
+        return shard_batches(batches, self.rank, self.world)
 
     def _prepare(self, idx):
         waves = [self.ds.wave(i) for i in idx]
@@ -134,7 +155,7 @@ class BucketedWaveLoader:
         return pack, done, host          # host buffer kept alive until the copy has run
 
     def __iter__(self):
-        batches = bucket_batches(self.lengths, self.batch_size, self.bucket_size, self.shuffle, self.drop_last, self.rng)
+        batches = self._batches(self.rng)
         nxt = self._prepare(batches[0]) if batches else None
         for k in range(len(batches)):
             pack, done, _host = nxt
@@ -144,3 +165,28 @@ class BucketedWaveLoader:
                 if torch.is_tensor(v):
                     v.record_stream(torch.cuda.current_stream())
             yield pack
+
+
+def build_dataloader(collector_path, vocab, batch_size, part="test", use_cuda=True, sample_rate=16000, window_size=400, n_mels=40,
+                     augment=False, predump=False, use_old=False, lfr_m=4, lfr_n=3, dtype=torch.bfloat16, shuffle=None, seed=0,
+                     rank=0, world=1):
+    """build_dataloader of the reference (data/data_loader/ai_shell_1.py:91-104), same arguments: reads the manifest
+    `<collector_path>_<part>.json` written by the reference's collector (one JSON object {"wave": path, "tgt": text}
+    per line, data_collector/ai_shell_1.py:73-79) and returns an iterable of Packs.  The reference computes features
+    on the CPU per utterance and can cache them as .t files (predump / use_old); here they are computed on the GPU
+    per batch, so both flags are accepted and ignored.  drop_last=True as in the reference (:103)."""
+    import json
+    if not use_cuda:
+        raise RuntimeError("the feature front end runs on the GPU only (no CPU fallback)")
+    if window_size != 400:
+        raise ValueError("the log-mel kernel is built for the reference's window of 400 samples (data_config.py:13)")
+    items = []
+    with open(collector_path + "_" + part + ".json", encoding="utf-8") as reader:
+        for line in reader:
+            if line.strip():
+                rec = json.loads(line)
+                items.append((rec["wave"], rec["tgt"]))
+    ds = WaveDataset(items, vocab, sample_rate=sample_rate)
+    parser = AudioParser(sample_rate=sample_rate, n_mels=n_mels, lfr_m=lfr_m, lfr_n=lfr_n, device="cuda")
+    return BucketedWaveLoader(ds, batch_size, parser=parser, augment=augment, shuffle=(part == "train") if shuffle is None else shuffle,
+                              drop_last=True, seed=seed, dtype=dtype, rank=rank, world=world)

@@ -13,9 +13,14 @@ MI355X-first design:
     wholly above the mark is all-reduced on a separate communication stream while backward continues;
   * xGMI is point-to-point (7 links per GPU): a few large buckets (default 16 MB) keep each
     transfer bandwidth-bound rather than latency-bound;
-  * the loss normalisers are made global BEFORE backward (token count all-reduced, CTC divided by
-    the global batch), so the summed gradients equal a single-process run on the concatenated
-    batch - no post-scaling pass over the gradients;
+  * the loss normalisers are made global BEFORE backward, so the summed gradients equal a single-process run on
+    the concatenated batch - no post-scaling pass over the gradients: the all-reduce of [non-pad token count,
+    local batch size] is started on the communication stream at the START of the step and the compute stream waits
+    for it only where the loss kernels need it (after the forward pass): neither the host nor the GPU ever idles on
+    it, and ranks may hold different local batch sizes (both kernels take their divisor from device memory);
+  * the wire format of the buckets is bf16 for bf16 models (67.6 MB per step at 33.8 M parameters instead of
+    135 MB; xGMI rings are per-link bound): cast on the communication stream, summed by RCCL, cast back into the
+    fp32 gradient buffer; fp32 models (parity mode) and ASR_DP_WIRE=fp32 keep fp32 on the wire;
   * the clip norm is computed on the reduced gradients, identical on every rank.
 """
 import os
@@ -59,9 +64,11 @@ def make_buckets(block_ranges, numel, bucket_elems, force_cuts=()):
 
 
 class GradBucketer:
-    """All-reduces `flat_g` bucket by bucket as `ready(offset)` marks move down."""
+    """All-reduces `flat_g` bucket by bucket as `ready(offset)` marks move down.
+    wire_dtype torch.bfloat16: each bucket travels as bf16 (cast -> all-reduce -> cast back, all on the
+    communication stream); None / torch.float32: the fp32 slice itself is reduced in place."""
 
-    def __init__(self, flat_g, block_ranges, bucket_bytes=32 << 20, group=None, force_cuts=()):
+    def __init__(self, flat_g, block_ranges, bucket_bytes=32 << 20, group=None, force_cuts=(), wire_dtype=None):
         self.g = flat_g
         self.group = group
         self.buckets = make_buckets(block_ranges, flat_g.numel(), max(1, bucket_bytes // flat_g.element_size()), force_cuts)
@@ -70,8 +77,14 @@ class GradBucketer:
         # doubled the step time on MI355X / ROCm 7 (11.0 vs 5.2 ms, measured with one rank)
         prio = int(os.environ.get("ASR_COMM_PRIORITY", "0"))
         self.comm_stream = torch.cuda.Stream(priority=prio) if self.cuda else None
+        self.wire = None
+        if wire_dtype is not None and wire_dtype != flat_g.dtype:
+            if not self.cuda:
+                raise ValueError("a reduced-precision wire format needs the gradients on the GPU (the casts are HIP kernels)")
+            self.wire = torch.empty(flat_g.numel(), dtype=wire_dtype, device=flat_g.device)
         self.next = 0
         self.works = []
+        self.bytes_on_wire = sum((e - s) for s, e in self.buckets) * (self.wire.element_size() if self.wire is not None else flat_g.element_size())
 
     def begin(self):
         self.next = 0
@@ -80,15 +93,24 @@ class GradBucketer:
     def _launch(self, i, streams=None):
         s, e = self.buckets[i]
         view = self.g[s:e]
-        if self.cuda:
-            for st in (streams or [torch.cuda.current_stream()]):   # producers of these gradients
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
+        if not self.cuda:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        for st in (streams or [torch.cuda.current_stream()]):   # producers of these gradients
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            # blocking-style calls: with the RCCL backend "wait" orders the communication stream behind the collective,
+            # the host does not block (gloo, used by the one-GPU tests, does block the host: correctness only)
+            if self.wire is None:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                from . import kernels as K
+                w = self.wire[s:e]
+                K.cast(view, w)
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                K.cast(w, view)
 
     def ready(self, offset, streams=None):
         """Gradients at flat offsets >= offset are final (after the work already queued on
@@ -103,29 +125,66 @@ class GradBucketer:
         for w in self.works:
             w.wait()
         self.works = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class _Counts:
+    """The step's global normalisers: [non-pad token count, batch size] summed over the ranks, all-reduced on the
+    communication stream while the forward pass runs."""
+
+    def __init__(self, buf, comm_stream, group):
+        self.buf, self.comm, self.group = buf, comm_stream, group
+        self.event = None
+
+    def start(self, n_valid, B):
+        """n_valid: 1-element f32 device tensor of this rank (written on the current stream); B: local batch size."""
+        cur = torch.cuda.current_stream()
+        self.buf[0:1].copy_(n_valid)
+        self.buf[1].fill_(float(B))
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.event = torch.cuda.Event()
+            self.event.record(self.comm)
+        return self
+
+    def wait(self):
+        """(global token count, global batch size) as 1-element device tensors; the current stream waits for them."""
+        torch.cuda.current_stream().wait_event(self.event)
+        return self.buf[0:1], self.buf[1:2]
 
 
 class DataParallel:
-    """Wraps a model built on engine.FlatParams; `iterate` has the reference's signature."""
+    """Wraps a model built on engine.FlatParams; `iterate` has the reference's signature, every other attribute
+    (config, train(), eval(), save(), load(), parameters(), ...) is the wrapped model's, as with the reference's
+    Wrapper (Predictor/Bases/base_model.py:9-21)."""
 
-    def __init__(self, model, device, bucket_bytes=16 << 20, reduce_loss=False):
+    def __init__(self, model, device, bucket_bytes=16 << 20, reduce_loss=False, wire_dtype="auto", group=None):
         self.model = model
         self.reduce_loss = reduce_loss
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         eng = model._ensure_engine(device)
         flat = model._flat
-        dist.broadcast(flat.p, src=0)          # identical replicas
+        dist.broadcast(flat.p, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)          # identical replicas
         flat.refresh_lowp()
+        if wire_dtype == "auto":      # bf16 models send bf16 gradients; ASR_DP_WIRE=fp32|bf16 overrides
+            env = os.environ.get("ASR_DP_WIRE", "")
+            wire_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(env, torch.bfloat16 if flat.lp is not None else torch.float32)
         # The all-reduce of the last bucket (lowest offsets = first encoder layer + input projection) starts when
         # backward ends and is fully exposed: cut it at the feed-forward block of encoder layer 0, whose gradients
         # are final one block earlier (the engine raises a mark there), so only ~4 MB remain for the very end.
         tail = eng.tail_mark_name()
-        self.bucketer = GradBucketer(flat.g, flat.block_range, bucket_bytes, force_cuts=[flat.index[tail][0]] if tail else ())
+        self.bucketer = GradBucketer(flat.g, flat.block_range, bucket_bytes, group=group, force_cuts=[flat.index[tail][0]] if tail else (),
+                                     wire_dtype=wire_dtype)
+        self._counts = _Counts(torch.zeros(2, dtype=torch.float32, device=flat.g.device), self.bucketer.comm_stream, group)
         eng.grad_ready = self.bucketer.ready
 
-    def _global_count(self, n_valid):
-        dist.all_reduce(n_valid, op=dist.ReduceOp.SUM)
-        return n_valid
+    def __getattr__(self, name):           # only called when normal lookup fails: forward to the wrapped model
+        return getattr(self.__dict__["model"], name)
 
     def iterate(self, input, optimizer=None, is_train=True):
         model = self.model
@@ -136,9 +195,7 @@ class DataParallel:
         model.zero_flat_grads()
         self.bucketer.begin()
         B = input.wave.shape[0]
-        # the token count only normalises the CE term: the CTC-only model needs no count exchange
-        loss, pg = model.train_step(input, n_valid_override=self._global_count if model.use_decoder else None,
-                                    ctc_batch=B * self.world)
+        loss, pg = model.train_step(input, count_hook=self._counts.start)
         self.bucketer.finish()
         optimizer.fused_step(model._flat, CLIP_NORM)
         cer = model._cer_ids(pg[0], pg[1]) if pg is not None else None      # of this rank's utterances, computed on the device
@@ -148,11 +205,13 @@ class DataParallel:
             if cer is not None:
                 metrics.add(cer=cer)
             return metrics, None
-        # CE was normalised by the GLOBAL token count (sum over ranks = global CE); the CTC term
-        # reported by the kernel is per local batch (mean over ranks = global CTC)
-        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+        # CE was normalised by the GLOBAL token count (sum over ranks = global CE); the CTC term the kernel reports is
+        # the mean over the LOCAL batch: weight it by local / global batch before the sum over ranks
+        loss = loss.clone()
+        loss[2] = loss[2] * (float(B) / self._counts.buf[1])
+        dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
         lam = model.ctc_weight
-        ce, ctc = loss[1], loss[2] / self.world
+        ce, ctc = loss[1], loss[2]
         total = ((1.0 - lam) * ce if model.use_ctc else ce) if model.use_decoder else 0.0
         if model.use_ctc:
             total = total + lam * ctc

@@ -171,12 +171,12 @@ class Linear:
         return (self.gb is not None and dy.dtype == torch.bfloat16 and self.N % 8 == 0 and self.K % 8 == 0 and
                 dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0)
 
-    def wgrad(self, dy, x, with_bias=False):
+    def wgrad(self, dy, x, with_bias=False, ws=None):
         """gw += dy^T x  (fp32 accumulation into the flat gradient buffer); with_bias (only when
-        fused_bias_wgrad): also gb += column sums of dy, inside the same kernel."""
+        fused_bias_wgrad): also gb += column sums of dy, inside the same kernel.  ws: scratch for the deterministic mode."""
         M = x.shape[0]
         if dy.dtype == torch.bfloat16 and self.N % 8 == 0 and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
-            K.gemm_tn(dy, x, self.gw, accumulate=True, dbias=self.gb if with_bias else None)
+            K.gemm_tn(dy, x, self.gw, accumulate=True, dbias=self.gb if with_bias else None, ws=ws)
         elif dy.dtype == torch.bfloat16:
             self.gw.add_(torch.mm(dy.t(), x).float())
         else:
@@ -283,6 +283,13 @@ class Engine:
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
         self.overlap_wgrad = True
+        # Deterministic mode (kernels.set_deterministic / ASR_DETERMINISTIC=1, read when the engine is built): every
+        # gradient reduction runs in a fixed order.  The weight gradients then stay on the main stream (the tied
+        # embedding / projection weight is updated by plain read-modify-writes of two kernels, which must not overlap),
+        # one launch per projection (the grouped kernel has only the atomic form).
+        self.deterministic = K.deterministic()
+        if self.deterministic:
+            self.overlap_wgrad = False
         # ASR_WGRAD_GROUP: "decoder" (default): the seven weight gradients of a DECODER layer (self-attention, cross
         # attention incl. the K|V projection of all encoder frames, feed-forward) go out as ONE grouped GEMM
         # (asr_gemm_tn_grouped_bf16) - the decoder's main stream is a chain of small launches (B*To rows) that
@@ -292,7 +299,7 @@ class Engine:
         # per config-2 layer) but one 100-us launch filling every CU overlaps worse with the main stream than
         # four short ones spread over the layer: step 3.84 (layer) / 3.96 (block) vs 3.79 ms, joint 6.27 vs 6.16.
         self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "decoder")
-        self.group_wgrad = None if self.group_wgrad == "0" else self.group_wgrad
+        self.group_wgrad = None if (self.group_wgrad == "0" or self.deterministic) else self.group_wgrad
         self._pending = []
         self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
         self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
@@ -415,7 +422,7 @@ class Engine:
         if not self.overlap_wgrad:
             if bias_from is not None and not fused:
                 lin.bgrad(bias_from, self.ws_side)
-            lin.wgrad(dy, x, with_bias=fused)
+            lin.wgrad(dy, x, with_bias=fused, ws=self.ws_side)
             return
         ev = self._event()
         ev.record()
@@ -426,7 +433,7 @@ class Engine:
             try:
                 if bias_from is not None and not fused:
                     lin.bgrad(bias_from, self.ws_side)
-                lin.wgrad(dy, x, with_bias=fused)
+                lin.wgrad(dy, x, with_bias=fused, ws=self.ws_side)
             finally:
                 K.STREAM_OVERRIDE = None
         else:
@@ -552,18 +559,18 @@ class Engine:
         dz, _ = self._ln_bwd(self.ln_in, self.lin_in.gb, dy, dy2, cache["xhat_in"], cache["rstd_in"], None, B, T, drop_p=p0, drop_seed=s0, drop_mode=2)
         # the last weight gradient runs on the MAIN stream: the side stream is still busy with layer 0,
         # and a cross-stream hand-over costs ~20 us of latency that nothing would hide at this point
-        self.lin_in.wgrad(dz, cache["x_in"])      # A/B: 8.50 vs 8.45 k utt/s
+        self.lin_in.wgrad(dz, cache["x_in"], ws=self.ws)      # A/B: 8.50 vs 8.45 k utt/s
         self._block_flush = self.group_wgrad == "block"
         self.flush_ln_reduce()
         self.join_side()
         self._ready("encoder.linear_in.weight")
 
     # ------------------------------------------------------------------ CTC head
-    def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True):
+    def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None):
         """Returns (nll (B,), d_enc contribution or None)."""
         logits = self.ctc_lo.fwd(enc)
         nll, dl = K.ctc_fwd_bwd(logits.view(B, T, self.V), wave_len, labels32, lab_len, self.ws, blank=0, grad_scale=grad_scale,
-                                dlogits=logits.view(B, T, self.V) if want_grad else None, want_grad=want_grad)
+                                dlogits=logits.view(B, T, self.V) if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div)
         if not want_grad:
             return nll, None
         dl = dl.view(B * T, self.V)

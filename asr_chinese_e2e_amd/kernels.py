@@ -41,8 +41,24 @@ def _stream():
     if STREAM_OVERRIDE is not None:
         return ctypes.c_void_p(STREAM_OVERRIDE)
     if _DEV_INDEX is None:
-        _DEV_INDEX = torch.cuda.current_device()   # one process per GPU: set once (dist.init / .cuda()) before the first launch
+        _DEV_INDEX = torch.cuda.current_device()   # one process per GPU: bind_device() (engine construction) or the first launch sets it
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
+
+
+def bind_device(device):
+    """One process drives ONE GPU: the launch stream is looked up on this device from now on.  Called when a model
+    builds its engine; a model on a device other than torch's current one is refused (its kernels would be issued
+    on the current device's stream against the other device's memory)."""
+    global _DEV_INDEX
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx != torch.cuda.current_device():
+        raise RuntimeError(f"the model lives on cuda:{idx} but torch's current device is cuda:{torch.cuda.current_device()}: call "
+                           f"torch.cuda.set_device({idx}) first (one process per GPU)")
+    if _DEV_INDEX is not None and _DEV_INDEX != idx:
+        raise RuntimeError(f"this process already launches on cuda:{_DEV_INDEX}; a second GPU (cuda:{idx}) needs its own process")
+    _DEV_INDEX = idx
 
 
 def _chk_f32(*ts):
@@ -58,41 +74,44 @@ def _chk_i32(*ts):
 
 
 class LaunchTimer:
-    """HIP-event timing of selected launches on the stream they are issued on (bench.py's
-    roofline leg).  `work` is the algorithmic flop (or byte) count of the launch."""
+    """HIP-event timing of selected launches on the stream they are issued on (bench.py's roofline / kernels
+    legs).  `work` is the algorithmic FLOP count of the launch, `nbytes` its algorithmic HBM bytes (0 = not stated)."""
 
     def __init__(self, names):
         self.names = set(names)
         self.rec = {n: [] for n in names}
 
-    def run(self, name, work, fn):
+    def run(self, name, work, fn, nbytes=0.0):
         if name not in self.names:
             return fn()
+        st = torch.cuda.ExternalStream(STREAM_OVERRIDE) if STREAM_OVERRIDE is not None else None   # side-stream launches: record there
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(st) if st is not None else e0.record()
         out = fn()
-        e1.record()
-        self.rec[name].append((e0, e1, work))
+        e1.record(st) if st is not None else e1.record()
+        self.rec[name].append((e0, e1, work, nbytes))
         return out
 
     def summary(self):
-        """name -> dict(launches, total_ms, avg_us, work_per_s) (call after a device sync)."""
+        """name -> dict(launches, total_ms, avg_us, work_per_s, work_per_launch, bytes_per_s, bytes_per_launch)
+        (call after a device sync)."""
         out = {}
         for n, r in self.rec.items():
             if not r:
                 continue
-            ms = [a.elapsed_time(b) for a, b, _ in r]
-            tot, work = sum(ms), sum(w for _, _, w in r)
-            out[n] = dict(launches=len(r), total_ms=tot, avg_us=1e3 * tot / len(r), work_per_s=work / (tot * 1e-3) if tot > 0 else 0.0,
-                          work_per_launch=work / len(r))
+            ms = [a.elapsed_time(b) for a, b, _, _ in r]
+            tot, work, nb = sum(ms), sum(x[2] for x in r), sum(x[3] for x in r)
+            sec = tot * 1e-3
+            out[n] = dict(launches=len(r), total_ms=tot, avg_us=1e3 * tot / len(r), work_per_s=work / sec if tot > 0 else 0.0,
+                          work_per_launch=work / len(r), bytes_per_s=nb / sec if tot > 0 else 0.0, bytes_per_launch=nb / len(r))
         return out
 
 
 TIMER = None   # set to a LaunchTimer by bench.py
 
 
-def timed(name, work, fn):
-    return fn() if TIMER is None else TIMER.run(name, work, fn)
+def timed(name, work, fn, nbytes=0.0):
+    return fn() if TIMER is None else TIMER.run(name, work, fn, nbytes)
 
 
 class Workspace:
@@ -128,8 +147,10 @@ def add_ln_fwd(x, res, gamma, beta, pe, lens, B, T, y=None, xhat=None, rstd=None
     y = torch.empty_like(x) if y is None else y
     xhat = torch.empty_like(x) if xhat is None else xhat
     rstd = torch.empty(B * T, dtype=torch.float32, device=x.device) if rstd is None else rstd
-    check(lib.asr_add_ln_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(pe), _p(lens), _p(y), _p(xhat), _p(rstd),
-                             B, T, d, float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_mode), _dt(x), _stream()), "asr_add_ln_fwd")
+    nb = (3 + (res is not None)) * x.numel() * x.element_size()      # x, (res), y, xhat: SURVEY 8(d) "LN/add/mask"
+    timed("add_ln_fwd", 0.0, lambda: check(
+        lib.asr_add_ln_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(pe), _p(lens), _p(y), _p(xhat), _p(rstd),
+                           B, T, d, float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_mode), _dt(x), _stream()), "asr_add_ln_fwd"), nb)
     return y, xhat, rstd
 
 
@@ -154,9 +175,11 @@ def add_ln_bwd(dy, dy2, xhat, rstd, gamma, lens, dgamma, dbeta, dbias, B, T, ws,
         w, dgamma, dbeta = partials, None, None
     else:
         w = ws.get(nbytes)
-    check(lib.asr_add_ln_bwd(_p(dy), _p(dy2), _p(xhat), _p(rstd), _p(gamma), _p(lens), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
-                             _p(dbias), _p(w), w.numel(), B, T, d, float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_mode),
-                             _dt(dy), _stream()), "asr_add_ln_bwd")
+    nb = (3 + (dy2 is not None) + (dx is not None)) * dy.numel() * dy.element_size()     # dy, (dy2), xhat, dz, (dx)
+    timed("add_ln_bwd", 0.0, lambda: check(
+        lib.asr_add_ln_bwd(_p(dy), _p(dy2), _p(xhat), _p(rstd), _p(gamma), _p(lens), _p(dz), _p(dx), _p(dgamma), _p(dbeta),
+                           _p(dbias), _p(w), w.numel(), B, T, d, float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_mode),
+                           _dt(dy), _stream()), "asr_add_ln_bwd"), nb)
     return dz, (dx if dx is not None else dz)
 
 
@@ -195,8 +218,11 @@ def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=No
     ldo = _strided_rows(o, H, dk)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if lse is None else lse
     scale = float(dk) ** -0.5 if scale is None else float(scale)
-    check(lib.asr_sdpa_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(k_len), B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo,
-                           int(causal), int(window), scale, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_fwd")
+    e = q.element_size()
+    timed("sdpa_fwd", 4.0 * B * H * Tq * Tk * dk, lambda: check(
+        lib.asr_sdpa_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(k_len), B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo,
+                         int(causal), int(window), scale, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_fwd"),
+          2.0 * B * H * (Tq + Tk) * dk * e)          # Q, O + K, V (4 B H T dk e at Tq = Tk)
     return o, lse
 
 
@@ -210,16 +236,20 @@ def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=F
     _chk_f32(lse)
     delta = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if delta is None else delta
     scale = float(dk) ** -0.5 if scale is None else float(scale)
-    check(lib.asr_sdpa_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk_), _p(dv), _p(k_len),
-                           B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, int(causal), int(window), scale, float(drop_p),
-                           int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_bwd")
+    e = q.element_size()
+    timed("sdpa_bwd", 10.0 * B * H * Tq * Tk * dk, lambda: check(
+        lib.asr_sdpa_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk_), _p(dv), _p(k_len),
+                         B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, int(causal), int(window), scale, float(drop_p),
+                         int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_bwd"),
+          B * H * (4.0 * Tq + 4.0 * Tk) * dk * e)    # Q, O, dO, dQ + K, V, dK, dV (8 x 16.4 MB at config 2); 5 products
     return dq, dk_, dv
 
 
 # --------------------------------------------------------------------------------- losses
 def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, zero_infinity=False, dlogits=None,
-                want_grad=True, nll=None):
-    """logits (B,T,V); returns (nll (B,), dlogits or None).  dlogits may alias logits."""
+                want_grad=True, nll=None, grad_scale_div=None):
+    """logits (B,T,V); returns (nll (B,), dlogits or None).  dlogits may alias logits.
+    grad_scale_div: optional 1-element f32 device tensor; the gradient scale is then grad_scale / grad_scale_div[0]."""
     B, T, V = logits.shape
     assert logits.is_contiguous()
     _chk_i32(in_len, labels, lab_len)
@@ -231,9 +261,12 @@ def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, ze
     if dlogits is not None:
         assert dlogits.is_contiguous() and dlogits.shape == logits.shape and dlogits.dtype == logits.dtype
     w = ws.get(lib.asr_ctc_workspace_bytes(B, T, Lmax))
-    check(lib.asr_ctc_fwd_bwd(_p(logits), _p(dlogits), _p(in_len), _p(labels), _p(lab_len), _p(nll), B, T, V, Lmax,
-                              int(blank), float(grad_scale), int(zero_infinity), _p(w), w.numel(), _dt(logits), _stream()),
-          "asr_ctc_fwd_bwd")
+    _chk_f32(grad_scale_div)
+    timed("ctc", 0.0, lambda: check(
+        lib.asr_ctc_fwd_bwd(_p(logits), _p(dlogits), _p(in_len), _p(labels), _p(lab_len), _p(nll), B, T, V, Lmax,
+                            int(blank), float(grad_scale), _p(grad_scale_div), int(zero_infinity), _p(w), w.numel(), _dt(logits), _stream()),
+        "asr_ctc_fwd_bwd"), (3.0 if dlogits is not None else 1.0) * logits.numel() * logits.element_size())   # 3 B T V e
+
     return nll, dlogits
 
 
@@ -292,8 +325,10 @@ def xent_fwd_bwd(logits, gold, n_valid, ignore_index=0, smoothing=0.0, grad_scal
     row_nll = torch.empty(M, dtype=torch.float32, device=logits.device) if row_nll is None else row_nll
     if want_grad and dlogits is None:
         dlogits = torch.empty_like(logits)
-    check(lib.asr_xent_fwd_bwd(_p(logits), _p(gold), _p(n_valid), _p(row_nll), _p(dlogits), M, V, int(ignore_index),
-                               float(smoothing), float(grad_scale), _dt(logits), _stream()), "asr_xent_fwd_bwd")
+    timed("xent", 0.0, lambda: check(
+        lib.asr_xent_fwd_bwd(_p(logits), _p(gold), _p(n_valid), _p(row_nll), _p(dlogits), M, V, int(ignore_index),
+                             float(smoothing), float(grad_scale), _dt(logits), _stream()), "asr_xent_fwd_bwd"),
+          (3.0 if dlogits is not None else 1.0) * logits.numel() * logits.element_size())                      # 3 M V e
     return row_nll, dlogits
 
 
@@ -395,7 +430,7 @@ def cast(src, dst):
 def grad_sumsq(g, out, ws):
     _chk_f32(g, out)
     w = ws.get(lib.asr_sumsq_workspace_bytes(g.numel()))
-    check(lib.asr_grad_sumsq(_p(g), g.numel(), _p(out), _p(w), w.numel(), _stream()), "asr_grad_sumsq")
+    timed("grad_sumsq", 0.0, lambda: check(lib.asr_grad_sumsq(_p(g), g.numel(), _p(out), _p(w), w.numel(), _stream()), "asr_grad_sumsq"), 4.0 * g.numel())
     return out
 
 
@@ -413,8 +448,11 @@ def adam_step(p, g, m, v, p_lp, hyper, sumsq, max_norm, b1, b2, eps, write_clipp
     assert g.numel() == n and m.numel() == n and v.numel() == n
     if p_lp is not None:
         assert p_lp.dtype == torch.bfloat16 and p_lp.numel() == n and p_lp.is_contiguous()
-    check(lib.asr_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, _p(hyper), _p(sumsq), float(max_norm), float(b1),
-                            float(b2), float(eps), int(write_clipped), _stream()), "asr_adam_step")
+    # p, g, m, v read + p, m, v (+ clipped g) written in fp32, bf16 shadow written: 28 (+4) (+2) B per parameter (~30)
+    timed("adam", 0.0, lambda: check(
+        lib.asr_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_lp), n, _p(hyper), _p(sumsq), float(max_norm), float(b1),
+                          float(b2), float(eps), int(write_clipped), _stream()), "asr_adam_step"),
+          (28.0 + (4.0 if write_clipped else 0.0) + (2.0 if p_lp is not None else 0.0)) * n)
 
 
 # --------------------------------------------------------------------------------- GEMM
@@ -446,17 +484,32 @@ def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None, family="gemm_nt"):
     return out
 
 
-def gemm_tn(dy, x, dw, accumulate=True, dbias=None):
-    """dw (N,K) f32 (+)= dy (M,N)^T @ x (M,K); bf16 operands, MFMA kernel.  dbias (N) f32 += column sums of dy."""
+def deterministic():
+    """True when the library's reductions run in a fixed order (asr_set_deterministic / ASR_DETERMINISTIC=1)."""
+    return bool(lib.asr_get_deterministic())
+
+
+def set_deterministic(on):
+    """Process-wide switch (see include/asr_hip.h); returns the previous value.  Engines read it when they are built."""
+    return bool(lib.asr_set_deterministic(int(bool(on))))
+
+
+def gemm_tn(dy, x, dw, accumulate=True, dbias=None, ws=None):
+    """dw (N,K) f32 (+)= dy (M,N)^T @ x (M,K); bf16 operands, MFMA kernel.  dbias (N) f32 += column sums of dy.
+    ws: a Workspace - needed in deterministic mode only (partial slabs, one per M-split)."""
     assert dy.dtype == x.dtype == torch.bfloat16 and dw.dtype == torch.float32
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dw.shape == (N, K) and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
     _chk_f32(dbias)
     assert dbias is None or dbias.numel() == N
+    need = lib.asr_gemm_tn_workspace_bytes(M, N, K)
+    w = None
+    if need:
+        w = ws.get(need) if ws is not None else torch.empty(need, dtype=torch.uint8, device=dy.device)
     timed("gemm_tn", 2.0 * M * N * K, lambda: check(
-        lib.asr_gemm_tn_bias_bf16(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), None, 0,
-                                  _stream()), "asr_gemm_tn_bias_bf16"))
+        lib.asr_gemm_tn_bias_bf16(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), int(accumulate), _p(w),
+                                  w.numel() if w is not None else 0, _stream()), "asr_gemm_tn_bias_bf16"))
     return dw
 
 

@@ -1,43 +1,52 @@
 #!/usr/bin/env python3
-"""bench.py - utterances/s of the full training step (fwd + CTC loss + bwd + clip + Noam/Adam).
+"""bench.py - utterances/s of the full training step (fwd + loss + bwd + grad all-reduce + clip + Noam/Adam).
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py
-  (one rank per GPU over RCCL).  W untimed warm-up steps, then EXACTLY K timed steps bracketed by
-  barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+  N > 1: either the driver launches  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  (one rank per GPU over RCCL; RANK / LOCAL_RANK / WORLD_SIZE in the environment), or - when WORLD_SIZE is NOT set -
+  this script starts those N ranks itself as a child `torch.distributed.run` BEFORE it touches the GPU (the parent
+  never initialises HIP and never execs) and passes the child's single JSON line through.
+  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + torch.cuda.synchronize() on both
+  sides, MAX over ranks, rank 0 prints ONE JSON line.  `n_gpus` is the number of ranks the process group formed.
 
-Workload at N=1 = BASELINE.json configs[1]: 6-layer Transformer encoder + CTC-only, bf16,
-batch 32, T=500, F=80, V=4232 (AISHELL-1 char vocab size), synthetic N(0,1) features, random-init
-weights.  --config joint runs configs[2] (encoder-decoder, lambda=0.3) instead.
-Weak scaling: every rank processes its own 32-utterance batch.
+Workload
+  N = 1: BASELINE.json configs[1]: 6-layer Transformer encoder + CTC-only, bf16, batch 32, T=500, F=80, V=4232,
+         synthetic N(0,1) features, random-init weights.  Extra keys: the joint model (configs[2]) and the
+         reference's dropout 0.1 recipe timed the same way.
+  N > 1: BASELINE.json configs[3]: joint CTC/attention (lambda = 0.3) encoder-decoder, 32 utterances per GPU
+         (weak scaling), bucketed RCCL all-reduce overlapped with backward.   --config ctc|joint overrides.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel family (MFMA GEMMs), algorithmic FLOP / HIP-event time of its
-                launches inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  roofline      dominant kernel family (MFMA GEMMs), algorithmic FLOP / HIP-event time of its launches, against the
+                dense bf16 MFMA peak (2.5 PFLOP/s).
+  kernels       per kernel family, HIP-event timed on the stream it is launched on: launches, us, algorithmic
+                bytes and FLOP per launch (SURVEY.md 8(d) figures), HBM GB/s and fraction of 8 TB/s, TFLOP/s and
+                fraction of the MFMA peak for the matrix kernels.
   cpu_baseline  the CPU oracle (oracle/ref_model.RefTrainer: op-for-op port of the reference's
                 TransformerOffical.iterate + CTC) timed on this host's cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--config", default="ctc", choices=["ctc", "joint"])
+    ap.add_argument("--config", default=None, choices=["ctc", "joint"], help="default: ctc (configs[1]) on one GPU, joint (configs[3]) on several")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--layers", type=int, default=6)
@@ -50,8 +59,11 @@ def parse():
                     "reference's iterate does (on the device: asr_cer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (joint model, dropout 0.1)")
+    ap.add_argument("--cpu-sample-batch", type=int, default=32)
+    ap.add_argument("--plumbing", action="store_true", help="tests only: form the process group, exchange one tensor, print the line "
+                    "skeleton - no GPU work (drives the N-rank launcher on a CPU-only machine)")
+    return ap.parse_args(argv)
 
 
 def host_cores():
@@ -77,14 +89,36 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(args):
-    """Oracle ('port') timed on the host cores: same model/shape, a bounded sample (batch 8)."""
+def launch_ranks(args):
+    """WORLD_SIZE unset and --gpus N > 1: run the N ranks as a child torch.distributed.run.  The parent has not
+    touched the GPU (no HIP call, not even torch.cuda.is_available()) and does not exec: it waits and relays."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log(f"WORLD_SIZE not set: starting {args.gpus} ranks: {' '.join(cmd)}")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in p.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(p.stdout.decode("utf-8", "replace"))
+        raise SystemExit(p.returncode or 1)
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
+def cpu_baseline(args, config):
+    """Oracle ('port') timed on the host cores: same model/shape (3 warm-up + >= 5 timed steps)."""
+    import torch
     from oracle import ref_model as R
     from asr_chinese_e2e_amd.data_handler import synthetic_pack
     torch.set_num_threads(host_cores())
     cores = torch.get_num_threads()
     log(f"cpu baseline on {cores} threads (affinity {len(os.sched_getaffinity(0))})")
-    joint = args.config == "joint"
+    joint = config == "joint"
     cfg = R.default_cfg(n_mels=80, lfr_m=1, layer_num=args.layers, use_decoder=joint, ctc_weight=0.3 if joint else 1.0)
     sd = R.init_state_dict(cfg, args.vocab, seed=0)
     tr = R.RefTrainer(sd, cfg, warmup=4000, id2token=[str(i) for i in range(args.vocab)])
@@ -92,25 +126,27 @@ def cpu_baseline(args):
     pack = synthetic_pack(B, args.frames, 80, args.vocab, seed=1234)
     batch = {k: pack[k] for k in ("wave", "wave_len", "tgt_for_input", "tgt_len")}
     tw = time.time()
-    tr.iterate(batch, loop_masks=True, with_cer=joint)            # warm-up
-    log(f"cpu warm-up step {time.time() - tw:.1f} s")
+    n_warm = 0
+    while n_warm < 3 and (n_warm < 1 or time.time() - tw < 20.0):   # 3 warm-up steps unless they alone exceed ~20 s
+        tr.iterate(batch, loop_masks=True, with_cer=joint)
+        n_warm += 1
+    log(f"cpu warm-up: {n_warm} steps, {time.time() - tw:.1f} s")
     n, t0 = 0, time.time()
-    while n < 2 or (time.time() - t0 < 10.0 and n < 6):
+    while n < 5 or (time.time() - t0 < 10.0 and n < 8):
         tr.iterate(batch, loop_masks=True, with_cer=joint)
         n += 1
         log(f"cpu step {n}: {time.time() - t0:.1f} s")
     dt = (time.time() - t0) / n
     return {"value": B / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of batch {B} x T={args.frames} (same {args.layers}-layer model, fp32, torch CPU, "
+            "sample": f"{n_warm} warm-up + {n} timed steps of batch {B} x T={args.frames} (same {args.layers}-layer model, fp32, torch CPU, "
                       f"python-loop masks as the reference), {dt:.2f} s/step"}
 
 
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed PMC summary (None if absent)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    pat = {"gemm_nt": "gemm_nt", "gemm_tn": "gemm_tn", "lib_gemm_dgrad": "Cijk"}[family]
+    pat = {"gemm_nt": "gemm_nt", "gemm_tn": "gemm_tn", "lib_gemm_dgrad": "Cijk"}.get(family, family)
     try:
-        table = json.load(open(path))
+        table = json.load(open(PMC_TRAFFIC_FILE))
     except (OSError, ValueError):
         return None
     rows = [v for k, v in table.items() if pat in k]
@@ -118,118 +154,209 @@ def pmc_traffic(family):
     return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
 
 
+MATRIX_FAMILIES = ("gemm_nt", "gemm_tn", "lib_gemm_dgrad", "sdpa_fwd", "sdpa_bwd")
+KERNEL_NAMES = {"gemm_nt": "gemm_nt_persist_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
+                "lib_gemm_dgrad": "hipBLASLt GEMM (input gradients not on the own kernel)", "sdpa_fwd": "sdpa_fwd_bf16_kernel (asr_sdpa_fwd)",
+                "sdpa_bwd": "sdpa_bwd kernels (asr_sdpa_bwd)", "add_ln_fwd": "add_ln_fwd_kernel", "add_ln_bwd": "add_ln_bwd_kernel",
+                "ctc": "ctc_lse_gather_rows + ctc_alpha_beta + ctc_label_fix (asr_ctc_fwd_bwd)", "xent": "xent_kernel", "adam": "adam_kernel (asr_adam_step)",
+                "grad_sumsq": "sumsq kernels (asr_grad_sumsq)"}
+
+
+class Run:
+    """One model + optimizer + batch on this rank, and the timed loop over it."""
+
+    def __init__(self, args, config, dropout, rank, dev, use_dp):
+        import torch
+        from asr_chinese_e2e_amd import Models
+        from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+        from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+        self.torch, self.args, self.joint, self.use_dp = torch, args, config == "joint", use_dp
+        Model = Models.TransformerOffical if self.joint else Models.TransformerCTC
+        cfg = Model.get_default_config()()
+        cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=dropout, layer_num=args.layers, ctc_weight=0.3 if self.joint else 1.0, dtype="bf16",
+                          attn_window=args.window, cer_in_iterate=args.cer, warm_up=4000))
+        torch.manual_seed(0)
+        self.model = Model(cfg, Vocab.synthetic(args.vocab)).to(dev)
+        self.opt = NoamOpt(cfg.d_model, 1, cfg.warm_up, FusedAdam(self.model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+        self.pack = synthetic_pack(args.batch, args.frames, 80, args.vocab, seed=1234 + rank, device=dev, dtype=torch.bfloat16)
+        self.runner, self.graphed, self.dp = self.model, False, None
+        if use_dp:
+            from asr_chinese_e2e_amd import dist as D
+            self.runner = self.dp = D.DataParallel(self.model, dev)
+        elif args.graph and dropout == 0.0:
+            from asr_chinese_e2e_amd.graph import GraphedModel
+            self.runner = GraphedModel(self.model)          # whole step as one hipGraph (single process, no dropout)
+            self.graphed = True
+        self.last = None
+
+    def barrier(self):
+        if self.use_dp:
+            self.torch.distributed.barrier()
+        self.torch.cuda.synchronize()
+
+    def steps(self, n, runner=None):
+        runner = runner or self.runner
+        for _ in range(n):
+            self.last, _ = runner.iterate(self.pack, optimizer=self.opt, is_train=True)
+
+    def timed(self, warmup, steps):
+        self.steps(warmup)
+        self.barrier()
+        t0 = time.perf_counter()
+        self.steps(steps)
+        self.barrier()
+        return time.perf_counter() - t0
+
+    def kernel_pass(self, n_inst):
+        """The SAME steps once more with HIP events around every launch of the listed kernel families (recorded on
+        the stream the kernel is launched on).  A separate pass: ~100 event pairs per step cost ~25 % wall time on
+        ROCm; the wgrad overlap is off so the durations are stand-alone."""
+        from asr_chinese_e2e_amd import kernels as K
+        timer = K.LaunchTimer(list(KERNEL_NAMES))
+        K.TIMER = timer
+        self.model._engine.overlap_wgrad = False
+        try:
+            self.steps(n_inst, runner=self.model if self.graphed else self.runner)   # events cannot be read back from a captured graph
+            self.barrier()
+        finally:
+            K.TIMER = None
+            self.model._engine.overlap_wgrad = not self.model._engine.deterministic
+        return timer.summary()
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args)                      # never returns
     # stdout carries exactly ONE line, the JSON result: libraries that write to file descriptor 1 (RCCL prints a
     # version banner when its first communicator is created) are sent to stderr for the whole run
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if env_world is not None and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or unset WORLD_SIZE and let bench.py start them)")
+    config = args.config or ("joint" if world > 1 else "ctc")
+    import torch
+
+    if args.plumbing:                           # launcher test on a CPU-only machine
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        formed = dist.get_world_size()
+        dist.barrier()
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"metric": "plumbing", "value": 0.0, "unit": "utterances/s", "n_gpus": formed, "steps": args.steps,
+                                             "warmup": args.warmup, "sum_of_ranks": float(t), "config": {"workload": config,
+                                             "global_batch": formed * args.batch, "parallelism": f"dp{formed}"}}) + "\n").encode())
+        dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    from asr_chinese_e2e_amd import Models, kernels as K
-    from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
-    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+    backend = os.environ.get("ASR_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_idx = local if backend == "nccl" else local % max(ndev, 1)   # "gloo": rehearse N ranks on a one-GPU box (they share the card)
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device("cuda", dev_idx)
     use_dp = world > 1 or os.environ.get("ASR_FORCE_DP") == "1"    # ASR_FORCE_DP: exercise the RCCL path with one rank
     if use_dp:
         from asr_chinese_e2e_amd import dist as D
-        D.init(os.environ.get("ASR_DIST_BACKEND", "nccl"))   # "gloo": rehearse N ranks on a one-GPU box (LOCAL_RANK=0 for all)
+        os.environ["LOCAL_RANK"] = str(dev_idx)
+        D.init(backend)
+        world = torch.distributed.get_world_size()      # the ranks the process group actually formed
 
-    joint = args.config == "joint"
-    Model = Models.TransformerOffical if joint else Models.TransformerCTC
-    cfg = Model.get_default_config()()
-    cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=args.dropout, layer_num=args.layers, ctc_weight=0.3 if joint else 1.0, dtype="bf16",
-                      attn_window=args.window, cer_in_iterate=args.cer, warm_up=4000))
-    torch.manual_seed(0)
-    model = Model(cfg, Vocab.synthetic(args.vocab)).to(dev)
-    adam = FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9)
-    opt = NoamOpt(cfg.d_model, 1, cfg.warm_up, adam)
-    pack = synthetic_pack(args.batch, args.frames, 80, args.vocab, seed=1234 + rank, device=dev, dtype=torch.bfloat16)
-    runner = model
-    graphed = False
-    if use_dp:
-        runner = D.DataParallel(model, dev)
-    elif args.graph and args.dropout == 0.0:
-        from asr_chinese_e2e_amd.graph import GraphedModel
-        runner = GraphedModel(model)          # whole step as one hipGraph (single process, no dropout)
-        graphed = True
-
-    def barrier():
-        if use_dp:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    last = None
-    log(f"rank {rank}/{world}: model on {dev}, warm-up {args.warmup} steps")
-    for _ in range(args.warmup):
-        last, _ = runner.iterate(pack, optimizer=opt, is_train=True)
-    barrier()
-    log("warm-up done")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last, _ = runner.iterate(pack, optimizer=opt, is_train=True)
-    barrier()
-    dt = time.perf_counter() - t0
+    run = Run(args, config, args.dropout, rank, dev, use_dp)
+    log(f"rank {rank}/{world}: {config} model on {dev}, warm-up {args.warmup} steps")
+    dt = run.timed(args.warmup, args.steps)
     log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
-    # Roofline leg: the SAME steps once more with HIP events around every launch of the GEMM
-    # families (events are recorded on the stream the kernels are launched on).  It is a separate
-    # pass because ~80 event pairs per step cost ~25 % wall time on ROCm; `value` above is from the
-    # un-instrumented region.  rocprofv3 (profiles/) cross-checks the per-kernel durations.
-    timer = None
+    summary, n_inst = None, min(args.steps, 10)
     if not args.no_kernel_timer:
-        timer = K.LaunchTimer(["gemm_nt", "gemm_tn", "lib_gemm_dgrad"])
-        K.TIMER = timer
-        n_inst = min(args.steps, 10)
-        model._engine.overlap_wgrad = False   # standalone kernel durations (concurrent streams inflate them)
-        inst_runner = model if graphed else runner          # events cannot be read back from a captured graph
-        for _ in range(n_inst):
-            inst_runner.iterate(pack, optimizer=opt, is_train=True)
-        barrier()
-        K.TIMER = None
-        model._engine.overlap_wgrad = True
+        summary = run.kernel_pass(n_inst)
     if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    loss = float(last.loss)
+    loss = float(run.last.loss)
+    joint, graphed = run.joint, run.graphed
+    wire = None
+    if run.dp is not None:
+        wire = {"bytes_per_step": run.dp.bucketer.bytes_on_wire, "buckets": len(run.dp.bucketer.buckets),
+                "dtype": "bf16" if run.dp.bucketer.wire is not None else "fp32", "backend": backend}
+
+    extras = {}
+    if world == 1 and not use_dp and not args.no_extras and rank == 0:
+        # the other single-GPU configurations, timed the same way (shorter): configs[2] and the reference's dropout recipe
+        del run
+        torch.cuda.empty_cache()
+        es, ew = max(10, min(args.steps, 50)), max(5, min(args.warmup, 15))
+        other = "joint" if config == "ctc" else "ctc"
+        r2 = Run(args, other, args.dropout, rank, dev, False)
+        d2 = r2.timed(ew, es)
+        extras[f"{other}_ms_per_step"] = 1e3 * d2 / es
+        extras[f"{other}_utterances_per_s"] = args.batch * es / d2
+        del r2
+        torch.cuda.empty_cache()
+        if args.dropout == 0.0:
+            r3 = Run(args, config, 0.1, rank, dev, False)
+            d3 = r3.timed(ew, es)
+            extras["dropout_0.1_ms_per_step"] = 1e3 * d3 / es      # reference recipe: transformer_official.py:115-122
+            extras["dropout_0.1_utterances_per_s"] = args.batch * es / d3
+            del r3
+            torch.cuda.empty_cache()
+        log(f"extras: {extras}")
 
     if rank == 0:
         utt = world * args.batch * args.steps / dt
+        step_ms = 1e3 * dt / args.steps
         out = {
             "metric": "training throughput (utterances/s; frames/s = x T), AISHELL-1-shaped 80-mel T=500",
             "value": utt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "frames_per_s": utt * args.frames, "final_loss": loss,
-            "config": {"workload": ("configs[2]: joint CTC/attention (lambda=0.3) encoder-decoder" if joint else
+            "config": {"workload": (("configs[3]: data-parallel " if world > 1 else "configs[2]: ") + "joint CTC/attention (lambda=0.3) encoder-decoder" if joint else
                                     "configs[1]: 6-layer Transformer encoder + CTC-only") +
                                    f", bf16, per-GPU batch {args.batch}, T={args.frames}, F=80, V={args.vocab}, "
                                    f"{args.layers} layers, d_model 512, 8x64 heads, ff 1024, dropout {args.dropout}, "
-                                   "fwd+loss+bwd+clip+Noam/Adam per step" + (", one hipGraph per step" if graphed else ", eager launches"),
+                                   "fwd+loss+bwd+" + ("bucketed gradient all-reduce+" if use_dp else "") + "clip+Noam/Adam per step" +
+                                   (", one hipGraph per step" if graphed else ", eager launches"),
                        "global_batch": world * args.batch, "seq_len": args.frames, "parallelism": f"dp{world}"},
         }
-        if timer is not None:
-            s = timer.summary()
-            fam = {k: v for k, v in s.items()}
+        if wire is not None:
+            out["all_reduce"] = wire
+        out.update(extras)
+        if summary:
+            fam = {k: v for k, v in summary.items() if k in ("gemm_nt", "gemm_tn", "lib_gemm_dgrad")}
             dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
             if dom:
                 a = fam[dom]["work_per_s"] / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": {"gemm_nt": "gemm_nt_persist_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
-                                                               "lib_gemm_dgrad": "hipBLASLt GEMM (input gradients not on the own kernel)"}[dom],
+                out["roofline"] = {"bound": "mfma", "kernel": KERNEL_NAMES[dom],
                                    "achieved": a, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_BF16_PEAK_TFLOPS,
-                                   "traffic": pmc_traffic(dom), "traffic_source": "profiles/round1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command (separate runs), bytes per launch averaged over the family's launches, FETCH_SIZE x2 (gfx950 correction)",
+                                   "traffic": pmc_traffic(dom), "traffic_source": os.path.relpath(PMC_TRAFFIC_FILE, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command (separate runs), bytes per launch averaged over the family's launches, FETCH_SIZE x2 (gfx950 correction)",
                                    "avg_launch_us": fam[dom]["avg_us"], "launches": fam[dom]["launches"],
                                    "flop_per_launch": fam[dom]["work_per_launch"],
-                                   "share_of_step": fam[dom]["total_ms"] / n_inst / (1e3 * dt / args.steps)}
-                out["kernel_families"] = {k: {"tflops": v["work_per_s"] / 1e12, "avg_us": v["avg_us"], "launches": v["launches"],
-                                              "share_of_step": v["total_ms"] / n_inst / (1e3 * dt / args.steps)} for k, v in fam.items()}
+                                   "share_of_step": fam[dom]["total_ms"] / n_inst / step_ms}
+            table = {}
+            for k, v in summary.items():
+                row = {"kernel": KERNEL_NAMES[k], "launches_per_step": v["launches"] / n_inst, "avg_us": v["avg_us"],
+                       "share_of_step": v["total_ms"] / n_inst / step_ms}
+                if v.get("bytes_per_launch"):
+                    gbs = v["bytes_per_s"] / 1e9
+                    row.update(bytes_per_launch=v["bytes_per_launch"], hbm_gbs=gbs, hbm_frac=gbs / HBM_PEAK_GBS)
+                if k in MATRIX_FAMILIES:
+                    tf = v["work_per_s"] / 1e12
+                    row.update(flop_per_launch=v["work_per_launch"], tflops=tf, mfma_frac=tf / MFMA_BF16_PEAK_TFLOPS)
+                table[k] = row
+            out["kernels"] = table
+            out["kernels_note"] = ("HIP events on the launch stream, weight-gradient overlap off (stand-alone durations); bytes / FLOP per launch are the "
+                                   "algorithmic figures of SURVEY.md 8(d) / DESIGN.md section 4; hbm_frac against 8 TB/s, mfma_frac against 2.5 PFLOP/s dense bf16")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, config)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dp:

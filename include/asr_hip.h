@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 2
+#define ASR_ABI_VERSION 3
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -52,6 +52,16 @@ typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 int asr_abi_version(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
 int asr_last_error(char* buf, size_t n);
+/* Deterministic mode (process-wide; initial value from the environment variable ASR_DETERMINISTIC).  The reference's
+ * autograd on CPU sums every gradient in a fixed order (torch.autograd through transformer_official.py:100-103);
+ * the default HIP path combines partial weight-gradient tiles, bias-gradient slices and embedding rows with fp32
+ * atomics, whose arrival order varies from run to run.  With the mode on, every such reduction runs in a fixed
+ * order: asr_gemm_tn_* write one partial slab per M-split into `ws` (asr_gemm_tn_workspace_bytes is then non-zero)
+ * and add the slabs in split order, the column-sum finalisers use one workgroup per column group, asr_embed_bwd
+ * adds the token rows in order, asr_gemm_tn_grouped_bf16 refuses.  Results are then bit-identical from run to run.
+ * asr_set_deterministic returns the previous value. */
+int asr_get_deterministic(void);
+int asr_set_deterministic(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused residual-add + LayerNorm (+ positional encoding) (+ pad-row zeroing).
@@ -147,14 +157,17 @@ int asr_sdpa_dropout_mask(uint8_t* mask, int B, int H, int Tq, int Tk, float dro
  * logits: (B, T, V) `dtype`;  in_len: (B) int32 frames per utterance (<= T);
  * labels: (B, Lmax) int32 padded; lab_len: (B) int32 (<= Lmax <= 255).
  * nll: (B) f32 = -log p(labels | x) (+inf when infeasible; 0 if zero_infinity).
- * dlogits: (B, T, V) `dtype` (may alias logits) = grad_scale * d(sum_b nll_b)/dlogits,
+ * dlogits: (B, T, V) `dtype` (may alias logits) = scale * d(sum_b nll_b)/dlogits,
  * rows t >= in_len[b] are 0.  If dlogits is NULL only nll is computed.
+ * scale = grad_scale, or grad_scale / *grad_scale_div when grad_scale_div (a DEVICE f32 scalar) is not NULL: under data
+ * parallelism the CTC term is normalised by the GLOBAL batch, which arrives from an all-reduce on the device - the
+ * host never waits for it (ABI 3; the cross-entropy kernel takes its token count the same way).
  */
 size_t asr_ctc_workspace_bytes(int B, int T, int Lmax);
 int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len,
                     const int32_t* labels, const int32_t* lab_len, float* nll, int B, int T, int V,
-                    int Lmax, int blank, float grad_scale, int zero_infinity, void* ws,
-                    size_t ws_bytes, int dtype, void* stream);
+                    int Lmax, int blank, float grad_scale, const float* grad_scale_div, int zero_infinity,
+                    void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Greedy CTC decoding: per-frame argmax over the vocabulary (first index wins ties, as
@@ -307,7 +320,9 @@ int asr_loss_combine(const float* row_nll, int M, const float* n_valid, const fl
  */
 int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void* res, void* C,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, void* stream);
-/* Weight gradient  dW (N, K) f32 (+)= dY^T (M, N)^T * X (M, K)   ("TN": reduction over rows). */
+/* Weight gradient  dW (N, K) f32 (+)= dY^T (M, N)^T * X (M, K)   ("TN": reduction over rows).
+ * ws: NULL / 0 in the default mode; in deterministic mode a 16-byte aligned buffer of
+ * asr_gemm_tn_workspace_bytes(M, N, K) bytes (partial slabs, one per M-split). */
 size_t asr_gemm_tn_workspace_bytes(int M, int N, int K);
 int asr_gemm_tn_bf16(const void* dY, const void* X, float* dW, int M, int N, int K, int ldy,
                      int ldx, int ldw, int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -40,7 +40,7 @@ def default_cfg(**over):
     """Merged model config (transformer_official.py:115-122 + data_config.py:11-16)."""
     cfg = dict(n_mels=80, lfr_m=4, d_model=512, hidden_size=64, ff_size=1024, num_head=8,
                dropout=0.0, layer_num=6, ctc_weight=0.0, cross_mask="ref_compat",
-               use_decoder=True)
+               use_decoder=True, attn_window=-1)
     cfg.update(over)
     return SimpleNamespace(**cfg)
 
@@ -97,6 +97,10 @@ def encoder_forward(sd, cfg, wave, wave_len, loop_masks=False):
     keep = valid_mask(wave_len, T, loop_masks)                           # (B,T)
     non_pad = keep.unsqueeze(-1).to(wave.dtype)
     masked = (~keep).unsqueeze(1).expand(B, T, T)                        # key-pad mask only
+    w = int(getattr(cfg, "attn_window", -1))
+    if w >= 0:   # long-form config: +-w frame band, the mask of transformer_new.py:53 (t.triu(t.tril(mask, 50), -50))
+        idx = torch.arange(T)
+        masked = masked | ((idx.view(T, 1) - idx.view(1, T)).abs() > w).unsqueeze(0)
     d = cfg.d_model
     x = F.linear(wave, sd["encoder.linear_in.weight"], sd["encoder.linear_in.bias"])
     x = F.layer_norm(x, (d,), sd["encoder.layer_norm_in.weight"], sd["encoder.layer_norm_in.bias"], LN_EPS)

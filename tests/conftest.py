@@ -17,3 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def deterministic_mode():
+    """Fixed-order reductions in libasr_hip.so for the duration of a test (engines read the switch when they are built)."""
+    from asr_chinese_e2e_amd import kernels
+    old = kernels.set_deterministic(True)
+    yield
+    kernels.set_deterministic(old)

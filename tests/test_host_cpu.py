@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/asr_hip.h but not exported by libasr_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert _lib.lib.asr_abi_version() == 2
+    assert _lib.lib.asr_abi_version() == _lib.ABI_VERSION == 3
     # argument counts of the binding match the header declarations
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "asr_hip.h")).read(), flags=re.S)
     for n in names:
@@ -251,3 +251,113 @@ def test_grad_bucketer_two_ranks_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_loader_shards_by_rank():
+    """BucketedWaveLoader under data parallelism: every rank builds the same batch list, keeps full batches only and takes
+    batches[rank::world] - disjoint, equally many per rank (dist.DataParallel needs the same number of steps everywhere)."""
+    import random
+    from asr_chinese_e2e_amd.data_handler import bucket_batches, shard_batches
+    lengths = [random.Random(0).randint(8000, 64000) for _ in range(103)]
+    lists = []
+    for rank in range(4):
+        b = bucket_batches(lengths, 8, 32, True, True, random.Random(5))      # same seed on every rank
+        lists.append(shard_batches(b, rank, 4))
+    assert len({len(l) for l in lists}) == 1 and len(lists[0]) == (103 // 8) // 4 == 3
+    seen = [i for l in lists for batch in l for i in batch]
+    assert len(seen) == len(set(seen)) and all(len(batch) == 8 for l in lists for batch in l)
+    assert shard_batches([[1], [2], [3]], 0, 1) == [[1], [2], [3]]
+
+
+def test_reference_format_optimizer_state_on_cpu(tmp_path):
+    """NoamOpt.save / load speak torch.optim.Adam.state_dict() (Trainer/optimizer.py:33-46 of the reference) for the fused
+    optimizer too: its flat moment buffers are sliced per parameter in model.parameters() order.  CPU check of the
+    slicing (the GPU tests step the optimizers)."""
+    from asr_chinese_e2e_amd import engine as E
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+    torch.manual_seed(0)
+    flat = E.FlatParams([[("a.weight", (6, 4))], [("a.bias", (6,))], [("b.weight", (3, 6, 1))]])
+    flat.allocate("cpu", lowp=False)
+    params = []
+    for name in ("a.weight", "a.bias", "b.weight"):
+        p = torch.nn.Parameter(torch.zeros(1))
+        p.data = flat.view(flat.p, name)
+        params.append(p)
+    # a stock Adam with some history, saved the reference's way
+    stock_params = [torch.nn.Parameter(torch.randn(*p.shape)) for p in params]
+    stock = torch.optim.Adam(stock_params, lr=3e-4, betas=(0.9, 0.98), eps=1e-9)
+    for _ in range(2):
+        for q in stock_params:
+            q.grad = torch.randn_like(q)
+        stock.step()
+    path = str(tmp_path / "e0_s2.opt")
+    torch.save({"opt_state": stock.state_dict(), "step": 2, "factor": 1, "model_size": 64, "rate": 1.25e-4}, path)
+    opt = NoamOpt(64, 1, 10, FusedAdam(params, lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+    opt.load(path, flat)
+    assert opt._step == 2 and opt._rate == 1.25e-4
+    for name, q in zip(("a.weight", "a.bias", "b.weight"), stock_params):
+        assert torch.equal(flat.view(flat.m, name), stock.state[q]["exp_avg"])
+        assert torch.equal(flat.view(flat.v, name), stock.state[q]["exp_avg_sq"])
+    assert float(flat.m[24:64].abs().max()) == 0.0          # alignment padding between blocks stays zero
+    # and back: the file written by the fused optimizer loads into a stock Adam with identical moments
+    opt._flat = flat
+    out = str(tmp_path / "e0_s2_fused.opt")
+    opt.save(out)
+    blob = torch.load(out, weights_only=True)
+    assert set(blob) == {"opt_state", "step", "factor", "model_size", "rate"}
+    again = torch.optim.Adam([torch.nn.Parameter(torch.zeros(*p.shape)) for p in params], lr=1.0)
+    again.load_state_dict(blob["opt_state"])
+    for q2, q in zip(again.param_groups[0]["params"], stock_params):
+        assert torch.equal(again.state[q2]["exp_avg"], stock.state[q]["exp_avg"]) and float(again.state[q2]["step"]) == 2.0
+    assert again.param_groups[0]["betas"] == (0.9, 0.98) and again.param_groups[0]["eps"] == 1e-9
+    # a checkpoint for another model is refused
+    bad = NoamOpt(64, 1, 10, FusedAdam(params[:2], lr=3e-4))
+    with pytest.raises(RuntimeError):
+        bad.load(path, flat)
+    # loaded before the buffers exist: kept, not dropped
+    late = NoamOpt(64, 1, 10, FusedAdam(params, lr=3e-4))
+    late.load(path, E.FlatParams([[("a.weight", (6, 4))]]))
+    assert late._pending_state is not None and late._step == 2
+
+
+def test_train_py_flags_and_config_merge():
+    """train.py mirrors main.py:14-64: fire-style flags, TrainConfig <- kwargs, ModelConfig merged over it, kwargs again;
+    unknown flags are added silently (the reference's own `--log_every_step=10`, main.py:103)."""
+    import train as T
+    flags = T.parse_flags(["--lr=3e-4", "--num_epoch=200", '--model_name=TransformerOffical', "--batch_size", "64", "--drop_exp=False",
+                           "--predump=False", "--use_old=True", "--warm_up=4000", "--log_every_step=10", "--augment"])
+    assert flags == dict(lr=3e-4, num_epoch=200, model_name="TransformerOffical", batch_size=64, drop_exp=False, predump=False, use_old=True,
+                         warm_up=4000, log_every_step=10, augment=True)
+    config = T.TrainConfig()
+    config.fn_build(flags)
+    Model, ModelConfig = T.get_model_class(config.model_name)
+    config.fn_combine(ModelConfig())
+    config.fn_build(flags)
+    assert config.d_model == 512 and config.hidden_size == 64 and config.warm_up == 4000 and config.log_every_iter == 100
+    assert config.log_every_step == 10 and config.n_mels == 80 and config.lfr_m == 4 and config.dropout == 0.1
+    assert Model.__name__ == "TransformerOffical"
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit):
+            T.train(synthetic=8, batch_size=4)
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks itself (child torch.distributed.run, parent never
+    touches the GPU) and relays ONE JSON line whose n_gpus is the size of the group the ranks formed.  --plumbing swaps the
+    GPU work for one gloo all-reduce so that the launcher runs on a CPU-only machine."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--plumbing"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["sum_of_ranks"] == 3.0 and out["config"]["global_batch"] == 64
+    assert out["config"]["workload"] == "joint" and out["config"]["parallelism"] == "dp2"      # N > 1 defaults to BASELINE configs[3]
+    # a rank count that contradicts the environment is refused instead of measuring one rank
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stdout + p.stderr)

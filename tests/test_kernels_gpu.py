@@ -575,6 +575,57 @@ def test_gemm_tn(K, M, N, K_):
     close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn bias gradient")
 
 
+@pytest.mark.parametrize("M,N,K_", [(16000, 512, 512), (16000, 4232, 512), (1000, 1536, 512), (8197, 264, 72)])
+def test_gemm_tn_deterministic_mode(K, ws, deterministic_mode, M, N, K_):
+    """ASR_DETERMINISTIC / asr_set_deterministic: partial tiles of the M-splits go to slabs that a second pass adds in split
+    order - two launches on the same inputs give IDENTICAL bits (the default path adds them with fp32 atomics in arrival
+    order), the values equal the fp32 product, and the bias gradient comes out of the same pass."""
+    assert K.deterministic()
+    torch.manual_seed(M + N)
+    dy = (torch.randn(M, N) * 0.5).bfloat16().to(DEV)
+    x = torch.randn(M, K_).bfloat16().to(DEV)
+    ref = dy.double().cpu().t() @ x.double().cpu()
+    outs = []
+    for rep in range(3):
+        dw = torch.ones(N, K_, device=DEV)
+        db = torch.full((N,), 2.0, device=DEV)
+        K.gemm_tn(dy, x, dw, accumulate=True, dbias=db, ws=ws)
+        outs.append((dw.clone(), db.clone()))
+    close(outs[0][0] - 1, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="deterministic gemm_tn")
+    close(outs[0][1] - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="deterministic bias gradient")
+    for dw, db in outs[1:]:
+        assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
+    dw2 = torch.full((N, K_), float("nan"), device=DEV)
+    K.gemm_tn(dy, x, dw2, accumulate=False, ws=ws)
+    close(dw2, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="deterministic gemm_tn overwrite")
+    with pytest.raises(RuntimeError):          # the grouped kernel only has the atomic form
+        K.gemm_tn_grouped([(dy, x, dw2, None)])
+
+
+def test_deterministic_mode_small_reductions(K, ws, deterministic_mode):
+    """Embedding scatter with repeated ids, column sums and the batched LayerNorm reduce: bit-identical across launches."""
+    torch.manual_seed(3)
+    ids = torch.randint(0, 7, (512,), dtype=torch.int32, device=DEV)          # many repeats per id
+    dy = torch.randn(512, 64, device=DEV)
+    outs = []
+    for _ in range(3):
+        demb = torch.zeros(7, 64, device=DEV)
+        K.embed_bwd(ids, dy, demb, 0.125)
+        outs.append(demb)
+    ref = torch.zeros(7, 64, dtype=torch.float64)
+    ref.index_add_(0, ids.cpu().long(), dy.double().cpu() * 0.125)
+    close(outs[0], ref, rtol=1e-5, atol=1e-5, what="serial embedding scatter")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    x = torch.randn(16000, 512, device=DEV).bfloat16()
+    sums = []
+    for _ in range(3):
+        out = torch.zeros(512, device=DEV)
+        K.colsum(x, out, ws, accumulate=True)
+        sums.append(out)
+    close(sums[0], x.double().sum(0), rtol=1e-4, atol=0.05, what="column sums")
+    assert torch.equal(sums[0], sums[1]) and torch.equal(sums[0], sums[2])
+
+
 def _tn_problem(M, N, K_, with_bias, seed, strided=False):
     g = torch.Generator().manual_seed(seed)
     dy = (torch.randn(M, N, generator=g) * 0.5 + 0.1).bfloat16().to(DEV)

@@ -4,8 +4,9 @@
    every parameter gradient, parameters after one and two Noam+Adam steps), tolerance = fp32
    round-off of a different summation order (1e-4 relative on gradients).
  * bf16 mode (MFMA attention + MFMA GEMMs, d_model=512 / d_k=64) against the CPU oracle
-   (oracle/ref_model.RefTrainer, fp32) on the same weights and batch: loss <= 2e-2 relative,
-   gradient cosine >= 0.995 per tensor (bf16 storage of activations).
+   (oracle/ref_model.RefTrainer, fp32) on the same weights and batch: SURVEY 8(d) gates - loss <= 1e-3 relative,
+   gradient cosine >= 0.999 per tensor (bf16 storage of activations); measured worst cases go to
+   gpurun_out/bf16_parity.jsonl.
  * joint CTC/attention (lambda = 0.3) and CTC-only against the oracle (CTC is not in the reference).
 """
 import numpy as np
@@ -149,9 +150,46 @@ def test_fp32_ctc_paths_match_oracle(mode):
             assert np.abs(got - want).max() <= 2.5 * ref["lr"], n
 
 
+def _report(name, rows):
+    """Measured parity figures of the bf16 path, kept for DESIGN.md (gpurun_out/ is merged back from the GPU box)."""
+    import json
+    import os
+    from tests.helpers import ROOT
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bf16_parity.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **rows}) + "\n")
+
+
+# SURVEY 8(d) tolerances for bf16 storage: loss <= 1e-3 relative, per-tensor gradient cosine >= 0.999.
+BF16_LOSS_RTOL = 1e-3
+BF16_COS = 0.999
+# Tensors that cannot meet the cosine gate, and why (measured worst cases are written to gpurun_out/bf16_parity.jsonl):
+#   *.w_ks.bias            - analytically zero gradient (softmax is shift-invariant): pure round-off in any implementation.
+BF16_COS_EXEMPT = ("w_ks.bias",)
+
+
+def bf16_gradient_gate(model, ref, name, cos_min=BF16_COS):
+    gmax = max(float(g.abs().max()) for g in ref["grads"].values())
+    worst, worst_name, worst_ratio = 1.0, "", 1.0
+    for n, p in model.named_parameters():
+        g = ref["grads"][n]
+        if float(g.abs().max()) < 1e-6 * max(gmax, 1e-30) or n.endswith(BF16_COS_EXEMPT):
+            continue
+        c = cos(p.grad, g)
+        r = float(p.grad.double().norm().cpu() / g.double().norm())
+        if c < worst:
+            worst, worst_name = c, n
+        if abs(r - 1) > abs(worst_ratio - 1):
+            worst_ratio = r
+        assert c > cos_min, (n, c)
+        assert 0.97 < r < 1.03, (n, r)
+    return worst, worst_name, worst_ratio
+
+
 @pytest.mark.parametrize("mode", ["joint", "ctc_only"])
 def test_bf16_mfma_path_matches_oracle(mode):
-    """d_model 512 / 8 heads x 64 / ff 1024: the shapes the MFMA kernels are built for."""
+    """d_model 512 / 8 heads x 64 / ff 1024: the shapes the MFMA kernels are built for.  Gates = SURVEY 8(d): loss
+    1e-3 relative, every gradient tensor's cosine >= 0.999 and norm within 3 %."""
     over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2)
     over.update(dict(ctc_weight=0.3) if mode == "joint" else dict(use_decoder=False, ctc_weight=1.0))
     B, T, F, V, L = 4, 136, 80, 56, 12
@@ -167,18 +205,10 @@ def test_bf16_mfma_path_matches_oracle(mode):
     model._ensure_engine(DEV)
     model.zero_flat_grads()
     loss, _ = model.train_step(pack)
-    assert abs(float(loss[0]) - float(ref["loss"])) < 2e-2 * abs(float(ref["loss"])), (float(loss[0]), float(ref["loss"]))
-    worst = 1.0
-    for n, p in model.named_parameters():
-        g = ref["grads"][n]
-        if float(g.abs().max()) < 1e-6 or n.endswith("w_ks.bias"):
-            continue
-        c = cos(p.grad, g)
-        worst = min(worst, c)
-        assert c > 0.99, (n, c)
-        r = float(p.grad.double().norm().cpu() / g.double().norm())
-        assert 0.9 < r < 1.1, (n, r)
-    assert worst > 0.99
+    rel = abs(float(loss[0]) - float(ref["loss"])) / abs(float(ref["loss"]))
+    worst, worst_name, ratio = bf16_gradient_gate(model, ref, "mfma_" + mode)
+    _report("bf16_mfma_path_" + mode, dict(loss_rel=rel, worst_cos=worst, worst_tensor=worst_name, worst_norm_ratio=ratio))
+    assert rel < BF16_LOSS_RTOL, (float(loss[0]), float(ref["loss"]))
 
 
 @pytest.mark.parametrize("mode", ["ctc_only", "joint"])
@@ -301,8 +331,12 @@ def test_baseline_config0_matches_oracle(dtype):
     model._ensure_engine(DEV)
     model.zero_flat_grads()
     loss, _ = model.train_step(pack)
-    tol = 1e-4 if dtype == "fp32" else 2e-2
-    assert abs(float(loss[0]) - float(ref["loss"])) < tol * abs(float(ref["loss"]))
+    tol = 1e-4 if dtype == "fp32" else BF16_LOSS_RTOL
+    rel = abs(float(loss[0]) - float(ref["loss"])) / abs(float(ref["loss"]))
+    if dtype == "bf16":
+        worst, worst_name, ratio = bf16_gradient_gate(model, ref, "config0")
+        _report("baseline_config0_bf16", dict(loss_rel=rel, worst_cos=worst, worst_tensor=worst_name, worst_norm_ratio=ratio))
+    assert rel < tol, (float(loss[0]), float(ref["loss"]))
     gmax = max(float(g.abs().max()) for g in ref["grads"].values())
     for n, p in model.named_parameters():
         g = ref["grads"][n]
@@ -312,8 +346,6 @@ def test_baseline_config0_matches_oracle(dtype):
             d = (p.grad.cpu() - g).abs()
             assert float((d > 1e-3 * g.abs() + 2e-5 * max(gmax, 1.0)).float().mean()) < 1e-3, n
             assert float(d.max()) < 1e-2 * float(g.abs().max()), n
-        elif float(g.abs().max()) > 1e-6 * gmax and not n.endswith("w_ks.bias"):
-            assert cos(p.grad.cpu(), g) > 0.99, n
 
 
 def test_padded_rows_are_exact_zero_and_ignore_garbage():
@@ -426,3 +458,103 @@ def test_dropout_training_and_eval_modes():
         m, _ = m1.iterate(pack, optimizer=opt, is_train=True)
         first = float(m.loss) if first is None else first
     assert np.isfinite(float(m.loss)) and float(m.loss) < first
+
+
+# ------------------------------------------------------------------------------------ BASELINE configs[2], [4]
+def test_full_size_joint_step_properties():
+    """BASELINE.json configs[2] at full size (joint CTC/attention, lambda = 0.3, B=32, T=500, F=80, V=4232, 6+6 layers, bf16),
+    ragged lengths: steps run, the loss is finite and falls on a repeated batch, and the size-independent properties
+    hold - padded encoder rows exactly 0, every CTC gradient row sums to 0 (so does the CTC head's bias gradient),
+    padded frames / tokens contribute nothing."""
+    from asr_chinese_e2e_amd.data_handler import synthetic_pack
+    cfg = R.default_cfg(n_mels=80, lfr_m=1, ctc_weight=0.3)
+    torch.manual_seed(0)
+    model = build(cfg, 4232, "TransformerOffical", dtype="bf16").cuda()
+    with torch.no_grad():      # N(0,1) tied embedding at d=512 gives logits of +-20: keep CE in a sane range for the loss trend
+        model.decoder.tgt_word_emb.weight.mul_(0.05)
+    opt = make_opt(model, cfg, 20)
+    pack = synthetic_pack(32, 500, 80, 4232, seed=11, ragged=True, device=DEV)
+    model._ensure_engine(DEV)
+    model._flat.refresh_lowp()
+    model.zero_flat_grads()
+    loss, _ = model.train_step(pack)
+    torch.cuda.synchronize()
+    assert all(np.isfinite(loss.cpu().numpy())), loss
+    g = {n: p.grad for n, p in model.named_parameters()}
+    assert all(bool(torch.isfinite(v).all()) for v in g.values())
+    gb = g["ctc_lo.bias"].double()
+    assert abs(float(gb.sum())) < 2e-2 * float(gb.abs().sum()), (float(gb.sum()), float(gb.abs().sum()))
+    # class 0 doubles as CTC blank and decoder padding: the embedding row of <pad> gets no CE gradient through the tied projection's
+    # targets, and no gradient tensor is identically zero
+    assert all(float(v.abs().max()) > 0 for n, v in g.items() if not n.endswith("w_ks.bias"))
+    enc = model.forward(pack).encoder_out.float()
+    for b in range(32):
+        n = int(pack.wave_len[b])
+        if n < 500:
+            assert float(enc[b, n:].abs().max()) == 0.0
+    losses = []
+    for _ in range(5):
+        m, _ = model.iterate(pack, optimizer=opt, is_train=True)
+        losses.append(float(m.loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_long_form_window_matches_oracle(dtype):
+    """BASELINE.json configs[4] at model level: T = 2000 frames, +-50-frame attention band on the encoder
+    (config.attn_window = 50; the mask of transformer_new.py:53), joint CTC/attention, against the oracle with the same band.
+    fp32: CTC loss 1e-4 relative (north_star), gradients 3e-4 of the largest; bf16 (d_model 512, MFMA kernels): SURVEY 8(d) gates."""
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, ctc_weight=0.3, attn_window=50)
+    B, T, F, V, L = 2, 2000, 80, 56, 20
+    cfg, sd, batch = oracle_case(B, T, F, V, L, over, seed=13)
+    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
+    sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    ref = R.RefTrainer(sd, cfg, warmup=25).iterate(batch)
+    # the band matters: the full-attention oracle gives a different loss
+    full = R.RefTrainer(sd, R.default_cfg(**{**vars(cfg), "attn_window": -1}), warmup=25).iterate(batch)
+    assert abs(float(full["loss"]) - float(ref["loss"])) > 1e-3 * abs(float(ref["loss"]))
+    model = build(cfg, V, "TransformerOffical", dtype=dtype).cuda()
+    model.load_state_dict(sd)
+    pack = to_pack(batch)
+    model._ensure_engine(DEV)
+    model.zero_flat_grads()
+    loss, _ = model.train_step(pack)
+    rel = abs(float(loss[0]) - float(ref["loss"])) / abs(float(ref["loss"]))
+    rel_ctc = abs(float(loss[2]) - float(ref["out"]["ctc"])) / abs(float(ref["out"]["ctc"]))
+    if dtype == "fp32":
+        assert rel < 1e-4 and rel_ctc < 1e-4, (rel, rel_ctc)
+        gmax = max(float(g.abs().max()) for g in ref["grads"].values())
+        for n, p in model.named_parameters():
+            if n.endswith("w_ks.bias"):
+                continue
+            d = (p.grad.cpu() - ref["grads"][n]).abs()
+            assert float((d > 1e-3 * ref["grads"][n].abs() + 3e-5 * max(gmax, 1.0)).float().mean()) < 1e-3, n
+    else:
+        worst, worst_name, ratio = bf16_gradient_gate(model, ref, "long_form")
+        _report("long_form_window_bf16", dict(loss_rel=rel, ctc_rel=rel_ctc, worst_cos=worst, worst_tensor=worst_name, worst_norm_ratio=ratio))
+        assert rel < BF16_LOSS_RTOL, (float(loss[0]), float(ref["loss"]))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_deterministic_mode_repeats_bit_for_bit(deterministic_mode, dtype):
+    """Two runs of three training steps from the same weights in deterministic mode end with IDENTICAL parameters
+    (every bit): no atomics in the weight-gradient split sums, bias gradients, LayerNorm reductions or the embedding scatter.
+    The values stay those of the default path (checked against it within the usual tolerances by the oracle tests)."""
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, ctc_weight=0.3)
+    cfg, sd, batch = oracle_case(4, 136, 80, 56, 12, over, seed=9)
+    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
+    sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    pack = to_pack(batch)
+    finals, losses = [], []
+    for run in range(2):
+        model = build(cfg, 56, "TransformerOffical", dtype=dtype).cuda()
+        model.load_state_dict(sd)
+        opt = make_opt(model, cfg, 25)
+        eng = model._ensure_engine(DEV)
+        assert eng.deterministic and not eng.overlap_wgrad and eng.group_wgrad is None
+        ls = [float(model.iterate(pack, optimizer=opt, is_train=True)[0].loss) for _ in range(3)]
+        torch.cuda.synchronize()
+        finals.append(model._flat.p.clone())
+        losses.append(ls)
+    assert losses[0] == losses[1], losses
+    assert torch.equal(finals[0], finals[1]), float((finals[0] - finals[1]).abs().max())
