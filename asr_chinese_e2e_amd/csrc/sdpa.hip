@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256, 3) void sdpa_bwd_dq_bf16_kernel(const bf16_t* 
     frags_from_global(dof, dob, ldo, q0, Tq, lane);
     const int qi = q0 + (lane & 31);
     const size_t stat = ((size_t)b * H + h) * Tq + min(qi, Tq - 1);
-    const float lse2 = lse[stat] * LOG2E;
+    // a query with no admissible key at all (a padded frame beyond the long-form band) has lse = -inf: its probabilities are 0
+    const float lse_raw = lse[stat];
+    const float lse2 = lse_raw == -INFINITY ? 1.0e30f : lse_raw * LOG2E;
     // delta = rowsum(dO o O): this wave already holds its 32 dO rows as fragments, so the separate
     // delta pass (one more read of O and dO, one more launch) is folded in here; the result is also
     // written out for the dK/dV kernel that runs next on the stream.
@@ -402,7 +404,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t*
     auto stat_load = [&](int q0) {
         if (tid < TILE) {
             const int qi = q0 + tid;
-            st_l = qi < Tq ? lseb[qi] * LOG2E : 1.0e30f;  // exp2(s - 1e30) = 0 for rows past the end
+            const float lr = qi < Tq ? lseb[qi] : -INFINITY;
+            st_l = lr == -INFINITY ? 1.0e30f : lr * LOG2E;  // exp2(s - 1e30) = 0 for rows past the end and for queries that see no key (lse = -inf)
             st_d = qi < Tq ? delb[qi] : 0.f;
         }
     };

@@ -75,8 +75,12 @@ def multi_head_attention(sd, pre, q_in, kv_in, masked, n_head, d_k):
     k = F.linear(kv_in, sd[pre + "w_ks.weight"], sd[pre + "w_ks.bias"]).view(B, Lk, n_head, d_k)
     v = F.linear(kv_in, sd[pre + "w_vs.weight"], sd[pre + "w_vs.bias"]).view(B, Lk, n_head, d_k)
     s = torch.einsum("bqhd,bkhd->bhqk", q, k) / (d_k ** 0.5)          # attention.py:76-77
-    s = s.masked_fill(masked.unsqueeze(1), float("-inf"))                # attention.py:80
-    p = torch.softmax(s, dim=-1)
+    # a query row with NO admissible key (only possible with the long-form band: a padded frame more than `window` frames past
+    # the end of its utterance) would be softmax(all -inf) = NaN, and NaN * 0 survives the pad zeroing; such a row attends to
+    # nothing: context 0, no gradient.  Without a band every row sees the valid keys, as in the reference.
+    dead = masked.all(dim=-1, keepdim=True)                              # (B, Lq, 1)
+    s = s.masked_fill((masked & ~dead).unsqueeze(1), float("-inf"))      # attention.py:80
+    p = torch.softmax(s, dim=-1) * (~dead).unsqueeze(1).to(s.dtype)
     ctx = torch.einsum("bhqk,bkhd->bqhd", p, v).reshape(B, Lq, n_head * d_k)
     out = F.linear(ctx, sd[pre + "fc.weight"], sd[pre + "fc.bias"])
     d = q_in.shape[-1]
