@@ -19,6 +19,8 @@
 //
 // f32 path: exact-fp32 VALU kernels with the same decomposition (used for fp32 parity mode and
 // for head sizes other than 64); one wave per query (fwd, dQ) or per key (dKV).
+#include <stdlib.h>
+
 #include "asr_common.h"
 
 namespace {
@@ -477,6 +479,296 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t*
     store_rows_T(dva, 1.f, dv + (size_t)b * Tk * ldv + h * DK, ldv, kk0, Tk, lane);
 }
 
+// ---------------------------------------------------------------- backward: ONE kernel per (b, h)
+// The dQ + dK/dV pair above reads Q, K, V, dO twice and computes S and dP twice (7 products, 2 exp passes; PMC traffic
+// 1.52 x the algorithmic bytes).  When all keys of a head fit one workgroup (Tk <= 512: every encoder / decoder shape of
+// the T = 500 configurations) the whole backward of a (b, h) pair is ONE workgroup of 8 waves:
+//   * wave w owns keys [64 w, 64 w + 64): their dK^T and dV^T live in its accumulators for the whole kernel (no sum
+//     across workgroups, no atomics), their V fragments in registers; K of all 512 keys sits in LDS once (72 KiB),
+//     pre-multiplied by scale * log2(e) so that the scores leave the MFMA in the exp2 domain;
+//   * the queries stream through in 32-row tiles (Q, dO: 4.5 KiB each, double buffered, prefetched more than a tile
+//     ahead in registers together with -lse log2(e) and -delta = -rowsum(dO o O), computed here from the O rows);
+//   * S and dP are computed ONCE, key on the lane (guide: "Key on the lane"), their accumulators START at the row
+//     constants (-lse log2(e), -delta; lanes of padded keys read a row of -1e30 instead), so p = exp2(S') and
+//     dS = p dP' need no scale, no subtraction, no row maximum and no key mask; P and dS feed dV^T += dO^T P and
+//     dK^T += Q^T dS straight from the accumulators;
+//   * only dS crosses LDS, once: each wave writes its 64 keys into a [key][query] image (8-byte pieces, 64-byte rows,
+//     chunk c of row r at c ^ ((r >> 1) & 7): writes and transposed reads conflict-free), double buffered, so ONE
+//     barrier per tile is enough; after it wave w computes ONE 16 x 16 block of dQ^T = K^T dS^T over all keys with
+//     MFMA 16x16x32 (both operands by transposed LDS reads) and stores it - dQ is reduced inside the workgroup, in a
+//     fixed order, while other waves already work on the next tile.
+// 5 products, 1 exp pass; HBM traffic = Q, K, V, O, dO read once + dQ, dK, dV written once.  Deterministic.
+// (A 4-wave form with the whole 512-entry register file per wave - operand sets shared by four key blocks, a third of
+// the LDS traffic - measured 102 us against 82 us for this form: one wave per SIMD exposes every LDS and MFMA latency.)
+constexpr int FB_WAVES = 8, FB_KEYS = 64 * FB_WAVES, FB_QT = 32, FB_THREADS = 64 * FB_WAVES;
+constexpr int FB_K_BYTES = FB_KEYS * TS * 2;                  // 73728
+constexpr int FB_DS_BYTES = FB_KEYS * FB_QT * 2;              // 32768 per buffer
+constexpr int FB_TILE_ELEMS = FB_QT * TS;
+constexpr int FB_STATS = (2 * 64 + 32) * 4;                   // [2 buffers][-lse log2e (32) | -delta (32)] + a row of -1e30
+constexpr int FB_LDS = FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2 + FB_STATS;   // 158336 B
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+// 16x16x32 operand by transposed LDS reads: lane (i = l & 15, g = l >> 4) gets img[row0 + 8 g + j][col0 + i], j = 0..7
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_tr16(const bf16_t* img, int row0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const bf16_t* p = img + (row0 + 8 * g + (i >> 2)) * LD + col0 + 4 * (i & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * LD));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ uint32_t scale_bf16_pair(uint32_t x, float f) {
+    const bf16_t lo = (bf16_t)(__uint_as_float(x << 16) * f), hi = (bf16_t)(__uint_as_float(x & 0xffff0000u) * f);
+    return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+template <bool DROP, bool MASKED>
+__global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                         const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                                         bf16_t* __restrict__ dq, bf16_t* __restrict__ dk_, bf16_t* __restrict__ dv,
+                                                                         const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
+                                                                         int causal, int window, float scale, uint32_t dseed, uint32_t dthr, float dscale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_fb[];
+    bf16_t* Kimg = (bf16_t*)smem_fb;
+    bf16_t* dSimg = (bf16_t*)(smem_fb + FB_K_BYTES);                               // two buffers of FB_KEYS x 32
+    bf16_t* tiles = (bf16_t*)(smem_fb + FB_K_BYTES + 2 * FB_DS_BYTES);
+    float* stats = (float*)(smem_fb + FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2);
+    float* s_neg = stats + 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
+    const bf16_t* dob = d_o + (size_t)b * Tq * ldo + h * DK;
+    const bf16_t* ob = o + (size_t)b * Tq * ldo + h * DK;
+    const bf16_t* kb = k + (size_t)b * Tk * ldk + h * DK;
+    const bf16_t* vb = v + (size_t)b * Tk * ldv + h * DK;
+    const float* lseb = lse + ((size_t)b * H + h) * Tq;
+    const int klen = min(k_len ? k_len[b] : Tk, Tk);
+    const int kk0 = 64 * w;
+    const bool active = kk0 < Tk;                 // wave-uniform: this wave owns keys of the head
+    const int nks = (Tk + 31) >> 5;               // 32-key steps of the dQ product
+    const float sc2 = scale * LOG2E;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // ---- K * scale * log2(e) of every key -> LDS (rows >= klen are zeros: padded keys never contribute); dS images start
+    //      as zeros (rows of waves without keys are never written and are read by the unrolled dQ loop)
+    for (int c = tid; c < FB_KEYS * 8; c += FB_THREADS) {
+        const int row = c >> 3, ch = c & 7;
+        u32x4 x = zero4;
+        if (row < klen) {
+            x = *(const u32x4*)(kb + (size_t)row * ldk + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = scale_bf16_pair(x[e], sc2);
+        }
+        *(u32x4*)(Kimg + row * TS + ch * 8) = x;
+    }
+    for (int c = tid; c < 2 * FB_DS_BYTES / 16; c += FB_THREADS) *(u32x4*)((char*)dSimg + c * 16) = zero4;
+    if (tid < 32) s_neg[tid] = -1.0e30f;
+    // ---- this wave's V rows as B-operand fragments (key on the lane)
+    bf16x8 vf[2][4];
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk) {
+        const int row = kk0 + 32 * kbk + (lane & 31);
+        const bool ok = row < klen;
+        const bf16_t* src = vb + (size_t)(ok ? row : 0) * ldv + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 x = *(const bf16x8*)(src + 16 * ks);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = (bf16_t)0.f;
+            }
+            vf[kbk][ks] = x;
+        }
+    }
+    // ---- query tile prefetch (registers): threads 0..255 one 16-byte piece of Q, 256..511 of dO (+ the O piece for delta)
+    const int t2 = tid & 255, prow = t2 >> 3, pch = t2 & 7;
+    const bool is_do = tid >= 256;
+    const bf16_t* srcA = is_do ? dob : qb;      // one code path for both halves of the workgroup
+    const size_t ldA = is_do ? (size_t)ldo : (size_t)ldq;
+    u32x4 pa = zero4, po = zero4;
+    float pl = 0.f;
+#define FB_PREFETCH(Q0)                                                                                   \
+    do {                                                                                                  \
+        const int qi_ = (Q0) + prow;                                                                      \
+        const bool ok_ = qi_ < Tq;                                                                        \
+        const size_t row_ = (size_t)(ok_ ? qi_ : 0);                                                      \
+        pa = *(const u32x4*)(srcA + row_ * ldA + pch * 8);                                                \
+        po = *(const u32x4*)(ob + row_ * ldo + pch * 8);                                                  \
+        if (!ok_) { pa = zero4; po = zero4; }                                                             \
+        const int ql_ = min((Q0) + (tid & 31), Tq - 1);                                                   \
+        const float lr_ = lseb[ql_];                                                                      \
+        pl = ((Q0) + (tid & 31) >= Tq || lr_ == -INFINITY) ? -1.0e30f : -lr_ * LOG2E;                     \
+    } while (0)
+    // rows past the end / rows that saw no key get -1e30: p = 0.  (Every thread loads one lse value: no divergent path.)
+#define FB_COMMIT(BUF)                                                                                    \
+    do {                                                                                                  \
+        bf16_t* T_ = tiles + (BUF) * 2 * FB_TILE_ELEMS + (is_do ? FB_TILE_ELEMS : 0);                     \
+        *(u32x4*)(T_ + prow * TS + pch * 8) = pa;                                                         \
+        float* st_ = stats + (BUF) * 64;                                                                  \
+        float d_ = 0.f;   /* delta = rowsum(dO o O): 8 lanes per row (the Q half computes a throw-away value) */ \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                \
+            d_ += __uint_as_float(pa[e_] << 16) * __uint_as_float(po[e_] << 16);                          \
+            d_ += __uint_as_float(pa[e_] & 0xffff0000u) * __uint_as_float(po[e_] & 0xffff0000u);          \
+        }                                                                                                 \
+        d_ += __shfl_xor(d_, 1, 64);                                                                      \
+        d_ += __shfl_xor(d_, 2, 64);                                                                      \
+        d_ += __shfl_xor(d_, 4, 64);                                                                      \
+        if (is_do && pch == 0) st_[32 + prow] = -d_;                                                      \
+        if (tid < FB_QT) st_[tid] = pl;                                                                   \
+    } while (0)
+
+    f32x16 dka[2][2], dva[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dka[a][c][i] = 0.f; dva[a][c][i] = 0.f; }
+    const int ntiles = (Tq + FB_QT - 1) / FB_QT;
+    const int d0 = 16 * (w >> 1), q0l = 16 * (w & 1);     // this wave's 16 x 16 block of dQ^T
+    bf16_t* dqb = dq + (size_t)b * Tq * ldq + h * DK;
+    // dS image addressing: 8-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7)
+    const int kjl = lane & 31;                              // key inside a 32-key block (f(key) does not depend on the block: 32 rows = 16 pairs)
+    const int fw = (kjl >> 1) & 7;
+    int ds_wr[4];                                           // element offsets of this lane's four pieces (queries 8 g + 4 hh ..) in its key row
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) ds_wr[g4] = kjl * FB_QT + 4 * ((2 * g4 + hh) ^ fw);
+    int ds_rd[2];                                           // transposed-read offsets (rows 8 g + (i >> 2) and + 4), columns q0l + 4 (i & 3)
+    {
+        const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+        for (int pl4 = 0; pl4 < 2; ++pl4) {
+            const int row = 8 * g + (i >> 2) + 4 * pl4;
+            ds_rd[pl4] = row * FB_QT + 4 * (((q0l >> 2) + (i & 3)) ^ ((row >> 1) & 7));
+        }
+    }
+    // ---- the two halves of a tile's work
+    auto phase_keys = [&](int t) {      // S, dP, P, dS, dV^T, dK^T of this wave's keys against query tile t; dS -> image t & 1
+        const int buf = t & 1, qt0 = t * FB_QT;
+        const bf16_t* Qt = tiles + buf * 2 * FB_TILE_ELEMS;
+        const bf16_t* Dt = Qt + FB_TILE_ELEMS;
+        const float* s_l = stats + buf * 64;
+        const float* s_d = s_l + 32;
+        bf16_t* dSw = dSimg + buf * (FB_DS_BYTES / 2);
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            const int key0 = kk0 + 32 * kbk, kj = key0 + kjl;
+            const float* s_lk = kj < klen ? s_l : s_neg;      // padded keys: p = 0 without a test per element
+            f32x16 st, dp;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4_t l4 = *(const f32x4_t*)(s_lk + 8 * g4 + 4 * hh);
+                const f32x4_t d4 = *(const f32x4_t*)(s_d + 8 * g4 + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[4 * g4 + e] = l4[e];
+                    dp[4 * g4 + e] = DROP ? 0.f : d4[e];
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Qt, 0, ks, lane), frag_row(Kimg, key0, ks, lane), st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Dt, 0, ks, lane), vf[kbk][ks], dp, 0, 0, 0);
+            }
+            if (MASKED) {
+                const bool need = (causal && key0 + 31 > qt0) || (window >= 0 && (key0 + 31 - qt0 > window || qt0 + 31 - key0 > window));
+                if (need) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (!visible(qt0 + acc_row(i, lane), kj, klen, causal, window)) st[i] = -1.0e30f;
+                }
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4_t d4 = {0.f, 0.f, 0.f, 0.f};
+                if (DROP) d4 = *(const f32x4_t*)(s_d + 8 * g4 + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g4 + e;
+                    const float p = __builtin_amdgcn_exp2f(st[i]);
+                    if (DROP) {
+                        const uint32_t el = (((uint32_t)(b * H + h)) * Tq + min(qt0 + 8 * g4 + 4 * hh + e, Tq - 1)) * ((Tk + 1) & ~1) + min(kj, Tk - 1);
+                        const float keepf = drop_keep_at(el, dseed, dthr) ? dscale : 0.f;
+                        dp[i] = p * (dp[i] * keepf + d4[e]);     // dS / scale (d4 = -delta)
+                        st[i] = p * keepf;                       // dropped probabilities feed dV
+                    } else {
+                        dp[i] = p * dp[i];                       // dS / scale: the factor is applied once, when dQ / dK are stored
+                        st[i] = p;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pfr = acc_to_frag(st, s2);
+                const bf16x8 dfr = acc_to_frag(dp, s2);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dva[kbk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Dt, 0, 32 * db, s2, lane), pfr, dva[kbk][db], 0, 0, 0);
+                    dka[kbk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 0, 32 * db, s2, lane), dfr, dka[kbk][db], 0, 0, 0);
+                }
+                // dS -> [key][query] image: the fragment of k-step s2 holds registers 8 s2 .. 8 s2 + 7 = the pieces g4 = 2 s2, 2 s2 + 1
+                const u32x4 dw = __builtin_bit_cast(u32x4, dfr);
+                const u32x2_t lo2 = {dw[0], dw[1]}, hi2 = {dw[2], dw[3]};
+                *(u32x2_t*)(dSw + (size_t)(key0 * FB_QT) + ds_wr[2 * s2]) = lo2;
+                *(u32x2_t*)(dSw + (size_t)(key0 * FB_QT) + ds_wr[2 * s2 + 1]) = hi2;
+            }
+        }
+    };
+    auto phase_dq = [&](int t) {        // this wave's 16 x 16 block of dQ^T for query tile t, over every key
+        const int buf = t & 1, qt0 = t * FB_QT;
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* dSr = dSimg + buf * (FB_DS_BYTES / 2);
+        for (int s4 = 0; s4 < nks; s4 += 4) {     // rows past the last key: K rows and dS rows are zeros
+            bf16x8 ka[4], da[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ka[u] = frag_tr16<TS>(Kimg, 32 * (s4 + u), d0, lane);
+                const bf16_t* pr = dSr + 32 * (s4 + u) * FB_QT;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[0]));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[1]));
+                da[u] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0], da[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[1], da[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[2], da[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[3], da[3], acc1, 0, 0, 0);
+        }
+        const int qi = qt0 + q0l + (lane & 15);     // accumulator: column = query, rows = d0 + 4 (l >> 4) + r
+        if (qi < Tq) {
+            bf16x4 ov;       // K was staged times scale * log2(e): dQ = scale dS K = dS K' / log2(e)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)((acc0[e] + acc1[e]) * LN2);
+            *(bf16x4*)(dqb + (size_t)qi * ldq + d0 + 4 * (lane >> 4)) = ov;
+        }
+    };
+
+    FB_PREFETCH(0);
+    FB_COMMIT(0);
+    if (ntiles > 1) FB_PREFETCH(FB_QT);
+    __syncthreads();         // K image, zeroed dS images, tile 0
+    // One barrier per tile.  Before barrier t: key phase of tile t (writes dS image t & 1, last read by the dQ block of
+    // tile t - 2, i.e. before barrier t - 1) and the store of tile t + 1 into tile buffer (t + 1) & 1 (last read by the key
+    // phase of tile t - 1).  After it: the dQ block of tile t, while other waves already run the key phase of tile t + 1.
+    // (Giving the two waves of a SIMD opposite phase orders through a wave-uniform switch was 10 us SLOWER: 92 vs 82.)
+    for (int t = 0; t < ntiles; ++t) {
+        if (active) phase_keys(t);
+        if (t + 1 < ntiles) FB_COMMIT((t + 1) & 1);
+        __syncthreads();
+        if (t + 2 < ntiles) FB_PREFETCH((t + 2) * FB_QT);
+        phase_dq(t);
+    }
+#undef FB_PREFETCH
+#undef FB_COMMIT
+    if (active) {
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            store_rows_T(dka[kbk], scale, dk_ + (size_t)b * Tk * ldk + h * DK, ldk, kk0 + 32 * kbk, Tk, lane);
+            store_rows_T(dva[kbk], 1.f, dv + (size_t)b * Tk * ldv + h * DK, ldv, kk0 + 32 * kbk, Tk, lane);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // exact fp32 VALU path (any dk <= 128)
 // ------------------------------------------------------------------------------------------
@@ -685,7 +977,24 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         if (dtype == ASR_F32) sdpa_delta_kernel<float><<<ceil_div(ngroups, 32), 256, 0, st>>>((const float*)o, (const float*)d_o, delta, B, H, Tq, dk, ldo);
         else sdpa_delta_kernel<bf16_t><<<ceil_div(ngroups, 32), 256, 0, st>>>((const bf16_t*)o, (const bf16_t*)d_o, delta, B, H, Tq, dk, ldo);
     }
-    if (mfma) {
+    static const int bwd_split = getenv("ASR_SDPA_BWD_SPLIT") ? atoi(getenv("ASR_SDPA_BWD_SPLIT")) : 0;   // 1: the dQ + dK/dV kernel pair for every shape (A/B runs)
+    if (mfma && Tk <= FB_KEYS && !bwd_split) {   // every key of a head fits one workgroup: single-pass backward
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+            attr = true;
+        }
+#define FB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
+        const bool masked = causal || window >= 0;
+        if (dthr && masked) sdpa_bwd_fused_bf16_kernel<true, true><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
+        else if (dthr) sdpa_bwd_fused_bf16_kernel<true, false><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
+        else if (masked) sdpa_bwd_fused_bf16_kernel<false, true><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
+        else sdpa_bwd_fused_bf16_kernel<false, false><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
+#undef FB_ARGS
+    } else if (mfma) {
         const int gq = ceil_div(Tq, 128) * H * B, gk = ceil_div(Tk, 128) * H * B;
 #define SDPA_BWD(D)                                                                                                                                        \
     do {                                                                                                                                                   \

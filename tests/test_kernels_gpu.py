@@ -130,9 +130,11 @@ def sdpa_ref(q, k, v, klen, causal, window, scale):
         vis = vis & (kj <= qi)
     if window >= 0:
         vis = vis & ((kj - qi).abs() <= window)
-    s = s.masked_fill(~vis, float("-inf"))
-    p = torch.softmax(s, -1)
-    return torch.einsum("bhqk,bkhd->bqhd", p, v), torch.logsumexp(s, -1)
+    dead = ~vis.any(-1, keepdim=True)          # a query with no admissible key (padded frame beyond the band): output 0, lse -inf
+    s = s.masked_fill(~vis & ~dead, float("-inf"))
+    p = torch.softmax(s, -1) * (~dead).to(s.dtype)
+    lse = torch.logsumexp(s, -1).masked_fill(dead.squeeze(-1), float("-inf"))
+    return torch.einsum("bhqk,bkhd->bqhd", p, v), lse
 
 
 SDPA_CASES = [
@@ -146,6 +148,12 @@ SDPA_CASES = [
     (torch.bfloat16, 1, 8, 500, 500, 64, False, -1, [500]),
     (torch.bfloat16, 2, 2, 300, 300, 64, False, 50, [300, 150]),  # +-50 frame band (long-form config)
     (torch.bfloat16, 2, 2, 20, 20, 16, True, -1, [20, 9]),        # bf16 storage, generic path
+    (torch.bfloat16, 2, 2, 500, 500, 64, False, -1, [500, 333]),  # config-2 head shape, ragged: single-pass backward (all keys in one workgroup)
+    (torch.bfloat16, 1, 2, 512, 512, 64, False, -1, [512]),       # exactly the 512 keys the single-pass backward holds
+    (torch.bfloat16, 1, 2, 97, 513, 64, False, -1, [513]),        # one key more: the dQ + dK/dV kernel pair
+    (torch.bfloat16, 2, 2, 300, 300, 64, False, 50, [300, 100]),  # band + short utterance: queries >= 151 of row 1 see NO key (lse -inf, zero gradients)
+    (torch.bfloat16, 2, 2, 24, 24, 64, True, -1, [24, 11]),       # decoder self-attention shape (causal, To ~ 20)
+    (torch.bfloat16, 1, 1, 40, 700, 64, False, 60, [650]),        # band on the kernel-pair path, dead rows included
 ]
 
 

@@ -25,4 +25,4 @@ fl = 4.0 * B * H * T * T * dk
 t = timeit(lambda: K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, o=o, lse=lse))
 print(f"fwd  {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s  {4 * B * T * d * 2 / t / 1e6:6.2f} TB/s algorithmic")
 t = timeit(lambda: K.sdpa_bwd(q, k, v, o, do, lse, klen, B, H, T, T, dk, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], False, window))
-print(f"bwd  {t:7.1f} us  {3.5 * fl / t / 1e6:6.0f} TF/s (7 products)")
+print(f"bwd  {t:7.1f} us  {2.5 * fl / t / 1e6:6.0f} TF/s (5 products: algorithmic)  {8 * B * T * d * 2 / t / 1e6:6.2f} TB/s algorithmic")
