@@ -74,6 +74,7 @@ SIGNATURES = {
     "asr_adam_step": (I, [P, P, P, P, P, Z, P, P, F, F, F, F, I, P]),
     "asr_loss_combine": (I, [P, I, P, P, I, F, F, P, P]),
     "asr_gemm_nt_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "asr_gemm_nt_add_ln_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "asr_gemm_tn_workspace_bytes": (Z, [I, I, I]),
     "asr_gemm_tn_bf16": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "asr_gemm_tn_bias_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),

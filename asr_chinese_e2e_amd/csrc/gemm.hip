@@ -556,6 +556,163 @@ static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bia
     gemm_nt_persist_kernel<ACT, NW, DBG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask);
 }
 
+// ------------------------------------------------------------------------- NT + residual + LayerNorm
+// out-projection / second feed-forward projection with their post-LN in the store tail (attention.py:59-60, module.py:72-75,
+// transformer_official.py:208, 211): y = LN(A W^T + bias + res) gamma + beta, rows t >= lens[b] zeroed, xhat and rstd kept for
+// the backward pass.  N = 512 is one whole row, so a workgroup owns 64 rows x 512 columns (250 workgroups at M = 16000) and
+// the row statistics never leave it: the separate add-LN launch and one write + read of the (M, 512) projection output disappear.
+//   * 8 waves as 2 (rows) x 4 (columns): wave tile 32 x 128 = 4 MFMA 32x32x16 blocks, accumulators start at the bias;
+//   * stage = [A 64 x 64 | W 512 x 64] bf16 = 72 KiB by LDS-DMA (whole 128-byte lines, swizzle on the source address as in
+//     the kernels above), ring of 2: the DMA instructions of k-step kt + 1 are issued between the MFMAs of kt;
+//   * store tail: C^T accumulators -> bf16 row-major tile in LDS (the ring is free by then), then 8 threads per row add the
+//     residual (16-byte coalesced loads), reduce mean / variance with three shuffles, normalise and store y and xhat
+//     with 16-byte row stores (the arithmetic of add_ln_fwd_kernel; the projection output is rounded to bf16 before the
+//     statistics exactly as the two-kernel path stores it).
+constexpr int LBM = 64, LBN = 512, LBK = 64;
+constexpr int LSTAGE = (LBM + LBN) * 128;      // 73728 B
+constexpr int LZS = 1040;                      // row stride (bytes) of the store-tail tile: 16-byte aligned, 260 dwords
+constexpr int LLDS = 2 * LSTAGE;               // 147456 B (store tail: 64 x 1040 = 66560 B + gamma / beta 4 KiB inside it)
+constexpr int LPPW = (LBM + LBN) / 8 / 8;      // 9 one-KiB DMA pieces per wave per stage
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_ln_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                            const bf16_t* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const int32_t* __restrict__ lens, bf16_t* __restrict__ Y, bf16_t* __restrict__ XH,
+                                                            float* __restrict__ rstd_out, int M, int K, int lda, int ldb, int T_) {
+    extern __shared__ __attribute__((aligned(16))) char smem_l[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * LBM;
+    const int wm = w >> 2, wn = w & 3;
+    const int r = lane & 31, hh = lane >> 5, srow = lane >> 3;
+    // DMA sources at k = 0: piece g = 9 w + j: 8-row group g of the stage (0..7 = A rows, 8..71 = W rows)
+    const bf16_t* src[LPPW];
+#pragma unroll
+    for (int j = 0; j < LPPW; ++j) {
+        const int g = w * LPPW + j;
+        const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));      // slot of chunk c in row R: c ^ ((R >> 1) & 7)
+        src[j] = g < LBM / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
+                             : W + (size_t)(8 * (g - LBM / 8) + srow) * ldb + schunk * 8;
+    }
+    auto dma = [&](int j, int slot, int k0) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + k0), (lds_void_t*)(smem_l + slot * LSTAGE + (w * LPPW + j) * 1024), 16, 0, 0);
+    };
+    f32x16 acc[4];   // [ni]: C^T blocks (n in registers, m on the lane), starting at the bias
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int nb = wn * 128 + ni * 32 + 8 * g4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
+                acc[ni][4 * g4 + e] = hh ? b_hi : b_lo;
+            }
+        }
+    const int sw = (r >> 1) & 7;
+    const int a_row = (wm * 32 + r) * 128;
+    const int w_row = LBM * 128 + (wn * 128 + r) * 128;      // + ni * 32 * 128
+    const int nk = K / LBK;
+#pragma unroll
+    for (int j = 0; j < LPPW; ++j) dma(j, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // stage kt landed in every wave; nobody still reads the slot refilled during this step
+        const bool more = kt + 1 < nk;
+        const int nslot = (kt + 1) & 1, nk0 = (kt + 1) * LBK;
+        const char* sb = smem_l + (kt & 1) * LSTAGE;
+        bf16x8 af[2], wf[2][4];
+        auto load_frags = [&](int buf, int ks) {
+            const int coff = ((2 * ks + hh) ^ sw) << 4;
+            af[buf] = *(const bf16x8*)(sb + a_row + coff);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
+        };
+        static_assert(LPPW == 9, "issue schedule below");
+        load_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1], acc[ni], 0, 0, 0);
+                // ring of 2: the next stage must land within THIS step, so its 9 DMA instructions go out early - one behind
+                // each of the first 9 MFMAs (spread over all 16 their latency was exposed at the next barrier: 25.0 -> ? us)
+                const int g = ks * 4 + ni;
+                if (g < LPPW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) dma(g, nslot, nk0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    __syncthreads();      // every wave has finished its fragment reads: the ring becomes the store-tail tile
+    float* gb = (float*)(smem_l + LBM * LZS);      // gamma (512) | beta (512)
+    for (int c = tid; c < 2 * LBN; c += 512) gb[c] = c < LBN ? gamma[c] : beta[c - LBN];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int nl = wn * 128 + ni * 32 + 8 * g4 + 4 * hh;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[ni][4 * g4 + e];
+            store4<bf16_t>((bf16_t*)(smem_l + (wm * 32 + r) * LZS + nl * 2), o);
+        }
+    __syncthreads();
+    // 8 threads per row, thread (row, seg) owns the 16-byte chunks p * 8 + seg, p = 0..7
+    const int row = tid >> 3, seg = tid & 7;
+    const int m = m0 + row;
+    const bool in_range = m < M;
+    const size_t grow = (size_t)(in_range ? m : M - 1) * LBN;
+    float z[64];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int ch = p * 8 + seg;
+        float a8[8], r8[8];
+        load8<bf16_t>((const bf16_t*)(smem_l + row * LZS + ch * 16), a8);
+        load8<bf16_t>(res + grow + ch * 8, r8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[p * 8 + e] = a8[e] + r8[e];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) s += z[i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    const float mean = s * (1.f / LBN);
+    float qv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) { z[i] -= mean; qv += z[i] * z[i]; }
+    qv += __shfl_xor(qv, 1, 64);
+    qv += __shfl_xor(qv, 2, 64);
+    qv += __shfl_xor(qv, 4, 64);
+    const float rstd = rsqrtf(qv * (1.f / LBN) + 1e-5f);
+    bool keep = true;
+    if (lens) {
+        const int mm = in_range ? m : M - 1, b = mm / T_, t = mm - b * T_;
+        keep = t < lens[b];
+    }
+    if (in_range) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int ch = p * 8 + seg;
+            float xh[8], out[8];
+            const f32x4 g0 = *(const f32x4*)(gb + ch * 8), g1 = *(const f32x4*)(gb + ch * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(gb + LBN + ch * 8), b1 = *(const f32x4*)(gb + LBN + ch * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[e] = z[p * 8 + e] * rstd;
+                const float gg = e < 4 ? g0[e] : g1[e - 4], bb = e < 4 ? b0[e] : b1[e - 4];
+                out[e] = keep ? xh[e] * gg + bb : 0.f;
+            }
+            store8<bf16_t>(XH + grow + ch * 8, xh);
+            store8<bf16_t>(Y + grow + ch * 8, out);
+        }
+        if (seg == 0) rstd_out[m] = rstd;
+    }
+}
+
 // ---------------------------------------------------------------------------------------- TN
 constexpr int TM = 64;     // reduction rows per LDS tile
 constexpr int TSW = 160;   // LDS row stride in elements (320 B == 64 mod 256: tr reads conflict-free)
@@ -1279,6 +1436,26 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     else
         ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
     ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
+    return ASR_OK;
+}
+
+extern "C" int asr_gemm_nt_add_ln_bf16(const void* A, const void* W, const float* bias, const void* res, const float* gamma, const float* beta,
+                                       const int32_t* lens, void* y, void* xhat, float* rstd, int B, int T, int N, int K, int lda, int ldb, void* stream) {
+    if (!A || !W || !res || !gamma || !beta || !y || !xhat || !rstd) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: null pointer");
+    if (B <= 0 || T <= 0 || K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: bad shape B=%d T=%d K=%d", B, T, K);
+    if (N != LBN) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: the fused kernel is built for rows of %d columns (got %d): use asr_gemm_nt_bf16 + asr_add_ln_fwd", LBN, N);
+    if (K % LBK || lda % 8 || ldb % 8 || lda < K || ldb < K) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: K must be a multiple of 64, lda / ldb multiples of 8 (K=%d lda=%d ldb=%d)", K, lda, ldb);
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)res | (uintptr_t)y | (uintptr_t)xhat) % 16) || (bias && (uintptr_t)bias % 16) || (((uintptr_t)gamma | (uintptr_t)beta) % 16))
+        ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: misaligned pointer");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LLDS);
+        attr = true;
+    }
+    const int M = B * T;
+    gemm_nt_ln_kernel<<<ceil_div(M, LBM), 512, LLDS, (hipStream_t)stream>>>((const bf16_t*)A, (const bf16_t*)W, bias, (const bf16_t*)res, gamma, beta, lens, (bf16_t*)y,
+                                                                            (bf16_t*)xhat, rstd, M, K, lda, ldb, T);
+    ASR_CHECK_LAUNCH("asr_gemm_nt_add_ln_bf16");
     return ASR_OK;
 }
 

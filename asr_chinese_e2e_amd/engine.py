@@ -303,6 +303,7 @@ class Engine:
         self._pending = []
         self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
         self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
+        self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
         self._ln_part, self._ln_pending = {}, []
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
@@ -318,6 +319,17 @@ class Engine:
         if not self.training or self.drop_p <= 0.0:
             return 0.0, 0
         return self.drop_p, (self.step_seed * 0x9E3779B1 + site * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF
+
+    def _fuse_ln(self, lin, a, res, drop_p):
+        """Projection + residual + LayerNorm as ONE kernel (asr_gemm_nt_add_ln_bf16): bf16, d_model = 512, no dropout at the site,
+        enough rows to fill the GPU with 64-row workgroups.  At config 2 the fused kernel takes 24.4 us against 15.2 + 12.1 us for
+        the out-projection (33.0 against 22.2 + 12.1 for w_2): it saves the write + read of the projection output (32 MB of the
+        96 MB the pair moves); the rest of the LayerNorm traffic (residual in, y and xhat out) is inherent, and a 64 x 512 tile
+        streams the whole weight matrix per 64 rows (1.5 x the L2 -> LDS traffic of the 256 x 128 tiling, which runs at the
+        ~67 GB/s per CU the L2 delivers).  Inside the training step the gain vanishes (3.360 vs 3.350 ms, two A/B pairs on one
+        box), so the two-kernel path stays the default; ASR_FUSE_LN=1 selects the fused kernel."""
+        return (self.fuse_ln and drop_p <= 0.0 and lin.wlp is not None and lin.N == 512 and a.shape[0] >= 4096 and res.dtype == torch.bfloat16
+                and K.gemm_nt_add_ln_supported(a, lin.wlp, res))
 
     def _ready(self, name):
         """Gradients at flat offsets >= this tensor's offset are final once the work queued so far
@@ -461,8 +473,11 @@ class Engine:
         pa, sa = self._drop(site)          # attention probabilities (attention.py:83)
         pf, sf = self._drop(site + 1)      # after fc, before residual + LN (attention.py:59)
         ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa)
-        a = m.fc.fwd(ctx)
-        y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)
+        if self._fuse_ln(m.fc, ctx, x, pf):      # out-projection + residual + LayerNorm in one kernel
+            y, xhat, rstd = K.gemm_nt_add_ln(ctx, m.fc.wlp, m.fc.b32, x, m.ln.g, m.ln.b, q_lens, B, Tq)
+        else:
+            a = m.fc.fwd(ctx)
+            y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)
         c.update(x=x, kv_src=kv_src, ctx=ctx, lse=lse, xhat=xhat, rstd=rstd, k_len=k_len, q_lens=q_lens, dims=(B, Tq, Tk), causal=causal,
                  window=window, cross=cross, drop=(pa, sa, pf, sf))
         return y, c
@@ -500,9 +515,12 @@ class Engine:
 
     def _ffn_block_fwd(self, f, x, B, T, lens, site):
         h = f.w1.fwd(x, act=ACT_RELU)
-        o = f.w2.fwd(h)
         pf, sf = self._drop(site)          # after w_2, before residual + LN (module.py:73)
-        y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o, drop_p=pf, drop_seed=sf, drop_mode=1)
+        if self._fuse_ln(f.w2, h, x, pf):
+            y, xhat, rstd = K.gemm_nt_add_ln(h, f.w2.wlp, f.w2.b32, x, f.ln.g, f.ln.b, lens, B, T)
+        else:
+            o = f.w2.fwd(h)
+            y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o, drop_p=pf, drop_seed=sf, drop_mode=1)
         return y, dict(x=x, h=h, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T), drop=(pf, sf))
 
     def _ffn_block_bwd(self, f, c, dy, dy2):

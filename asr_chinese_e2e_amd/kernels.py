@@ -494,6 +494,31 @@ def set_deterministic(on):
     return bool(lib.asr_set_deterministic(int(bool(on))))
 
 
+def gemm_nt_add_ln_supported(a, w, res):
+    return (a.dtype == torch.bfloat16 and w.shape[0] == 512 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+            and res.is_contiguous() and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def gemm_nt_add_ln(a, w, bias, res, gamma, beta, lens, B, T, y=None, xhat=None, rstd=None):
+    """y = LN(a @ w^T + bias + res) * gamma + beta with rows t >= lens[b] zeroed, in one kernel (N = 512).  Returns (y, xhat, rstd)."""
+    assert a.dtype == w.dtype == res.dtype == torch.bfloat16
+    M, K = a.shape
+    N = w.shape[0]
+    assert M == B * T and w.shape[1] == K and res.shape == (M, N) and res.is_contiguous() and a.stride(1) == 1 and w.stride(1) == 1
+    _chk_f32(bias, gamma, beta)
+    _chk_i32(lens)
+    assert gamma.numel() == N and beta.numel() == N and (bias is None or bias.numel() == N) and (lens is None or lens.numel() == B)
+    y = torch.empty_like(res) if y is None else y
+    xhat = torch.empty_like(res) if xhat is None else xhat
+    rstd = torch.empty(M, dtype=torch.float32, device=a.device) if rstd is None else rstd
+    assert y.is_contiguous() and xhat.is_contiguous() and y.shape == res.shape == xhat.shape
+    nb = 3.0 * res.numel() * 2 + a.numel() * 2            # A, res read; y, xhat written
+    timed("gemm_nt_ln", 2.0 * M * N * K, lambda: check(
+        lib.asr_gemm_nt_add_ln_bf16(_p(a), _p(w), _p(bias), _p(res), _p(gamma), _p(beta), _p(lens), _p(y), _p(xhat), _p(rstd), B, T, N, K,
+                                    a.stride(0), w.stride(0), _stream()), "asr_gemm_nt_add_ln_bf16"), nb)
+    return y, xhat, rstd
+
+
 def gemm_tn(dy, x, dw, accumulate=True, dbias=None, ws=None):
     """dw (N,K) f32 (+)= dy (M,N)^T @ x (M,K); bf16 operands, MFMA kernel.  dbias (N) f32 += column sums of dy.
     ws: a Workspace - needed in deterministic mode only (partial slabs, one per M-split)."""

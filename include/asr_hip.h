@@ -320,6 +320,16 @@ int asr_loss_combine(const float* row_nll, int M, const float* n_valid, const fl
  */
 int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void* res, void* C,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, void* stream);
+/* Projection + residual + LayerNorm in ONE kernel (N must be 512 = d_model: a workgroup owns whole rows):
+ *   y = LN(A W^T + bias + res) * gamma + beta, rows t >= lens[b] zeroed (lens may be NULL); xhat, rstd as asr_add_ln_fwd.
+ * Replaces:  fc -> (dropout) -> layer_norm(out + residual) -> *= non_pad_mask      attention.py:59-60, transformer_official.py:208
+ *            w_2 -> (dropout) -> layer_norm(out + residual) -> *= non_pad_mask     module.py:71-75, transformer_official.py:211
+ * i.e. asr_gemm_nt_bf16 followed by asr_add_ln_fwd without the round trip of the (B*T, 512) projection output through HBM.
+ * A: (B*T, K) lda bf16; W: (512, K) ldb bf16; bias (512) f32 or NULL; res, y, xhat: (B*T, 512) bf16 contiguous; gamma, beta: (512) f32;
+ * rstd: (B*T) f32.  No dropout form (dropout > 0: use the two-kernel path). */
+int asr_gemm_nt_add_ln_bf16(const void* A, const void* W, const float* bias, const void* res, const float* gamma,
+                            const float* beta, const int32_t* lens, void* y, void* xhat, float* rstd, int B, int T,
+                            int N, int K, int lda, int ldb, void* stream);
 /* Weight gradient  dW (N, K) f32 (+)= dY^T (M, N)^T * X (M, K)   ("TN": reduction over rows).
  * ws: NULL / 0 in the default mode; in deterministic mode a 16-byte aligned buffer of
  * asr_gemm_tn_workspace_bytes(M, N, K) bytes (partial slabs, one per M-split). */

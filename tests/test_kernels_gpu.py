@@ -490,6 +490,48 @@ def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     close(out, ref, rtol=1e-2, atol=1e-2, what="gemm_nt")
 
 
+@pytest.mark.parametrize("B,T,K_,use_bias,use_len", [(32, 500, 512, True, True), (32, 500, 1024, True, True), (3, 70, 64, False, False), (2, 333, 512, True, True)])
+def test_gemm_nt_add_ln_fused(K, B, T, K_, use_bias, use_len):
+    """Projection + residual + LayerNorm in one kernel (fc / w_2 with their post-LN, attention.py:59-60, module.py:72-75) ==
+    the fp64 formula, and == the two-kernel path (asr_gemm_nt_bf16 -> asr_add_ln_fwd) to bf16 rounding; padded rows are exact zeros."""
+    torch.manual_seed(B * T + K_)
+    M, N = B * T, 512
+    a = (torch.randn(M, K_) * 0.7).bfloat16()
+    w = (torch.randn(N, K_) * K_ ** -0.5).bfloat16()
+    bias = torch.randn(N) * 0.1 if use_bias else None
+    res = torch.randn(M, N).bfloat16()
+    gamma, beta = 1 + 0.1 * torch.randn(N), 0.05 * torch.randn(N)
+    lens = torch.randint(T // 2, T + 1, (B,), dtype=torch.int32) if use_len else None
+    if lens is not None:
+        lens[0] = T
+    ad, wd, rd = a.to(DEV), w.to(DEV), res.to(DEV)
+    bd = bias.to(DEV) if use_bias else None
+    ld = lens.to(DEV) if use_len else None
+    y, xhat, rstd = K.gemm_nt_add_ln(ad, wd, bd, rd, gamma.to(DEV), beta.to(DEV), ld, B, T)
+    # two-kernel path on the same inputs
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(ad, wd, bd, c)
+    y2, xhat2, rstd2 = K.add_ln_fwd(c.clone(), rd, gamma.to(DEV), beta.to(DEV), None, ld, B, T)
+    close(y, y2.float(), rtol=2e-2, atol=2e-2, what="fused vs two kernels: y")
+    close(xhat, xhat2.float(), rtol=2e-2, atol=2e-2, what="fused vs two kernels: xhat")
+    close(rstd, rstd2, rtol=5e-3, atol=1e-5, what="fused vs two kernels: rstd")
+    # fp64 formula (projection rounded to bf16 before the statistics, as both paths store it)
+    proj = (a.double() @ w.double().t() + (bias.double() if use_bias else 0)).bfloat16().double()
+    z = proj + res.double()
+    mean, var = z.mean(-1, keepdim=True), z.var(-1, unbiased=False, keepdim=True)
+    xr = (z - mean) / torch.sqrt(var + 1e-5)
+    yr = xr * gamma.double() + beta.double()
+    if use_len:
+        keep = (torch.arange(T).view(1, T) < lens.view(B, 1)).reshape(M, 1)
+        yr = yr * keep
+        assert float(y.float().cpu()[~keep.squeeze(1)].abs().max() if (~keep).any() else 0.0) == 0.0
+    close(xhat, xr, rtol=1.6e-2, atol=2.5e-2, what="fused xhat vs fp64")      # one bf16 ulp of the projection moves xhat by ~2^-9 |proj| rstd
+    close(y, yr, rtol=1.6e-2, atol=3e-2, what="fused y vs fp64")
+    close(rstd, (1 / torch.sqrt(var + 1e-5)).squeeze(1), rtol=5e-3, atol=1e-5, what="fused rstd vs fp64")
+    with pytest.raises(RuntimeError):
+        K.gemm_nt_add_ln(ad, wd[:256], bd[:256] if use_bias else None, rd[:, :256].contiguous(), gamma[:256].to(DEV), beta[:256].to(DEV), ld, B, T)
+
+
 @pytest.mark.parametrize("M,N,K_", [(16000, 1024, 512), (777, 264, 128), (4100, 512, 1536)])
 def test_gemm_nt_relu_mask_epilogue(K, M, N, K_):
     """ACT_RELU_MASK: C = (A W^T) where the mask tensor is > 0, else exactly 0 (the ReLU backward folded into the
