@@ -327,6 +327,11 @@ class _SpeechTransformer(BaseModel):
         row_nll = nll = None
         d_enc = None
         pg = None
+        ctc_done = None
+        ctc_scale = dict(grad_scale=lam * loss_scale, grad_scale_div=batch_div) if batch_div is not None else dict(grad_scale=lam * loss_scale / float(B))
+        ctc_async = (self.use_decoder and self.use_ctc and eng.overlap_ctc and not eng.deterministic and not torch.cuda.is_current_stream_capturing())
+        if ctc_async:      # joint model: the CTC branch runs beside the decoder's forward pass
+            nll, d_enc, ctc_done = eng.ctc_branch_async(enc, wave_len, labels32, lab_len, B, T, **ctc_scale)
         if self.use_decoder:
             cross_len = input.tgt_len.to(torch.int32) if self.cross_mask == "ref_compat" else wave_len
             pred, dcache = eng.decoder_fwd(prep, enc, cross_len, B, T)
@@ -334,15 +339,12 @@ class _SpeechTransformer(BaseModel):
                 pg = (pred.view(B, -1, self.V).argmax(-1), ys_out)
             w_ce = (1.0 - lam) if self.use_ctc else 1.0
             row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, smoothing=self.label_smoothing, grad_scale=w_ce * loss_scale, dlogits=pred)
-        if self.use_ctc:
-            if batch_div is not None:     # global batch size, on the device
-                nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale=lam * loss_scale, grad_scale_div=batch_div)
-            else:
-                nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale=lam * loss_scale / float(B))
+        if self.use_ctc and not ctc_async:
+            nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, **ctc_scale)
         if self.use_decoder:
             if d_enc is None:
                 d_enc = torch.zeros_like(enc)
-            eng.decoder_bwd(dcache, dpred, d_enc)
+            eng.decoder_bwd(dcache, dpred, d_enc, d_enc_ready=ctc_done)
         eng.encoder_bwd(ecache, d_enc)
         loss = K.loss_combine(row_nll, n_valid, nll, (1.0 - lam) if self.use_ctc else 1.0, lam)
         return loss, pg

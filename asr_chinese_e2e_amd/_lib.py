@@ -42,6 +42,7 @@ LN_REDUCE_MAX = 16
 SIGNATURES = {
     "asr_abi_version": (I, []),
     "asr_last_error": (I, [c_char_p, Z]),
+    "asr_stream_fork": (I, [P, P]),
     "asr_get_deterministic": (I, []),
     "asr_set_deterministic": (I, [I]),
     "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, U, I, I, P]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "asr_adam_step": (I, [P, P, P, P, P, Z, P, P, F, F, F, F, I, P]),
     "asr_loss_combine": (I, [P, I, P, P, I, F, F, P, P]),
     "asr_gemm_nt_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "asr_gemm_small_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "asr_gemm_nt_add_ln_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "asr_gemm_tn_workspace_bytes": (Z, [I, I, I]),
     "asr_gemm_tn_bf16": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),

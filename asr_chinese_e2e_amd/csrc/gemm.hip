@@ -556,6 +556,104 @@ static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bia
     gemm_nt_persist_kernel<ACT, NW, DBG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask);
 }
 
+// ------------------------------------------------------------------------- small-M projections (decoder)
+// The decoder works on B * To ~ 550 rows: a 256 x 128 persistent tile gives such a GEMM 12 workgroups and ~11 us of
+// mostly fixed cost (144 KiB ring prologue, store tail), and the library GEMM its input gradients go to costs the host
+// ~28 us per call (the joint step is host-bound as much as GPU-bound).  This kernel: 64 x 64 tiles (72 .. 216 workgroups),
+// 4 waves (2 x 2, one MFMA 32x32x16 block each), register-staged double-buffered LDS tiles, one barrier per 64-deep k-step.
+//   TB = false: B is (N, K), K-contiguous: C = A B^T            (forward: y = x W^T + bias, optional ReLU)
+//   TB = true : B is (K, N), N-contiguous: C = A B              (input gradient: dx = dy W; W as stored, no transposed copy:
+//               the operand fragments come from transposed LDS reads in natural k order)
+// mask (TB only): C = 0 where mask <= 0 (the ReLU backward of module.py:70-71 in the store tail).
+constexpr int SM = 64, SS = 72;      // tile edge, LDS row stride (elements)
+struct Stage2 { u32x4 v[2]; };
+__device__ __forceinline__ void sm_load(Stage2& st, const bf16_t* __restrict__ base, size_t ld, int row0, int rows, int c0, int cols, int tid) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int id = tid + 256 * c, row = id >> 3, ch = id & 7;
+        const int gr = row0 + row, gc = c0 + ch * 8;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        st.v[c] = (gr < rows && gc < cols) ? *(const u32x4*)(base + (size_t)gr * ld + gc) : z;
+    }
+}
+__device__ __forceinline__ void sm_store(const Stage2& st, bf16_t* tile, int tid) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int id = tid + 256 * c, row = id >> 3, ch = id & 7;
+        *(u32x4*)(tile + row * SS + ch * 8) = st.v[c];
+    }
+}
+// operand fragment from a [k][n] tile by transposed reads, natural k order: lane (r, hh), j -> tile[16 s + 8 hh + j][col0 + r]
+__device__ __forceinline__ bf16x8 sm_frag_tr(const bf16_t* tile, int col0, int s, int lane) {
+    const int G = lane >> 4, i = lane & 15;
+    const bf16_t* p = tile + (16 * s + 8 * (G >> 1) + (i >> 2)) * SS + col0 + 16 * (G & 1) + 4 * (i & 3);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * SS));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool TB, int ACT>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, const float* __restrict__ bias,
+                                                         const bf16_t* __restrict__ mask, bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb,
+                                                         int ldc, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * SM * SS];      // [2 buffers][A | B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+    const int m0 = tm * SM, n0 = tn * SM;
+    const int wm = w >> 1, wn = w & 1, r = lane & 31, hh = lane >> 5;
+    f32x16 acc;   // C^T block: n in registers, m on the lane
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    Stage2 sa, sb;
+    auto load = [&](int k0) {
+        sm_load(sa, A, lda, m0, M, k0, K, tid);
+        if (TB) sm_load(sb, Bm, ldb, k0, K, n0, N, tid);     // rows = k, columns = n
+        else sm_load(sb, Bm, ldb, n0, N, k0, K, tid);        // rows = n, columns = k
+    };
+    load(0);
+    sm_store(sa, smem, tid);
+    sm_store(sb, smem + SM * SS, tid);
+    __syncthreads();
+    const int nk = (K + SM - 1) / SM;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bf16_t* As = smem + (kt & 1) * 2 * SM * SS;
+        const bf16_t* Bs = As + SM * SS;
+        if (kt + 1 < nk) load((kt + 1) * SM);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 af = *(const bf16x8*)(As + (wm * 32 + r) * SS + 16 * ks + 8 * hh);
+            const bf16x8 bf = TB ? sm_frag_tr(Bs, wn * 32, ks, lane) : *(const bf16x8*)(Bs + (wn * 32 + r) * SS + 16 * ks + 8 * hh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc, 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            bf16_t* nx = smem + ((kt + 1) & 1) * 2 * SM * SS;      // last read in step kt - 1, before the barrier below of that step
+            sm_store(sa, nx, tid);
+            sm_store(sb, nx + SM * SS, tid);
+        }
+        __syncthreads();
+    }
+    const int m = m0 + wm * 32 + r;
+    if (m >= M) return;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + wn * 32 + 8 * g4 + 4 * hh;
+        if (n >= N) continue;      // N % 8 == 0: a 4-element piece is inside or outside as a whole
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = acc[4 * g4 + e] + (bias ? bias[n + e] : 0.f);
+            if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
+            o[e] = x;
+        }
+        if (ACT == ASR_ACT_RELU_MASK) {
+            const f32x4 h4 = load4<bf16_t>(mask + (size_t)m * ldc + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = h4[e] > 0.f ? o[e] : 0.f;
+        }
+        store4<bf16_t>(C + (size_t)m * ldc + n, o);
+    }
+}
+
 // ------------------------------------------------------------------------- NT + residual + LayerNorm
 // out-projection / second feed-forward projection with their post-LN in the store tail (attention.py:59-60, module.py:72-75,
 // transformer_official.py:208, 211): y = LN(A W^T + bias + res) gamma + beta, rows t >= lens[b] zeroed, xhat and rstd kept for
@@ -1436,6 +1534,34 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     else
         ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
     ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
+    return ASR_OK;
+}
+
+extern "C" int asr_gemm_small_bf16(const void* A, const void* Bm, const float* bias, const void* mask, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                   int trans_b, int act, void* stream) {
+    if (!A || !Bm || !C) ASR_FAIL(ASR_EINVAL, "asr_gemm_small_bf16: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_small_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || ldc % 4 || lda < K || ldc < N || ldb < (trans_b ? N : K))
+        ASR_FAIL(ASR_EINVAL, "asr_gemm_small_bf16: N, K, lda, ldb must be multiples of 8, ldc of 4 (N=%d K=%d lda=%d ldb=%d ldc=%d)", N, K, lda, ldb, ldc);
+    if ((((uintptr_t)A | (uintptr_t)Bm) % 16) || ((uintptr_t)C % 8) || (mask && (uintptr_t)mask % 8) || (bias && (uintptr_t)bias % 4)) ASR_FAIL(ASR_EINVAL, "asr_gemm_small_bf16: misaligned pointer");
+    if (act != ASR_ACT_NONE && act != ASR_ACT_RELU && act != ASR_ACT_RELU_MASK) ASR_FAIL(ASR_EINVAL, "asr_gemm_small_bf16: unknown activation %d", act);
+    if ((act == ASR_ACT_RELU_MASK) != (mask != nullptr)) ASR_FAIL(ASR_EINVAL, "asr_gemm_small_bf16: ASR_ACT_RELU_MASK needs the activations in `mask` (and only it)");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_n = ceil_div(N, SM), grid = tiles_n * ceil_div(M, SM);
+    const bf16_t *a = (const bf16_t*)A, *b = (const bf16_t*)Bm, *mk = (const bf16_t*)mask;
+    bf16_t* c = (bf16_t*)C;
+#define SMALL(TB_, ACT_) gemm_small_kernel<TB_, ACT_><<<grid, 256, 0, st>>>(a, b, bias, mk, c, M, N, K, lda, ldb, ldc, tiles_n)
+    if (trans_b) {
+        if (act == ASR_ACT_RELU_MASK) SMALL(true, ASR_ACT_RELU_MASK);
+        else if (act == ASR_ACT_RELU) SMALL(true, ASR_ACT_RELU);
+        else SMALL(true, ASR_ACT_NONE);
+    } else {
+        if (act == ASR_ACT_RELU_MASK) SMALL(false, ASR_ACT_RELU_MASK);
+        else if (act == ASR_ACT_RELU) SMALL(false, ASR_ACT_RELU);
+        else SMALL(false, ASR_ACT_NONE);
+    }
+#undef SMALL
+    ASR_CHECK_LAUNCH("asr_gemm_small_bf16");
     return ASR_OK;
 }
 

@@ -42,6 +42,27 @@ extern "C" int asr_last_error(char* buf, size_t n) {
     return (int)strlen(g_err);
 }
 
+// ---- stream fork: "everything queued on `to` from now on runs after what is queued on `from` so far" ----------------------
+// One call = hipEventRecord + hipStreamWaitEvent on an event from a process-wide pool (timing disabled).  The engine forks
+// to its side streams ~50 times per step; through torch.cuda.Event objects that costs the host ~12 us each (measured),
+// through this entry point ~2 us.  Re-using an event is safe: a wait refers to the record that preceded it at call time.
+// Not for use during stream capture (captured events belong to their graph): the caller keeps torch events there.
+static hipEvent_t g_fork_events[256];
+static unsigned g_fork_next = 0;
+static bool g_fork_init = false;
+extern "C" int asr_stream_fork(void* from_stream, void* to_stream) {
+    if (!g_fork_init) {
+        for (int i = 0; i < 256; ++i)
+            if (hipEventCreateWithFlags(&g_fork_events[i], hipEventDisableTiming) != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_fork: hipEventCreateWithFlags failed");
+        g_fork_init = true;
+    }
+    hipEvent_t ev = g_fork_events[g_fork_next++ & 255u];
+    hipError_t e = hipEventRecord(ev, (hipStream_t)from_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)to_stream, ev, 0);
+    if (e != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_fork: %s", hipGetErrorString(e));
+    return ASR_OK;
+}
+
 namespace {
 
 constexpr int EW_BLOCK = 256;

@@ -126,9 +126,18 @@ class Linear:
         return sub
 
     # ---- forward
+    SMALL_M = int(os.environ.get("ASR_SMALL_M", "1024"))      # rows up to which the 64 x 64-tile kernel serves a projection (the decoder's B*To)
+
+    def small(self, x, reduce_len):
+        """True when the small-M kernel (asr_gemm_small_bf16) takes this operand: few rows, bf16, 8-element alignment."""
+        return (x.dtype == torch.bfloat16 and x.shape[0] <= Linear.SMALL_M and self.N % 8 == 0 and self.K % 8 == 0 and x.stride(0) % 8 == 0
+                and x.stride(1) == 1 and x.data_ptr() % 16 == 0 and reduce_len <= 2048)
+
     def fwd(self, x, act=ACT_NONE, out=None):
         M = x.shape[0]
         out = torch.empty(M, self.N, dtype=x.dtype, device=x.device) if out is None else out
+        if self.small(x, self.K) and out.stride(0) % 4 == 0:
+            return K.gemm_small(x, self.wlp, self.b32, out, trans_b=False, act=act)
         if x.dtype == torch.bfloat16 and K.gemm_nt_supported(M, self.N, self.K, x.stride(0), self.wlp.stride(0), out.stride(0)):
             K.gemm_nt(x, self.wlp, self.b32, out, act)
             return out
@@ -153,6 +162,10 @@ class Linear:
         of the ReLU in front of this projection - their backward mask is applied in the GEMM's store tail."""
         w = self.wlp if dy.dtype == torch.bfloat16 else self.w32
         flops = 2.0 * dy.shape[0] * self.N * self.K
+        if not accumulate and self.small(dy, self.N) and (out is None or out.stride(0) % 4 == 0):
+            # few rows (decoder): dX = dY W straight from the weight as stored, on the 64 x 64-tile kernel (no library call, no transposed copy)
+            out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
+            return K.gemm_small(dy, self.wlp, None, out, trans_b=True, act=ACT_RELU_MASK if relu_mask is not None else ACT_NONE, mask=relu_mask)
         if self.own_dgrad(dy, accumulate):
             # dX = dY W as an NT product with the transposed weight copy: own MFMA kernel instead of the library GEMM
             out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
@@ -279,6 +292,12 @@ class Engine:
         # Weight/bias gradients are off the critical path (only the optimizer reads them): they run
         # on a side stream, concurrently with the dgrad chain on the main stream, so the short,
         # latency-bound kernels of both chains fill each other's idle CUs.
+        # the CTC branch of the joint model runs on its own stream beside the decoder's forward pass (ctc_branch_async);
+        # off in deterministic mode (the weight gradients then share one scratch buffer on whatever stream is current)
+        self.ctc_stream = torch.cuda.Stream(device=flat.device)
+        self.ws_ctc = K.Workspace(flat.device)
+        self.overlap_ctc = os.environ.get("ASR_CTC_OVERLAP", "1") == "1"
+        self.aux_overlap = os.environ.get("ASR_AUX_OVERLAP", "1") == "1" and not K.deterministic()   # cross-attention K|V work on that stream too
         self.side = torch.cuda.Stream(device=flat.device)
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
@@ -372,6 +391,15 @@ class Engine:
         self._ev_next = (self._ev_next + 1) & 63
         return ev
 
+    def _fork(self, stream):
+        """`stream` continues after everything queued on the current stream so far."""
+        if torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            stream.wait_event(ev)
+        else:
+            K.stream_fork(stream.cuda_stream)
+
     def refresh_transposes(self):
         """W^T copies for the own-kernel input gradients: one launch on the side stream, which is idle during the
         forward pass; the backward pass waits for it (wait_transposes) before its first input-gradient GEMM.
@@ -379,9 +407,7 @@ class Engine:
         module's train / eval flag says."""
         if self._tr_tiles is None:
             return
-        ev = self._event()
-        ev.record()
-        self.side.wait_event(ev)
+        self._fork(self.side)
         K.STREAM_OVERRIDE = self._side_handle
         try:
             K.transpose_batched(self.flat.lp, self.flat.lpT, self._tr_tiles)
@@ -411,9 +437,7 @@ class Engine:
         if not self.overlap_wgrad:
             K.gemm_tn_grouped(probs, accumulate=True)
             return
-        ev = self._event()
-        ev.record()
-        self.side.wait_event(ev)
+        self._fork(self.side)
         K.STREAM_OVERRIDE = self._side_handle
         try:
             K.gemm_tn_grouped(probs, accumulate=True)
@@ -436,9 +460,7 @@ class Engine:
                 lin.bgrad(bias_from, self.ws_side)
             lin.wgrad(dy, x, with_bias=fused, ws=self.ws_side)
             return
-        ev = self._event()
-        ev.record()
-        self.side.wait_event(ev)
+        self._fork(self.side)
         own = dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
         if own:     # only own kernels run: hand them the side stream directly instead of switching torch's current stream
             K.STREAM_OVERRIDE = self._side_handle
@@ -457,7 +479,7 @@ class Engine:
             for t in (dy, x):
                 t.record_stream(self.side)
 
-    def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross, site):
+    def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross, site, kv_pre=None):
         """x: (B*Tq, d) queries + residual; kv_src: (B*Tk, d).  Returns output and cache."""
         H, dk, hd = self.H, self.dk, self.H * self.dk
         c = {}
@@ -467,7 +489,11 @@ class Engine:
             c["qkv"] = qkv
         else:
             q = m.q.fwd(x)
-            kv = m.kv.fwd(kv_src)
+            if kv_pre is not None:      # projected ahead of time on the auxiliary stream (decoder_fwd)
+                kv, ev = kv_pre
+                torch.cuda.current_stream().wait_event(ev)
+            else:
+                kv = m.kv.fwd(kv_src)
             k, v = kv[:, :hd], kv[:, hd:]
             c["q"], c["kv"] = q, kv
         pa, sa = self._drop(site)          # attention probabilities (attention.py:83)
@@ -508,7 +534,16 @@ class Engine:
             self._wgrad(m.q, dq, c["x"], bias_from=dq)
             self._wgrad(m.kv, dkv, c["kv_src"], bias_from=dkv)
             dx = m.q.dgrad(dq)
-            m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
+            if self.aux_overlap and not torch.cuda.is_current_stream_capturing():
+                # d_enc += dK|dV W_kv (a 16000-row GEMM) is off the decoder's dependent chain: only the encoder's backward pass
+                # needs d_enc.  It runs on the auxiliary stream (in order behind the CTC branch and the previous layers' adds);
+                # decoder_bwd joins that stream at its end.
+                self._fork(self.ctc_stream)
+                with torch.cuda.stream(self.ctc_stream):
+                    m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
+                dkv.record_stream(self.ctc_stream)
+            else:
+                m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
         if self._block_flush:
             self.flush_wgrads()
         return dx, dz
@@ -528,7 +563,7 @@ class Engine:
         pf, sf = c["drop"]
         dz, dxg = self._ln_bwd(f.ln, f.w2.gb, dy, dy2, c["xhat"], c["rstd"], c["lens"], B, T, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(f.w2, dxg, c["h"])
-        fused_relu = self.fuse_relu_bwd and f.w2.own_dgrad(dxg) and c["h"].is_contiguous() and c["h"].data_ptr() % 16 == 0
+        fused_relu = self.fuse_relu_bwd and (f.w2.own_dgrad(dxg) or f.w2.small(dxg, f.w2.N)) and c["h"].is_contiguous() and c["h"].data_ptr() % 16 == 0
         dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)     # ReLU backward in the GEMM's store tail
         fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
         if not fused_relu:
@@ -584,10 +619,27 @@ class Engine:
         self._ready("encoder.linear_in.weight")
 
     # ------------------------------------------------------------------ CTC head
-    def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None):
+    def ctc_branch_async(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, grad_scale_div=None):
+        """The whole CTC branch (head projection, forward-backward, its input gradient and weight gradient) on its own stream,
+        beside the decoder's forward pass: the decoder is a chain of ~70 launches on B*To ~ 550 rows that leaves most of the
+        GPU idle, the CTC branch is four large kernels (~0.3 ms at config 3) that do not depend on it.  Returns (nll, d_enc,
+        event): consumers on the main stream wait for the event (decoder_bwd does, before its first write into d_enc)."""
+        main = torch.cuda.current_stream()
+        self._fork(self.ctc_stream)
+        with torch.cuda.stream(self.ctc_stream):
+            nll, d_enc = self.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale, grad_scale_div=grad_scale_div, ws=self.ws_ctc)
+            done = torch.cuda.Event()
+            done.record(self.ctc_stream)
+        for t in (enc, wave_len, labels32, lab_len):
+            t.record_stream(self.ctc_stream)
+        for t in (nll, d_enc):
+            t.record_stream(main)
+        return nll, d_enc, done
+
+    def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None, ws=None):
         """Returns (nll (B,), d_enc contribution or None)."""
         logits = self.ctc_lo.fwd(enc)
-        nll, dl = K.ctc_fwd_bwd(logits.view(B, T, self.V), wave_len, labels32, lab_len, self.ws, blank=0, grad_scale=grad_scale,
+        nll, dl = K.ctc_fwd_bwd(logits.view(B, T, self.V), wave_len, labels32, lab_len, ws if ws is not None else self.ws, blank=0, grad_scale=grad_scale,
                                 dlogits=logits.view(B, T, self.V) if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div)
         if not want_grad:
             return nll, None
@@ -610,17 +662,34 @@ class Engine:
         pe_, se_ = self._drop(2)           # dropout(emb * scale + PE)  (transformer_official.py:306-307)
         x = K.embed_pe_fwd(ys_in.reshape(-1), self.emb32, self.pe, self.d ** -0.5, B, To, self.dtype, drop_p=pe_, drop_seed=se_)
         cache = dict(B=B, T=T, To=To, ys_in=ys_in, layers=[], drop=(pe_, se_))
+        kv_pre = [None] * self.L
+        if self.aux_overlap and not torch.cuda.is_current_stream_capturing():
+            # the six cross-attention K|V projections of the encoder output (16000-row GEMMs, 26 us each) do not depend on the
+            # decoder state: they run on the auxiliary stream while the main stream works through the decoder's small kernels
+            self._fork(self.ctc_stream)
+            with torch.cuda.stream(self.ctc_stream):
+                for i, (slf, cross, ffn) in enumerate(self.dec):
+                    kv = cross.kv.fwd(enc)
+                    e = torch.cuda.Event()
+                    e.record(self.ctc_stream)
+                    kv.record_stream(torch.cuda.current_stream())
+                    kv_pre[i] = (kv, e)
+            enc.record_stream(self.ctc_stream)
+            for kv, _ in kv_pre:
+                kv.record_stream(torch.cuda.current_stream())
         for i, (slf, cross, ffn) in enumerate(self.dec):
             x1, c1 = self._attn_block_fwd(slf, x, x, B, To, To, dec_len, dec_len, True, -1, False, site=100 + 8 * i)
-            x2, c2 = self._attn_block_fwd(cross, x1, enc, B, To, T, cross_len, dec_len, False, -1, True, site=102 + 8 * i)
+            x2, c2 = self._attn_block_fwd(cross, x1, enc, B, To, T, cross_len, dec_len, False, -1, True, site=102 + 8 * i, kv_pre=kv_pre[i])
             x, c3 = self._ffn_block_fwd(ffn, x2, B, To, dec_len, site=104 + 8 * i)
             cache["layers"].append((c1, c2, c3))
         pred = self.prj.fwd(x)
         cache["x_last"] = x
         return pred, cache
 
-    def decoder_bwd(self, cache, dpred, d_enc):
-        """dpred (B*To, V); accumulates the encoder-output gradient into d_enc (B*T, d) in place."""
+    def decoder_bwd(self, cache, dpred, d_enc, d_enc_ready=None):
+        """dpred (B*To, V); accumulates the encoder-output gradient into d_enc (B*T, d) in place.
+        d_enc_ready: event after which d_enc holds the CTC branch's contribution (ctc_branch_async); waited for before the
+        first cross-attention block adds to it."""
         self._in_decoder = True
         self.wait_transposes()
         self._wgrad(self.prj, dpred, cache["x_last"])
@@ -629,12 +698,17 @@ class Engine:
             slf, cross, ffn = self.dec[i]
             c1, c2, c3 = cache["layers"][i]
             dx, dz = self._ffn_block_bwd(ffn, c3, dy, dy2)
+            if d_enc_ready is not None:
+                torch.cuda.current_stream().wait_event(d_enc_ready)
+                d_enc_ready = None
             dx, dz = self._attn_block_bwd(cross, c2, dx, dz, d_kv_src=d_enc)
             dx, dz = self._attn_block_bwd(slf, c1, dx, dz)
             dy, dy2 = dx, dz
             self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
         dx = dy + dy2  # gradient wrt the embedding output
         K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1])
+        if self.aux_overlap:
+            torch.cuda.current_stream().wait_stream(self.ctc_stream)      # d_enc is complete (CTC branch + every cross-attention add)
         self._in_decoder = False
         self._ready("decoder.tgt_word_emb.weight")
         if self.use_ctc:

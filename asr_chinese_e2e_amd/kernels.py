@@ -45,6 +45,13 @@ def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
 
 
+def stream_fork(to_stream_handle, from_stream_handle=None):
+    """Work queued on `to` from now on runs after what is queued on `from` (default: torch's current stream) so far.
+    Raw stream handles (ints); ~2 us of host time against ~12 us for torch.cuda.Event record + wait."""
+    frm = _stream() if from_stream_handle is None else ctypes.c_void_p(from_stream_handle)
+    check(lib.asr_stream_fork(frm, ctypes.c_void_p(to_stream_handle)), "asr_stream_fork")
+
+
 def bind_device(device):
     """One process drives ONE GPU: the launch stream is looked up on this device from now on.  Called when a model
     builds its engine; a model on a device other than torch's current one is refused (its kernels would be issued
@@ -111,7 +118,9 @@ TIMER = None   # set to a LaunchTimer by bench.py
 
 
 def timed(name, work, fn, nbytes=0.0):
-    return fn() if TIMER is None else TIMER.run(name, work, fn, nbytes)
+    if TIMER is None:
+        return fn()
+    return TIMER.run(name, work, fn, nbytes)
 
 
 class Workspace:
@@ -492,6 +501,21 @@ def deterministic():
 def set_deterministic(on):
     """Process-wide switch (see include/asr_hip.h); returns the previous value.  Engines read it when they are built."""
     return bool(lib.asr_set_deterministic(int(bool(on))))
+
+
+def gemm_small(a, bm, bias, out, trans_b=False, act=ACT_NONE, mask=None):
+    """Small-M projection (see include/asr_hip.h): out (M, N) = act(a (M, K) @ bm^T + bias) with bm (N, K), or a @ bm with bm (K, N) when trans_b."""
+    M, K = a.shape
+    N = out.shape[1]
+    assert a.dtype == bm.dtype == out.dtype == torch.bfloat16 and out.shape[0] == M
+    assert bm.shape == ((K, N) if trans_b else (N, K)) and a.stride(1) == 1 and bm.stride(1) == 1 and out.stride(1) == 1
+    _chk_f32(bias)
+    if mask is not None:
+        assert mask.dtype == torch.bfloat16 and mask.shape == out.shape and mask.stride() == out.stride()
+    timed("gemm_small", 2.0 * M * N * K, lambda: check(
+        lib.asr_gemm_small_bf16(_p(a), _p(bm), _p(bias), _p(mask), _p(out), M, N, K, a.stride(0), bm.stride(0), out.stride(0), int(trans_b), int(act),
+                                _stream()), "asr_gemm_small_bf16"))
+    return out
 
 
 def gemm_nt_add_ln_supported(a, w, res):

@@ -60,6 +60,11 @@ int asr_last_error(char* buf, size_t n);
  * and add the slabs in split order, the column-sum finalisers use one workgroup per column group, asr_embed_bwd
  * adds the token rows in order, asr_gemm_tn_grouped_bf16 refuses.  Results are then bit-identical from run to run.
  * asr_set_deterministic returns the previous value. */
+/* Stream ordering helper of the host runtime: work queued on `to_stream` after this call runs after the work queued on
+ * `from_stream` before it (hipEventRecord + hipStreamWaitEvent on a pooled event).  The reference has one stream and
+ * synchronises every step (trainer11.py:73-74); the engine runs weight gradients / the CTC branch / communication on side
+ * streams and forks ~50 times per step.  Must not be called while either stream is being captured into a hipGraph. */
+int asr_stream_fork(void* from_stream, void* to_stream);
 int asr_get_deterministic(void);
 int asr_set_deterministic(int on);
 
@@ -320,6 +325,14 @@ int asr_loss_combine(const float* row_nll, int M, const float* n_valid, const fl
  */
 int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void* res, void* C,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, void* stream);
+/* Small-M form of the projections (the decoder's B*To ~ 550 rows; transformer_official.py:446-458 through attention.py:43-59 and
+ * module.py:70-71): 64 x 64 tiles, many short workgroups instead of a dozen long ones.
+ *   trans_b = 0: C (M, N) = act(A (M, K) * Bm (N, K)^T + bias)        forward, Bm = the weight as stored
+ *   trans_b = 1: C (M, N) = A (M, K) * Bm (K, N) (+ bias)             input gradient dx = dy W, Bm = the SAME weight (no transposed copy)
+ * act: ASR_ACT_NONE / ASR_ACT_RELU / ASR_ACT_RELU_MASK (C = 0 where mask <= 0; mask (M, N) ldc bf16 = the activations of the ReLU whose
+ * backward this is).  All bf16, fp32 accumulation; N, K, lda, ldb multiples of 8. */
+int asr_gemm_small_bf16(const void* A, const void* Bm, const float* bias, const void* mask, void* C, int M, int N, int K,
+                        int lda, int ldb, int ldc, int trans_b, int act, void* stream);
 /* Projection + residual + LayerNorm in ONE kernel (N must be 512 = d_model: a workgroup owns whole rows):
  *   y = LN(A W^T + bias + res) * gamma + beta, rows t >= lens[b] zeroed (lens may be NULL); xhat, rstd as asr_add_ln_fwd.
  * Replaces:  fc -> (dropout) -> layer_norm(out + residual) -> *= non_pad_mask      attention.py:59-60, transformer_official.py:208

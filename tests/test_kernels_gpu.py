@@ -490,6 +490,32 @@ def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     close(out, ref, rtol=1e-2, atol=1e-2, what="gemm_nt")
 
 
+@pytest.mark.parametrize("M,N,K_,trans_b,act", [(544, 512, 512, False, 0), (544, 1536, 512, False, 0), (544, 1024, 512, False, 1), (544, 512, 1024, False, 0),
+                                                 (544, 512, 1536, True, 0), (544, 1024, 512, True, 0), (544, 512, 1024, True, 2), (37, 40, 24, False, 0),
+                                                 (70, 264, 136, True, 2), (1000, 4232, 512, False, 0)])
+def test_gemm_small(K, M, N, K_, trans_b, act):
+    """Small-M projections of the decoder: forward (x W^T + bias, ReLU) and input gradient (dy W from the weight as stored, ReLU mask in
+    the store tail) against the fp64 product of the bf16-rounded operands."""
+    torch.manual_seed(M + N + K_)
+    a = torch.randn(M, K_).bfloat16()
+    bm = (torch.randn(K_, N) if trans_b else torch.randn(N, K_)).bfloat16() * 0.25
+    bias = torch.randn(N) if act != 2 else None
+    ref = a.double() @ (bm.double() if trans_b else bm.double().t())
+    if bias is not None:
+        ref = ref + bias.double()
+    mask = None
+    if act == 1:
+        ref = ref.clamp_min(0)
+    elif act == 2:
+        mask = torch.randn(M, N).bfloat16()
+        ref = torch.where(mask.double() > 0, ref, torch.zeros_like(ref))
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    K.gemm_small(a.to(DEV), bm.to(DEV), bias.to(DEV) if bias is not None else None, out, trans_b=trans_b, act=act, mask=mask.to(DEV) if mask is not None else None)
+    close(out, ref, rtol=1e-2, atol=2e-2 * math.sqrt(K_ / 64), what=f"gemm_small {M}x{N}x{K_} trans_b={trans_b} act={act}")
+    with pytest.raises(RuntimeError):
+        K.gemm_small(a.to(DEV)[:, :12], bm.to(DEV)[:12] if trans_b else bm.to(DEV)[:, :12], None, out, trans_b=trans_b)      # K not a multiple of 8
+
+
 @pytest.mark.parametrize("B,T,K_,use_bias,use_len", [(32, 500, 512, True, True), (32, 500, 1024, True, True), (3, 70, 64, False, False), (2, 333, 512, True, True)])
 def test_gemm_nt_add_ln_fused(K, B, T, K_, use_bias, use_len):
     """Projection + residual + LayerNorm in one kernel (fc / w_2 with their post-LN, attention.py:59-60, module.py:72-75) ==

@@ -6,8 +6,9 @@ from asr_chinese_e2e_amd import Models
 from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
 from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
 
-M = Models.TransformerCTC
-cfg = M.get_default_config()(); cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=0.0, ctc_weight=1.0, cer_in_iterate=False))
+JOINT = len(sys.argv) > 1 and sys.argv[1] == "joint"
+M = Models.TransformerOffical if JOINT else Models.TransformerCTC
+cfg = M.get_default_config()(); cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=0.0, ctc_weight=0.3 if JOINT else 1.0, cer_in_iterate=False))
 model = M(cfg, Vocab.synthetic(4232)).cuda()
 opt = NoamOpt(512, 1, 4000, FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
 pack = synthetic_pack(32, 500, 80, 4232, device="cuda", dtype=torch.bfloat16)
