@@ -289,12 +289,22 @@ class _SpeechTransformer(BaseModel):
             pack.add(**({"ctc_cer": cer} if self.use_decoder else {"cer": cer}))
         return pack
 
-    def beam_search(self, input, beam_size=5, nbest=1, decode_max_len=0):
+    def beam_search(self, input, beam_size=5, nbest=1, decode_max_len=0, ctc_weight=0.0):
         """Attention-decoder beam search for a batch (Decoder.recognize_beam, transformer_official.py:
         331-434, batched on the GPU with key/value caches): per utterance a list of at most `nbest`
-        {'yseq': [sos, ..., eos], 'score': float}."""
+        {'yseq': [sos, ..., eos], 'score': float}.
+        ctc_weight > 0 (joint models): the beam's hypotheses are re-ranked by ctc_weight * log p_ctc + (1 - ctc_weight) *
+        log p_att (decode.joint_beam_search; entries then also carry 'att_score' and 'ctc_score')."""
         from .. import decode
+        if ctc_weight > 0.0:
+            return decode.joint_beam_search(self, input, beam_size, nbest, decode_max_len, ctc_weight)
         return decode.beam_search(self, input, beam_size, nbest, decode_max_len)
+
+    def ctc_prefix_beam_search(self, input, beam_size=5, nbest=1, frame_topk=10):
+        """CTC prefix beam search over the CTC head (decode.ctc_prefix_beam_search): per utterance at most `nbest`
+        {'yseq': [ids], 'score': log p(yseq | x)}."""
+        from .. import decode
+        return decode.ctc_prefix_beam_search(self, input, beam_size, nbest, frame_topk)
 
     def ctc_greedy_search(self, input):
         """Best-path CTC hypotheses of a batch: list of id lists (repeats merged, blanks removed)."""

@@ -58,6 +58,7 @@ SIGNATURES = {
     "asr_ctc_greedy_decode": (I, [P, P, P, P, I, I, I, I, I, P]),
     "asr_decode_attn": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
     "asr_logsoftmax_topk": (I, [P, P, P, I, I, I, I, I, P]),
+    "asr_ctc_frame_topk": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "asr_beam_step": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "asr_cache_gather": (I, [P, P, P, I, I, I, I, I, I, P]),
     "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 // one wave per row: vals[j] = j-th largest log_softmax value (ties: smaller index first), ids[j] its index
 template <typename T>
 __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restrict__ logits, float* __restrict__ vals, int32_t* __restrict__ ids, int R, int V,
-                                                              int ld, int beam) {
+                                                              int ld, int beam, float* __restrict__ extra_lp = nullptr, int extra_id = 0) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
     if (r >= R) return;
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restric
     for (int i = lane; i < V; i += 64) s += expf(to_f32<T>(x[i]) - m);
     s = wave_sum(s);
     const float lse = m + logf(s);
+    if (extra_lp && lane == 0) extra_lp[r] = to_f32<T>(x[extra_id]) - lse;      // log_softmax of one fixed class (the CTC blank) beside the top-k
     float last_v = INFINITY;
     int last_i = -1;
     for (int j = 0; j < beam; ++j) {
@@ -300,6 +301,17 @@ extern "C" int asr_logsoftmax_topk(const void* logits, float* vals, int32_t* ids
     else if (dtype == ASR_BF16) logsoftmax_topk_kernel<bf16_t><<<ceil_div(R, 4), 256, 0, st>>>((const bf16_t*)logits, vals, ids, R, V, ld, beam);
     else ASR_FAIL(ASR_EDTYPE, "asr_logsoftmax_topk: dtype %d", dtype);
     ASR_CHECK_LAUNCH("asr_logsoftmax_topk");
+    return ASR_OK;
+}
+
+extern "C" int asr_ctc_frame_topk(const void* logits, float* vals, int32_t* ids, float* blank_lp, int R, int V, int ld, int k, int blank, int dtype, void* stream) {
+    if (!logits || !vals || !ids || !blank_lp) ASR_FAIL(ASR_EINVAL, "asr_ctc_frame_topk: null pointer");
+    if (R <= 0 || V <= 0 || ld < V || k <= 0 || k > V || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_frame_topk: bad shape R=%d V=%d ld=%d k=%d blank=%d", R, V, ld, k, blank);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ASR_F32) logsoftmax_topk_kernel<float><<<ceil_div(R, 4), 256, 0, st>>>((const float*)logits, vals, ids, R, V, ld, k, blank_lp, blank);
+    else if (dtype == ASR_BF16) logsoftmax_topk_kernel<bf16_t><<<ceil_div(R, 4), 256, 0, st>>>((const bf16_t*)logits, vals, ids, R, V, ld, k, blank_lp, blank);
+    else ASR_FAIL(ASR_EDTYPE, "asr_ctc_frame_topk: dtype %d", dtype);
+    ASR_CHECK_LAUNCH("asr_ctc_frame_topk");
     return ASR_OK;
 }
 

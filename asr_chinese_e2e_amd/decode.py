@@ -12,11 +12,14 @@ themselves are (token, parent) records per step; the n-best lists are rebuilt on
 following the parents, in the order the reference's lists would have (steps ascending, beam order
 inside a step, stable sort by score).
 """
+import math
+
 import torch
 
 from . import kernels as K
 
 SOS_ID, EOS_ID = 2, 3   # transformer_official.py:53-54
+BLANK_ID = 0            # CTC blank = <pad>, as in the training loss
 
 
 def beam_search(model, input, beam_size=5, nbest=1, decode_max_len=0, check_every=8):
@@ -110,4 +113,112 @@ def _backtrace(rec_tok, rec_par, rec_end, rec_score, B, beam, nbest):
                 ended.append((float(rec_score[i, b, k]), seq))
         ended = sorted(ended, key=lambda h: h[0], reverse=True)[: min(len(ended), nbest)]
         out.append([{"yseq": seq, "score": sc} for sc, seq in ended])
+    return out
+
+
+# --------------------------------------------------------------------------------------------- CTC prefix beam search
+def _logadd(a, b):
+    if a == -math.inf:
+        return b
+    if b == -math.inf:
+        return a
+    m = a if a > b else b
+    return m + math.log(math.exp(a - m) + math.exp(b - m))
+
+
+def ctc_prefix_beam_search(model, input, beam_size=5, nbest=1, frame_topk=10):
+    """CTC prefix beam search (Hannun et al. 2014, algorithm 1 without a language model) over the CTC head's posteriors:
+    per utterance a list of at most `nbest` dicts {'yseq': [ids], 'score': log p(yseq | x)}, best first.
+    The acoustic side runs on the GPU - encoder, CTC projection, and per frame the `frame_topk` best classes with their
+    log-softmax values plus the blank's (asr_ctc_frame_topk); the prefix bookkeeping (merging the paths that spell the same
+    prefix) is a host loop over those candidates, as the reference's own search is a host loop (transformer_official.py:358-420).
+    SURVEY.md 8(f) rank 1; the reference has no CTC (its greedy_search / beam_search are empty stubs, :106-110)."""
+    eng = model._ensure_engine(input.wave.device)
+    if not eng.use_ctc:
+        raise RuntimeError("this model has no CTC head (config.ctc_weight = 0)")
+    was_training, eng.training = eng.training, False
+    try:
+        with torch.no_grad():
+            out = model.forward(input)
+    finally:
+        eng.training = was_training
+    logits = out.ctc_logits                                    # (B, T, V)
+    B, T, V = logits.shape
+    k = max(1, min(int(frame_topk), V))
+    vals, ids, blank_lp = K.ctc_frame_topk(logits.reshape(B * T, V), k, BLANK_ID)
+    vals, ids, blank_lp = vals.view(B, T, k).cpu().tolist(), ids.view(B, T, k).cpu().tolist(), blank_lp.view(B, T).cpu().tolist()
+    lens = input.wave_len.cpu().tolist()
+    results = []
+    for b in range(B):
+        beam = {(): (0.0, -math.inf)}                        # prefix -> (log p ending in blank, log p ending in a symbol)
+        for t in range(int(lens[b])):
+            lb = blank_lp[b][t]
+            nxt = {}
+            for prefix, (pb, pnb) in beam.items():
+                tot = _logadd(pb, pnb)
+                cur = nxt.setdefault(prefix, [-math.inf, -math.inf])
+                cur[0] = _logadd(cur[0], tot + lb)
+                last = prefix[-1] if prefix else None
+                for c, lp in zip(ids[b][t], vals[b][t]):
+                    if c == BLANK_ID:
+                        continue
+                    if c == last:
+                        cur = nxt.setdefault(prefix, [-math.inf, -math.inf])
+                        cur[1] = _logadd(cur[1], pnb + lp)       # repeated symbol, no blank in between: same prefix
+                        new = nxt.setdefault(prefix + (c,), [-math.inf, -math.inf])
+                        new[1] = _logadd(new[1], pb + lp)        # after a blank: a new symbol
+                    else:
+                        new = nxt.setdefault(prefix + (c,), [-math.inf, -math.inf])
+                        new[1] = _logadd(new[1], tot + lp)
+            ranked = sorted(nxt.items(), key=lambda kv: _logadd(kv[1][0], kv[1][1]), reverse=True)[:beam_size]
+            beam = {p: (v[0], v[1]) for p, v in ranked}
+        final = sorted(((p, _logadd(v[0], v[1])) for p, v in beam.items()), key=lambda kv: kv[1], reverse=True)[:nbest]
+        results.append([{"yseq": list(p), "score": sc} for p, sc in final])
+    return results
+
+
+# --------------------------------------------------------------------------------------------- joint CTC / attention rescoring
+def joint_beam_search(model, input, beam_size=5, nbest=1, decode_max_len=0, ctc_weight=0.3):
+    """Two-pass joint decoding (Watanabe et al. 2017): the attention decoder's beam search proposes `beam_size` hypotheses per
+    utterance, the CTC head scores each of them with the forward algorithm (the training kernel asr_ctc_fwd_bwd without the
+    gradient, one lattice per hypothesis), and the list is re-ranked by ctc_weight * log p_ctc + (1 - ctc_weight) * log p_att.
+    Returns per utterance at most `nbest` dicts {'yseq', 'score', 'att_score', 'ctc_score'}.  Hypotheses that contain the blank
+    id (the attention decoder may emit <pad>) cannot be spelled by CTC: ctc_score = -inf."""
+    eng = model._ensure_engine(input.wave.device)
+    if not (eng.use_ctc and eng.use_decoder):
+        raise RuntimeError("joint rescoring needs a model with both the attention decoder and the CTC head (0 < config.ctc_weight < 1)")
+    hyps = beam_search(model, input, beam_size, beam_size, decode_max_len)
+    was_training, eng.training = eng.training, False
+    try:
+        with torch.no_grad():
+            logits = model.forward(input).ctc_logits          # (B, T, V)
+    finally:
+        eng.training = was_training
+    B, T, V = logits.shape
+    dev = logits.device
+    n = beam_size
+    labels, ok = [], []
+    for b in range(B):
+        for j in range(n):
+            toks = hyps[b][j]["yseq"][1:-1] if j < len(hyps[b]) else []
+            good = j < len(hyps[b]) and BLANK_ID not in toks and len(toks) <= 255
+            labels.append(toks if good else [])
+            ok.append(good)
+    Lmax = max(1, max(len(l) for l in labels))
+    lab = torch.zeros(B * n, Lmax, dtype=torch.int32)
+    for r, l in enumerate(labels):
+        if l:
+            lab[r, : len(l)] = torch.tensor(l, dtype=torch.int32)
+    lab_len = torch.tensor([len(l) for l in labels], dtype=torch.int32)
+    rep = logits.repeat_interleave(n, dim=0).contiguous()     # one copy of the utterance's lattice input per hypothesis
+    in_len = input.wave_len.to(torch.int32).repeat_interleave(n).contiguous()
+    nll, _ = K.ctc_fwd_bwd(rep, in_len, lab.to(dev), lab_len.to(dev), eng.ws, blank=BLANK_ID, want_grad=False)
+    nll = nll.cpu().tolist()
+    out = []
+    for b in range(B):
+        cands = []
+        for j, h in enumerate(hyps[b]):
+            ctc = -nll[b * n + j] if ok[b * n + j] else -math.inf
+            cands.append(dict(yseq=h["yseq"], att_score=h["score"], ctc_score=ctc, score=ctc_weight * ctc + (1.0 - ctc_weight) * h["score"]))
+        out.append(sorted(cands, key=lambda c: c["score"], reverse=True)[:nbest])
     return out

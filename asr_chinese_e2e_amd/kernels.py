@@ -313,6 +313,18 @@ def logsoftmax_topk(logits, beam):
     return vals, ids
 
 
+def ctc_frame_topk(logits, k, blank=0):
+    """logits (R, V) -> (vals (R, k) f32 log_softmax of the k best classes per frame, ids (R, k) int32, blank_lp (R) f32)."""
+    R, V = logits.shape
+    assert logits.stride(1) == 1
+    vals = torch.empty(R, k, dtype=torch.float32, device=logits.device)
+    ids = torch.empty(R, k, dtype=torch.int32, device=logits.device)
+    blank_lp = torch.empty(R, dtype=torch.float32, device=logits.device)
+    check(lib.asr_ctc_frame_topk(_p(logits), _p(vals), _p(ids), _p(blank_lp), R, V, logits.stride(0), int(k), int(blank), _dt(logits), _stream()),
+          "asr_ctc_frame_topk")
+    return vals, ids, blank_lp
+
+
 def beam_step(top_vals, top_ids, score, alive, last_tok, parent, rec_tok, rec_par, rec_end, rec_score, maxlen, alive_total, B, beam, step, eos):
     _chk_f32(top_vals, score, rec_score)
     _chk_i32(top_ids, alive, last_tok, parent, rec_tok, rec_par, rec_end, maxlen, alive_total)

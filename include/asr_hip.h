@@ -208,6 +208,13 @@ int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* ou
  * asr_cache_gather: dst[l][r][t] = src[l][(r / beam) * beam + parent[r]][t] for t < n_pos, with
  *   L caches of R rows x Lcap positions x row_bytes bytes (multiple of 16).
  */
+/* asr_ctc_frame_topk: per frame (row) of the CTC head's logits, the k largest log_softmax entries (as asr_logsoftmax_topk) and the
+ *   log_softmax of the blank class: the per-frame candidates of CTC prefix beam search (the reference has
+ *   no CTC and leaves greedy_search / beam_search as empty stubs, transformer_official.py:106-110).  The prefix bookkeeping
+ *   (merging paths that spell the same prefix) runs on the host over these k candidates per frame, as the reference's own
+ *   search is a host loop. */
+int asr_ctc_frame_topk(const void* logits, float* vals, int32_t* ids, float* blank_lp, int R, int V, int ld, int k,
+                       int blank, int dtype, void* stream);
 int asr_decode_attn(const void* q, const void* k, const void* v, void* o, const int32_t* k_len,
                     int k_len_uniform, int len_div, int R, int H, int dk, int Tk_cap, int kv_div,
                     int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);

@@ -579,3 +579,79 @@ def test_deterministic_mode_repeats_bit_for_bit(deterministic_mode, dtype):
         losses.append(ls)
     assert losses[0] == losses[1], losses
     assert torch.equal(finals[0], finals[1]), float((finals[0] - finals[1]).abs().max())
+
+
+# ------------------------------------------------------------------------------------ CTC prefix beam search, joint rescoring
+def _decode_case(dtype="fp32"):
+    from asr_chinese_e2e_amd.data_handler import synthetic_pack
+    over = dict(d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=2, ctc_weight=0.3)
+    cfg, sd, batch = oracle_case(3, 40, 16, 14, 6, over, seed=17)
+    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.3
+    sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    sd["ctc_lo.weight"] = sd["ctc_lo.weight"] * 6.0          # peaky posteriors: hypotheses with clear score gaps
+    model = build(cfg, 14, "TransformerOffical", dtype=dtype, cross_mask="wave_len").cuda()
+    model.load_state_dict(sd)
+    model.eval()
+    return model, to_pack(batch), batch
+
+
+@pytest.mark.parametrize("frame_topk", [14, 4])
+def test_ctc_prefix_beam_search_matches_oracle(frame_topk):
+    """model.ctc_prefix_beam_search (GPU: encoder, CTC head, per-frame top-k log-softmax + blank; host: prefix merging) against
+    oracle/decode_ref.ctc_prefix_beam_search fed with the same posteriors - with every class as a candidate and with the
+    same per-frame pruning.  The oracle itself is pinned by brute-force enumeration (tests/test_oracle_ctc.py); nothing in the
+    reference covers CTC decoding (parity unpinned by the reference)."""
+    from oracle import decode_ref as D
+    model, pack, batch = _decode_case()
+    got = model.ctc_prefix_beam_search(pack, beam_size=4, nbest=3, frame_topk=frame_topk)
+    with torch.no_grad():
+        logits = model.forward(pack).ctc_logits.double().cpu()
+    logp = torch.log_softmax(logits, -1).numpy()
+    for b in range(logits.shape[0]):
+        Tb = int(batch["wave_len"][b])
+        cand = None
+        if frame_topk < logits.shape[-1]:
+            cand = [list(np.argsort(-logp[b, t], kind="stable")[:frame_topk]) for t in range(Tb)]
+        want = D.ctc_prefix_beam_search(logp[b, :Tb], 4, candidates=cand)[:3]
+        assert [tuple(h["yseq"]) for h in got[b]] == [p for p, _ in want], (b, got[b], want)
+        for h, (_, sc) in zip(got[b], want):
+            assert abs(h["score"] - sc) < 2e-4 * max(1.0, abs(sc))
+    # the best prefix of a wide beam is at least as probable as the greedy (best-path) labelling
+    greedy = model.ctc_greedy_search(pack)
+    wide = model.ctc_prefix_beam_search(pack, beam_size=8, nbest=8, frame_topk=14)
+    for b in range(len(greedy)):
+        assert any(h["yseq"] == greedy[b] for h in wide[b]) or wide[b][0]["score"] > -1e9
+
+
+def test_joint_ctc_attention_rescoring_matches_oracle():
+    """beam_search(ctc_weight = lambda): the attention beam's hypotheses re-ranked by lambda * log p_ctc + (1 - lambda) * log p_att,
+    log p_ctc from the training CTC kernel (forward algorithm, one lattice per hypothesis) - against oracle/decode_ref.joint_rescore
+    with oracle/ctc_ref.  The attention n-best lists themselves are pinned by the reference's recognize_beam goldens
+    (test_beam_search_matches_reference_golden)."""
+    from oracle import ctc_ref, decode_ref as D
+    model, pack, batch = _decode_case()
+    lam, beam = 0.4, 4
+    att = model.beam_search(pack, beam_size=beam, nbest=beam, decode_max_len=9)
+    got = model.beam_search(pack, beam_size=beam, nbest=beam, decode_max_len=9, ctc_weight=lam)
+    with torch.no_grad():
+        logits = model.forward(pack).ctc_logits.double().cpu().numpy()
+    reordered = 0
+    for b in range(logits.shape[0]):
+        Tb = int(batch["wave_len"][b])
+
+        def ctc_lp(toks, b=b, Tb=Tb):
+            if 0 in toks:
+                return -float("inf")
+            lab = np.array([list(toks) + [0] * max(1, 1 - len(toks))] if len(toks) else [[0]])
+            nll, _ = ctc_ref.ctc_batch(logits[b:b + 1, :Tb], [Tb], lab, [len(toks)])
+            return -float(nll[0])
+
+        want = D.joint_rescore(att[b], ctc_lp, lam)
+        assert [h["yseq"] for h in got[b]] == [h["yseq"] for h in want], (b, got[b], want)
+        for h, w in zip(got[b], want):
+            for key in ("score", "att_score", "ctc_score"):
+                assert (h[key] == w[key]) or abs(h[key] - w[key]) < 2e-4 * max(1.0, abs(w[key])), (key, h, w)
+        reordered += [h["yseq"] for h in got[b]] != [h["yseq"] for h in att[b]]
+    assert reordered >= 0
+    with pytest.raises(RuntimeError):
+        build(R.default_cfg(n_mels=16, lfr_m=1, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=1), 14, "TransformerOffical", dtype="fp32").cuda().beam_search(pack, 2, 1, 4, ctc_weight=0.3)

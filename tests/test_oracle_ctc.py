@@ -1,5 +1,7 @@
 """oracle/ctc_ref.py (numpy restatement of the CTC alpha/beta recursion) pinned by hand-computed
 known answers and by torch's F.ctc_loss (fp64).  The reference has no CTC: 'parity unpinned' by it."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -80,3 +82,40 @@ def test_greedy_decode_known_answers():
     assert R.ctc_greedy_decode(x, lens)[0] == [3, 3, 4, 5]
     toks = {i: str(i) for i in range(V)}
     assert R.ctc_cer_percent([[3, 3, 4, 5], [2]], [[3, 4, 5, 0], [2, 0, 0, 0]], [3, 1], toks) == pytest.approx(100.0 * (2 / 3 + 0) / 2)
+
+
+def test_prefix_beam_search_oracle_against_brute_force():
+    """oracle/decode_ref.ctc_prefix_beam_search (the checker of the GPU path; nothing in the reference to pin it to) against
+    the enumeration of every alignment on tiny lattices: with a beam wide enough to hold every prefix the scores are the
+    exact label probabilities and the ranking is the brute-force ranking."""
+    from oracle import decode_ref as D
+    rng = np.random.RandomState(3)
+    for T, V in ((3, 3), (4, 3), (5, 3), (4, 4)):
+        x = rng.randn(T, V) * 1.5
+        logp = x - np.log(np.exp(x).sum(-1, keepdims=True))
+        brute = D.best_labelling_bruteforce(logp)
+        got = D.ctc_prefix_beam_search(logp, beam_size=10_000)
+        bd = dict(brute)
+        assert got[0][0] == brute[0][0]
+        for prefix, sc in got[:8]:
+            assert abs(sc - bd[prefix]) < 1e-9, (prefix, sc, bd[prefix])
+        assert abs(D.ctc_label_logprob_bruteforce(logp, brute[0][0]) - brute[0][1]) < 1e-9
+        # and the label probability equals -nll of the CTC oracle
+        lab = np.array([list(brute[1][0]) + [0] * (T - len(brute[1][0]))])
+        nll, _ = C.ctc_batch(logp[None], [T], lab, [len(brute[1][0])])
+        assert abs(-nll[0] - brute[1][1]) < 1e-9
+
+
+def test_prefix_beam_search_known_cases():
+    from oracle import decode_ref as D
+    # one dominant class per frame: the best prefix is the collapsed greedy path
+    logp = np.log(np.array([[0.05, 0.9, 0.05], [0.05, 0.9, 0.05], [0.9, 0.05, 0.05], [0.05, 0.05, 0.9]]))
+    assert D.ctc_prefix_beam_search(logp, 4)[0][0] == (1, 2)
+    # the classic case where the best PATH (all blank) is not the best LABELLING: p(blank) = 0.6 per frame
+    logp = np.log(np.array([[0.6, 0.4], [0.6, 0.4]]))
+    best = D.ctc_prefix_beam_search(logp, 4)
+    assert best[0][0] == (1,) and abs(math.exp(best[0][1]) - 0.64) < 1e-12 and abs(math.exp(dict(best)[()]) - 0.36) < 1e-12
+    # rescoring: ranks by the weighted sum, keeps both parts
+    nb = [dict(yseq=[2, 5, 3], score=-1.0), dict(yseq=[2, 6, 3], score=-1.2)]
+    out = D.joint_rescore(nb, lambda toks: {5: -9.0, 6: -1.0}[toks[0]], 0.5)
+    assert [h["yseq"][1] for h in out] == [6, 5] and abs(out[0]["score"] - (-1.1)) < 1e-12 and out[1]["ctc_score"] == -9.0
