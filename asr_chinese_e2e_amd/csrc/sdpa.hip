@@ -479,6 +479,272 @@ __global__ __launch_bounds__(256, 2) void sdpa_bwd_dkv_bf16_kernel(const bf16_t*
     store_rows_T(dva, 1.f, dv + (size_t)b * Tk * ldv + h * DK, ldv, kk0, Tk, lane);
 }
 
+// ---------------------------------------------------------------- forward: K and V resident in LDS (Tk <= 512)
+// The kernel above stages every 64-key K / V tile through registers with two barriers per tile and each 128-query workgroup
+// streams the whole K / V of its head again.  When the keys of a head fit LDS (Tk <= 512: K and V images of 64 KiB each)
+// ONE workgroup of 8 waves serves a whole (b, h) pair:
+//   * K and V arrive ONCE, by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 key rows per wave instruction), all issued at
+//     kernel entry in tile order; the first pass over the tiles waits per tile (counted vmcnt + one barrier), so the
+//     softmax of tile 0 runs while tiles 1..7 are still in flight (a register-staged prologue cost ~5 us: the 32 MB of
+//     all heads' K / V at the memory rate, with every CU idle);
+//   * rows are 128 B unpadded; 16-byte chunk c of row r sits at position c ^ f((r >> 1) & 7), f(h) = ((h & 1) << 2) | (h >> 1)
+//     (applied to the SOURCE address of the DMA): the ds_read_b128 row fragments of K and the ds_read_b64_tr_b16
+//     transposed fragments of V are both bank-conflict free;
+//   * every wave owns 64 queries (two 32-query blocks, one after the other; Q fragments in registers) and walks the key tiles
+//     with no barrier after the first pass; fragment reads are issued a phase ahead of their MFMAs;
+//   * same arithmetic as sdpa_fwd_bf16_kernel (S^T = K Q^T so that the softmax statistics are lane-local and P^T is already
+//     the operand of O^T += V^T P^T; exp2 domain; masks from lengths), except that the row sums of P come out of the
+//     matrix pipe (an all-ones A operand: 4 MFMAs instead of 32 VALU adds per tile - the loop is VALU-issue bound) and the
+//     accumulator is only rescaled when the running maximum moved by more than 2^8.
+constexpr int FF_KEYS = 512, FF_THREADS = 512;
+constexpr int FF_IMG = FF_KEYS * 128;          // 65536 B per image
+constexpr int FF_LDS = 2 * FF_IMG;
+__device__ __forceinline__ int ff_swz(int row) {
+    const int h = (row >> 1) & 7;
+    return ((h & 1) << 2) | (h >> 1);
+}
+__device__ __forceinline__ void ff_wait_tiles(int younger) {      // at most `younger` tiles (2 DMAs each) may still be in flight
+    switch (younger) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    }
+}
+
+template <bool DROP, bool MASKED>
+__global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                         bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
+                                                                         int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
+                                                                         uint32_t dseed, uint32_t dthr, float dscale) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_ff[];
+    const char* Kimg = smem_ff;
+    const char* Vimg = smem_ff + FF_IMG;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
+    const bf16_t* kb = k + (size_t)b * Tk * ldk + h * DK;
+    const bf16_t* vb = v + (size_t)b * Tk * ldv + h * DK;
+    const int klen = min(k_len ? k_len[b] : Tk, Tk);
+    const int ntile = (klen + TILE - 1) / TILE;      // 64-key tiles that hold a valid key
+    const float sc2 = scale * LOG2E;
+    bf16_t* ob = o + (size_t)b * Tq * ldo + h * DK;
+
+    // The K / V stream: tile t = two DMAs (K, V) of every wave; rows past klen repeat the last key (finite; masked).
+    // The DMA is inline asm, invisible to the compiler's vmcnt bookkeeping, so the order is: tile 0, then the Q fragments of the
+    // wave's first block as ordinary loads that are CONSUMED (the compiler's vmcnt(0) for them covers tile 0, which is needed
+    // first anyway), then tiles 1..; from there on only the counted waits of ff_wait_tiles() touch vmcnt.
+    bf16x8 qf[4];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_ff;
+    const int r8 = 8 * w + (lane >> 3), c8 = 8 * ((lane & 7) ^ ff_swz(r8));
+    auto dma_tile = [&](int t) {
+        const int rc = min(TILE * t + r8, klen - 1);
+        const bf16_t* sk = kb + (size_t)rc * ldk + c8;
+        const bf16_t* sv = vb + (size_t)rc * ldv + c8;
+        const unsigned dk_ = __builtin_amdgcn_readfirstlane(lds0 + (TILE * t + 8 * w) * 128), dv_ = dk_ + FF_IMG;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sk), "s"(dk_) : "memory");      // m0 has no compiler-generated user in this kernel
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sv), "s"(dv_) : "memory");
+    };
+    // Only FF_AHEAD tiles are ever in flight: with all of them requested at entry (every CU at once: 48 MB) a wave's FIRST tile
+    // queues behind everybody's later ones and the first softmax started ~10 us into the kernel.
+    // The rendezvous (counted wait + barrier) is per PAIR of tiles: a barrier per tile locked the two waves of a SIMD into the
+    // same phase (all MFMA, then all VALU) and cost ~40 % per tile against the barrier-free second pass.
+    constexpr int FF_AHEAD = 3;
+    if (ntile > 0) dma_tile(0);
+    frags_from_global(qf, qb, ldq, 64 * w, Tq, lane);
+    asm volatile("; Q fragments landed" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
+    for (int t = 1; t < min(ntile, MASKED ? FF_KEYS / TILE : FF_AHEAD + 1); ++t) dma_tile(t);      // masked variants: everything (they wait for all of it)
+    // lane bases of the fragment reads (bytes); tile, sub-block and k-step are immediates / one add
+    int kofs[4], vofs[2][2];
+    {
+        const int r = lane & 31, hh = lane >> 5, f = ff_swz(r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kofs[ks] = r * 128 + (((2 * ks + hh) ^ f) << 4);
+        const int G = lane >> 4, i = lane & 15, rv = 4 * (G >> 1) + (i >> 2);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int chunk = 4 * db + 2 * (G & 1) + ((i & 3) >> 1);
+                vofs[db][hi] = FF_IMG + (rv + 8 * hi) * 128 + ((chunk ^ ff_swz(rv + 8 * hi)) << 4) + 8 * (i & 1);      // V image: the rest fits the 16-bit offset field
+            }
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+
+    bool streamed = false;      // the first pass over the tiles consumes the stream; after it everything is resident
+    for (int qc = 0; qc < Tq; qc += 64 * 8) {         // 512 queries per pass (one pass at T = 500)
+        const int q0w = qc + 64 * w;
+        bf16x8 qnext[4];
+#pragma unroll 1
+        for (int qbk = 0; qbk < 2; ++qbk) {
+            const int q0 = q0w + 32 * qbk;
+            const bool stream = !streamed && !MASKED;
+            if (!streamed && MASKED) {      // masked variants walk different tile ranges per wave: no per-tile rendezvous, wait for everything
+                ff_wait_tiles(0);
+                __syncthreads();
+            }
+            if (streamed) {
+                if (q0 >= Tq) break;
+                if (qbk == 1 && !MASKED) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];      // fetched under the first block's last tile
+                } else {
+                    frags_from_global(qf, qb, ldq, q0, Tq, lane);
+                }
+            }
+            const bool active = q0 < Tq;       // an idle wave of the first pass still keeps the rendezvous
+            const int qi = q0 + (lane & 31);
+            f32x16 oacc[2], lacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; lacc[i] = 0.f; }
+            float m = M_INIT, l = 0.f;
+            int t0 = 0, t1 = ntile;
+            if (MASKED) {
+                if (causal) t1 = min(t1, (min(q0 + 32, Tq) + TILE - 1) / TILE);
+                if (window >= 0) { t1 = min(t1, (min(q0 + 32, Tq) + window + TILE - 1) / TILE); t0 = max(0, q0 - window) / TILE; }
+                if (!active) t1 = t0;
+            }
+            bf16x8 kf[2][4];
+            constexpr bool PREFETCH = !MASKED;      // the masked variants have no registers to spare for it
+#define FF_LOAD_K(T_)                                                                                       \
+    {                                                                                                       \
+        const char* kpt = Kimg + (T_) * (TILE * 128);                                                       \
+        _Pragma("unroll") for (int sub = 0; sub < 2; ++sub)                                                 \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) kf[sub][ks] = *(const bf16x8*)(kpt + kofs[ks] + sub * 4096); \
+    }
+            if (PREFETCH && !stream && t0 < t1) FF_LOAD_K(t0);
+            for (int t = t0; t < t1; ++t) {
+                const int k0 = t * TILE;
+                if (stream) {
+                    if ((t & 1) == 0) {      // tiles t and t+1 must have landed; t+2 and t+3 may be in flight; t+4, t+5 go out
+                        ff_wait_tiles(min(2, max(0, ntile - 2 - t)));
+                        __syncthreads();
+                        if (t + 4 < ntile) dma_tile(t + 4);
+                        if (t + 5 < ntile) dma_tile(t + 5);
+                    }
+                    if (!active) continue;
+                    FF_LOAD_K(t);
+                } else if (!PREFETCH) {
+                    FF_LOAD_K(t);
+                }
+                if (!MASKED && qbk == 0 && t == t1 - 1 && q0 + 32 < Tq) frags_from_global(qnext, qb, ldq, q0 + 32, Tq, lane);
+                f32x16 st[2];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[sub][i] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[ks], st[sub], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 vf[2][2][2];
+                {
+                    const char* vpt = Kimg + k0 * 128;      // vofs carries the V image offset
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int db = 0; db < 2; ++db) {
+                                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vpt + vofs[db][0] + (32 * sub + 16 * s2) * 128));
+                                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vpt + vofs[db][1] + (32 * sub + 16 * s2) * 128));
+                                vf[sub][s2][db] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                            }
+                }
+                if (PREFETCH && !stream && t + 1 < t1) FF_LOAD_K(t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const bool edge = (k0 + TILE > klen) || (MASKED && ((causal && k0 + TILE - 1 > q0) || (window >= 0 && (k0 + TILE - 1 - q0 > window || q0 + 31 - k0 > window))));
+                if (edge) {
+                    if (!MASKED) {      // key-length mask only: one compare per element
+                        const int lim = klen - k0 - 4 * (lane >> 5);
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i)
+                                if (32 * sub + (i & 3) + 8 * (i >> 2) >= lim) st[sub][i] = -INFINITY;
+                    } else {
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i)
+                                if (!visible(qi, k0 + 32 * sub + acc_row(i, lane), klen, causal, window)) st[sub][i] = -INFINITY;
+                    }
+                }
+                // The loop is VALU-issue bound (dk = 64: 16 MFMAs against 32 softmax elements per lane), so the element work is
+                // max3 / fma / exp2 (scalar f32: the packed v_pk_* forms issue slower than the two ops they replace), and the
+                // accumulators are only rescaled when the running maximum moved by more than 2^8 in the exp2 domain (P stays
+                // <= 256: exact in fp32, and l / lse stay consistent with m).
+                float tmax = M_INIT;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, st[sub][i]);
+                {      // the other half-wave's maximum: one VALU lane swap instead of an LDS round trip
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                    tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
+                if (__builtin_amdgcn_ballot_w64((tmax - m) * sc2 > 8.f) != 0) {      // wave-uniform
+                    asm volatile("; rescale" ::: "memory");
+                    const float mn = fmaxf(m, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * sc2);
+                    m = mn;
+                    if constexpr (DROP) l *= alpha;
+                    else lacc[0] *= alpha;      // every register of lacc holds the same sum; only [0] is read
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+                }
+                const float mc = m * sc2;
+                float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        const float p0 = __builtin_amdgcn_exp2f(fmaf(st[sub][i], sc2, -mc));
+                        const float p1 = __builtin_amdgcn_exp2f(fmaf(st[sub][i + 1], sc2, -mc));
+                        st[sub][i] = p0;
+                        st[sub][i + 1] = p1;
+                        if constexpr (DROP) { ps0 += p0; ps1 += p1; }
+                    }
+                if constexpr (DROP) {
+                    l += ps0 + ps1;      // the sum is over the un-dropped P: VALU adds here
+                    const uint32_t rowbase = (((uint32_t)(b * H + h)) * Tq + min(qi, Tq - 1)) * ((Tk + 1) & ~1);
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) {
+                            const uint32_t hsh = drop_hash((rowbase + k0 + 32 * sub + acc_row(i, lane)) >> 1, dseed);
+                            st[sub][i] = drop_keep(hsh, 0, dthr) ? st[sub][i] * dscale : 0.f;
+                            st[sub][i + 1] = drop_keep(hsh, 1, dthr) ? st[sub][i + 1] * dscale : 0.f;
+                        }
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 pf = acc_to_frag(st[sub], s2);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[sub][s2][db], pf, oacc[db], 0, 0, 0);
+                        if constexpr (!DROP) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+                    }
+            }
+#undef FF_LOAD_K
+            streamed = true;
+            if (!active) break;
+            if constexpr (DROP) l += __shfl_xor(l, 32, 64);
+            else l = lacc[0];      // the contraction ran over all 64 keys of every tile: no cross-half add
+            const float inv = l > 0.f ? 1.f / l : 0.f;
+            store_rows_T(oacc, inv, ob, ldo, q0, Tq, lane);
+            if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m * sc2 + log2f(l)) * LN2 : -INFINITY;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- backward: ONE kernel per (b, h)
 // The dQ + dK/dV pair above reads Q, K, V, dO twice and computes S and dP twice (7 products, 2 exp passes; PMC traffic
 // 1.52 x the algorithmic bytes).  When all keys of a head fit one workgroup (Tk <= 512: every encoder / decoder shape of
@@ -945,7 +1211,24 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
     const uint32_t dthr = drop_thr16(drop_p);
     const float dscale = 1.f / (1.f - drop_p);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o)) {
+    static const int fwd_tiled = getenv("ASR_SDPA_FWD_TILED") ? atoi(getenv("ASR_SDPA_FWD_TILED")) : 0;   // 1: the register-staged tile kernel for every shape (A/B runs)
+    if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o) && Tk <= FF_KEYS && !fwd_tiled) {   // K and V of a head fit LDS: one workgroup per (b, h)
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+            attr = true;
+        }
+#define FF_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
+        const bool masked = causal || window >= 0;
+        if (dthr && masked) sdpa_fwd_fused_bf16_kernel<true, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
+        else if (dthr) sdpa_fwd_fused_bf16_kernel<true, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
+        else if (masked) sdpa_fwd_fused_bf16_kernel<false, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
+        else sdpa_fwd_fused_bf16_kernel<false, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
+#undef FF_ARGS
+    } else if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o)) {
         const int grid = ceil_div(Tq, 128) * H * B;
         if (dthr) sdpa_fwd_bf16_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
         else sdpa_fwd_bf16_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);

@@ -301,7 +301,7 @@ class Engine:
         self.side = torch.cuda.Stream(device=flat.device)
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
-        self.overlap_wgrad = True
+        self.overlap_wgrad = os.environ.get("ASR_WGRAD_OVERLAP", "1") == "1"      # 0: weight gradients on the main stream (A/B runs)
         # Deterministic mode (kernels.set_deterministic / ASR_DETERMINISTIC=1, read when the engine is built): every
         # gradient reduction runs in a fixed order.  The weight gradients then stay on the main stream (the tied
         # embedding / projection weight is updated by plain read-modify-writes of two kernels, which must not overlap),
