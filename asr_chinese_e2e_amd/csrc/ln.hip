@@ -10,6 +10,9 @@
 namespace {
 
 constexpr int LN_WAVES = 4;  // waves (rows in flight) per workgroup
+#ifndef LN_UNROLL
+#define LN_UNROLL 2
+#endif
 
 // per-lane slice of one row: N values. VEC8: value c*8+j is column c*512 + lane*8 + j;
 // otherwise value k is column k*64 + lane (masked by col < d).
@@ -69,52 +72,66 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
     RS::loadf(gamma, d, lane, g);
     RS::loadf(beta, d, lane, bt);
     const float inv_d = 1.f / (float)d;
-    for (int row = blockIdx.x * LN_WAVES + w; row < rows; row += gridDim.x * LN_WAVES) {
-        const int b = row / T_, t = row - b * T_;
-        float z[N];
-        RS::load(x + (size_t)row * d, d, lane, z);
-        if constexpr (DROP == 1) RS::dropout(z, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
-        if (res) {
-            float r[N];
-            RS::load(res + (size_t)row * d, d, lane, r);
+    // LN_U rows per wave and trip, their loads issued together: one row per wave kept ~32 KB per CU in flight (16 waves x
+    // 2 KB), half of what the memory latency needs at this bandwidth (measured 3.7 of ~6 TB/s streaming rate).
+    constexpr int LN_U = (N <= 8) ? LN_UNROLL : ((N <= 16) ? 2 : 1);
+    const int stride = gridDim.x * LN_WAVES;
+    for (int row0 = blockIdx.x * LN_WAVES + w; row0 < rows; row0 += LN_U * stride) {
+        float z[LN_U][N], r[LN_U][N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) z[i] += r[i];
+        for (int u = 0; u < LN_U; ++u) {
+            const int row = row0 + u * stride;
+            if (row < rows) {      // wave-uniform
+                RS::load(x + (size_t)row * d, d, lane, z[u]);
+                if (res) RS::load(res + (size_t)row * d, d, lane, r[u]);
+            }
         }
-        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) s += z[i];
-        const float mean = wave_sum(s) * inv_d;
-        float q = 0.f;
+        for (int u = 0; u < LN_U; ++u) {
+            const int row = row0 + u * stride;
+            if (row >= rows) break;
+            const int b = row / T_, t = row - b * T_;
+            if constexpr (DROP == 1) RS::dropout(z[u], (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
+            if (res) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            // padded lanes of the scalar path hold z = 0: exclude them from the variance
-            float c = z[i] - mean;
-            if constexpr (!VEC8) c = (i * 64 + lane < d) ? c : 0.f;
-            z[i] = c;
-            q += c * c;
+                for (int i = 0; i < N; ++i) z[u][i] += r[u][i];
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) s += z[u][i];
+            const float mean = wave_sum(s) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                // padded lanes of the scalar path hold z = 0: exclude them from the variance
+                float c = z[u][i] - mean;
+                if constexpr (!VEC8) c = (i * 64 + lane < d) ? c : 0.f;
+                z[u][i] = c;
+                q += c * c;
+            }
+            const float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
+            const bool keep = lens ? (t < lens[b]) : true;
+            float out[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                z[u][i] *= rstd;
+                out[i] = z[u][i] * g[i] + bt[i];
+            }
+            if (pe) {
+                float p[N];
+                RS::loadf(pe + (size_t)t * d, d, lane, p);
+#pragma unroll
+                for (int i = 0; i < N; ++i) out[i] += p[i];
+            }
+            if constexpr (DROP == 2) RS::dropout(out, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
+            if (!keep) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) out[i] = 0.f;
+            }
+            RS::store(xhat + (size_t)row * d, d, lane, z[u]);
+            RS::store(y + (size_t)row * d, d, lane, out);
+            if (lane == 0) rstd_out[row] = rstd;
         }
-        const float rstd = rsqrtf(wave_sum(q) * inv_d + 1e-5f);
-        const bool keep = lens ? (t < lens[b]) : true;
-        float out[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            z[i] *= rstd;
-            out[i] = z[i] * g[i] + bt[i];
-        }
-        if (pe) {
-            float p[N];
-            RS::loadf(pe + (size_t)t * d, d, lane, p);
-#pragma unroll
-            for (int i = 0; i < N; ++i) out[i] += p[i];
-        }
-        if constexpr (DROP == 2) RS::dropout(out, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
-        if (!keep) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) out[i] = 0.f;
-        }
-        RS::store(xhat + (size_t)row * d, d, lane, z);
-        RS::store(y + (size_t)row * d, d, lane, out);
-        if (lane == 0) rstd_out[row] = rstd;
     }
 }
 
@@ -132,49 +149,67 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < N; ++i) acc_g[i] = acc_b[i] = acc_z[i] = 0.f;
     const float inv_d = 1.f / (float)d;
-    for (int row = blockIdx.x * LN_WAVES + w; row < rows; row += gridDim.x * LN_WAVES) {
-        const int b = row / T_, t = row - b * T_;
-        const bool keep = lens ? (t < lens[b]) : true;
-        float o[N];
-        if (keep) {
-            float gy[N], xh[N];
-            RS::load(dy + (size_t)row * d, d, lane, gy);
-            if (dy2) {
-                float e[N];
-                RS::load(dy2 + (size_t)row * d, d, lane, e);
+    // LN_U rows per wave and trip with their loads issued together (see add_ln_fwd_kernel)
+    constexpr int LN_U = (N <= 8) ? LN_UNROLL : ((N <= 16) ? 2 : 1);
+    const int stride = gridDim.x * LN_WAVES;
+    for (int row0 = blockIdx.x * LN_WAVES + w; row0 < rows; row0 += LN_U * stride) {
+        float gy[LN_U][N], xh[LN_U][N], e[LN_U][N], rs[LN_U];
+        bool keep[LN_U];
 #pragma unroll
-                for (int i = 0; i < N; ++i) gy[i] += e[i];
+        for (int u = 0; u < LN_U; ++u) {
+            const int row = row0 + u * stride;
+            keep[u] = false;
+            if (row < rows) {      // wave-uniform
+                const int b = row / T_, t = row - b * T_;
+                keep[u] = lens ? (t < lens[b]) : true;
+                if (keep[u]) {
+                    RS::load(dy + (size_t)row * d, d, lane, gy[u]);
+                    if (dy2) RS::load(dy2 + (size_t)row * d, d, lane, e[u]);
+                    RS::load(xhat + (size_t)row * d, d, lane, xh[u]);
+                    rs[u] = rstd_in[row];
+                }
             }
-            if constexpr (DROP == 2) RS::dropout(gy, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
-            RS::load(xhat + (size_t)row * d, d, lane, xh);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                acc_g[i] += gy[i] * xh[i];
-                acc_b[i] += gy[i];
-                gy[i] *= g[i];
-                s1 += gy[i];
-                s2 += gy[i] * xh[i];
-            }
-            s1 = wave_sum(s1) * inv_d;
-            s2 = wave_sum(s2) * inv_d;
-            const float rstd = rstd_in[row];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                o[i] = rstd * (gy[i] - s1 - xh[i] * s2);
-                if constexpr (!VEC8) o[i] = (i * 64 + lane < d) ? o[i] : 0.f;
-                if constexpr (DROP != 1) acc_z[i] += o[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < N; ++i) o[i] = 0.f;
         }
-        RS::store(dz + (size_t)row * d, d, lane, o);
-        if constexpr (DROP == 1) {   // gradient wrt the pre-dropout GEMM output (and its bias)
-            RS::dropout(o, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
 #pragma unroll
-            for (int i = 0; i < N; ++i) acc_z[i] += o[i];
-            RS::store(dx + (size_t)row * d, d, lane, o);
+        for (int u = 0; u < LN_U; ++u) {
+            const int row = row0 + u * stride;
+            if (row >= rows) break;
+            float o[N];
+            if (keep[u]) {
+                if (dy2) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) gy[u][i] += e[u][i];
+                }
+                if constexpr (DROP == 2) RS::dropout(gy[u], (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    acc_g[i] += gy[u][i] * xh[u][i];
+                    acc_b[i] += gy[u][i];
+                    gy[u][i] *= g[i];
+                    s1 += gy[u][i];
+                    s2 += gy[u][i] * xh[u][i];
+                }
+                s1 = wave_sum(s1) * inv_d;
+                s2 = wave_sum(s2) * inv_d;
+                const float rstd = rs[u];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    o[i] = rstd * (gy[u][i] - s1 - xh[u][i] * s2);
+                    if constexpr (!VEC8) o[i] = (i * 64 + lane < d) ? o[i] : 0.f;
+                    if constexpr (DROP != 1) acc_z[i] += o[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) o[i] = 0.f;
+            }
+            RS::store(dz + (size_t)row * d, d, lane, o);
+            if constexpr (DROP == 1) {   // gradient wrt the pre-dropout GEMM output (and its bias)
+                RS::dropout(o, (uint32_t)row * (uint32_t)d, lane, seed, thr, dscale);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc_z[i] += o[i];
+                RS::store(dx + (size_t)row * d, d, lane, o);
+            }
         }
     }
     // LN_WAVES x d floats of dynamic LDS (8 KiB at d = 512): a fixed 32-KiB array left room for only
@@ -195,8 +230,9 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
 // forward: 1024 workgroups measured best (5.15 TB/s vs 3.9 at 512); backward: its grid is also the
 // number of partial rows the finalize pass has to sum
 static int ln_grid_fwd(int rows) {
+    static const int cap = getenv("ASR_LN_GRID_FWD") ? atoi(getenv("ASR_LN_GRID_FWD")) : 1024;
     int g = ceil_div(rows, LN_WAVES);
-    return g < 1024 ? g : 1024;
+    return g < cap ? g : cap;
 }
 static int ln_grid(int rows) {
     static const int cap = getenv("ASR_LN_GRID") ? atoi(getenv("ASR_LN_GRID")) : 1024;   // measured: 256 -> 29.7, 512 -> 21.3, 1024 -> 19.4, 2048 -> 23.5 us

@@ -7,7 +7,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ASR_BF16, ASR_F32, ACT_NONE, ACT_RELU, LN_REDUCE_MAX, TN_GROUP_MAX, LnReduceItem, TnProblem, check, lib
+from ._lib import ASR_BF16, ASR_F32, ACT_NONE, ACT_RELU, LN_REDUCE_MAX, TN_GROUP_MAX, LnReduceItem, TnProblem, check
+from ._lib import fast as lib      # vectorcall trampolines into the C ABI (_lib.py); pointers and stream handles are plain ints
 
 _DT = {torch.float32: ASR_F32, torch.bfloat16: ASR_BF16}
 
@@ -24,7 +25,7 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise ValueError("the HIP path needs CUDA (ROCm) tensors; there is no CPU fallback")
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 _DEV_INDEX = None
@@ -39,17 +40,17 @@ def _stream():
     private raw getter is a single C call."""
     global _DEV_INDEX
     if STREAM_OVERRIDE is not None:
-        return ctypes.c_void_p(STREAM_OVERRIDE)
+        return STREAM_OVERRIDE
     if _DEV_INDEX is None:
         _DEV_INDEX = torch.cuda.current_device()   # one process per GPU: bind_device() (engine construction) or the first launch sets it
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
+    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
 def stream_fork(to_stream_handle, from_stream_handle=None):
     """Work queued on `to` from now on runs after what is queued on `from` (default: torch's current stream) so far.
     Raw stream handles (ints); ~2 us of host time against ~12 us for torch.cuda.Event record + wait."""
-    frm = _stream() if from_stream_handle is None else ctypes.c_void_p(from_stream_handle)
-    check(lib.asr_stream_fork(frm, ctypes.c_void_p(to_stream_handle)), "asr_stream_fork")
+    frm = _stream() if from_stream_handle is None else from_stream_handle
+    check(lib.asr_stream_fork(frm, to_stream_handle), "asr_stream_fork")
 
 
 def bind_device(device):
@@ -206,7 +207,7 @@ def add_ln_bwd_reduce_batched(items, d):
             assert dg.numel() == d and db.numel() == d and (dbias is None or dbias.numel() == d)
             assert part.numel() >= lib.asr_add_ln_bwd_workspace_bytes(rows, d)
             q.ws, q.dgamma, q.dbeta, q.dbias, q.rows = _p(part), _p(dg), _p(db), _p(dbias), rows
-        check(lib.asr_add_ln_bwd_reduce_batched(ctypes.byref(arr), len(chunk), d, _stream()), "asr_add_ln_bwd_reduce_batched")
+        check(lib.asr_add_ln_bwd_reduce_batched(ctypes.addressof(arr), len(chunk), d, _stream()), "asr_add_ln_bwd_reduce_batched")
 
 
 # --------------------------------------------------------------------------------- attention
@@ -591,7 +592,7 @@ def gemm_tn_grouped(problems, accumulate=True):
             q.dY, q.X, q.dW, q.dbias = _p(dy), _p(x), _p(dw), _p(dbias)
             q.M, q.N, q.K, q.ldy, q.ldx, q.ldw = M, N, Kd, dy.stride(0), x.stride(0), dw.stride(0)
             flops += 2.0 * M * N * Kd
-        timed("gemm_tn", flops, lambda: check(lib.asr_gemm_tn_grouped_bf16(ctypes.byref(arr), len(chunk), int(accumulate), _stream()),
+        timed("gemm_tn", flops, lambda: check(lib.asr_gemm_tn_grouped_bf16(ctypes.addressof(arr), len(chunk), int(accumulate), _stream()),
                                               "asr_gemm_tn_grouped_bf16"))
 
 

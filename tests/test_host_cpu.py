@@ -56,6 +56,41 @@ def test_error_reporting_without_gpu():
         _lib.check(-1, "x")
 
 
+def test_fastcall_trampolines_agree_with_ctypes():
+    """The launch path (csrc/fastcall.c) reaches the same entry points with the same argument placement as ctypes:
+    host-only entry points give identical results, argument errors come back as the same ASR_EINVAL, and the mixed
+    pointer / int / float / size_t signatures (floats interleaved, > 6 integer arguments on the stack) parse."""
+    from asr_chinese_e2e_amd import _lib
+    f, c = _lib.fast, _lib.lib
+    assert f.asr_abi_version() == c.asr_abi_version() == _lib.ABI_VERSION
+    for args in ((32, 500, 22), (1, 1, 1), (7, 2000, 50)):
+        assert f.asr_ctc_workspace_bytes(*args) == c.asr_ctc_workspace_bytes(*args)
+    for args in ((16000, 512), (3, 8)):
+        assert f.asr_add_ln_bwd_workspace_bytes(*args) == c.asr_add_ln_bwd_workspace_bytes(*args)
+        assert f.asr_colsum_workspace_bytes(*args) == c.asr_colsum_workspace_bytes(*args)
+    assert f.asr_sumsq_workspace_bytes(1 << 33) == c.asr_sumsq_workspace_bytes(1 << 33)      # size_t beyond 32 bits
+    assert f.asr_gemm_tn_workspace_bytes(16000, 512, 512) == c.asr_gemm_tn_workspace_bytes(16000, 512, 512)
+    # 17 arguments, floats at positions 12 and 13: a null pointer is refused before anything is launched
+    assert f.asr_add_ln_fwd(None, None, None, None, None, None, None, None, None, 1, 1, 8, 0.0, 0, 0, 0, None) == -1
+    assert "null pointer" in _lib.last_error()
+    # the shape check sits behind 5 pointers and reads stack-passed ints: M = -3 must be what the callee sees
+    assert f.asr_gemm_nt_bf16(16, 16, None, None, 16, -3, 8, 8, 8, 8, 8, 0, None) == -1
+    assert "M=-3" in _lib.last_error()
+    # two floats interleaved with ints: the SECOND one (dropout p = 1.5) must arrive in its own register and is refused by value
+    assert f.asr_embed_bwd(16, 16, 16, 22.6, 4, 8, 100, 1.5, 0, 0, None) == -1
+    assert "p=1.5" in _lib.last_error()
+    with pytest.raises(TypeError):
+        f.asr_ctc_workspace_bytes(32, 500)                 # arity
+    with pytest.raises(TypeError):
+        f.asr_ctc_workspace_bytes(32, 500, "22")           # kind
+    with pytest.raises(OverflowError):
+        f.asr_ctc_workspace_bytes(32, 500, 1 << 40)        # int range
+    from asr_chinese_e2e_amd import _asr_fastcall
+    with pytest.raises(ValueError):
+        _asr_fastcall.make(1, "x", "F" * 9, "I")           # more floats than xmm registers: outside the trampoline
+
+
+
 def test_no_cpu_fallback_in_product_path():
     from asr_chinese_e2e_amd import kernels as K
     with pytest.raises(ValueError, match="no CPU fallback"):
