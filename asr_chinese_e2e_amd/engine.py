@@ -243,6 +243,39 @@ def ffn_param_block(pre, d, ff):
             [(pre + "layer_norm.weight", (d,))], [(pre + "layer_norm.bias", (d,))]]
 
 
+_STREAMS = {}
+
+
+def _shared_stream(device, kind):
+    """One auxiliary stream of each kind per device and PROCESS, shared by every engine: the HIP runtime multiplexes
+    streams onto a few hardware queues, and a second model with streams of its own ran its step 2.5x slower
+    (13.8 against 5.6 ms, joint config) - its main and side work landed on one queue.  Engines of one process run
+    their steps one after the other, so sharing costs nothing."""
+    key = (torch.device(device).index, kind)
+    if key not in _STREAMS:
+        _STREAMS[key] = _side_stream(device) if kind == "wgrad" else torch.cuda.Stream(device=device)
+    return _STREAMS[key]
+
+
+def _side_stream(device):
+    """The weight-gradient stream.  ASR_SIDE_PRIORITY=low (default) creates it at the LOWEST HIP stream priority: its
+    GEMMs are off the critical path, and at equal priority they take CUs from the dgrad / attention / LayerNorm chain
+    whenever both have workgroups pending (the LayerNorm backward ran 30 us beside them against 14 us alone).
+    torch.cuda.Stream only offers normal / high, so the stream comes from the HIP runtime torch has loaded and is
+    wrapped as an ExternalStream (host plumbing; it lives as long as the process)."""
+    if os.environ.get("ASR_SIDE_PRIORITY", "low") != "low":
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0 or least.value == greatest.value:
+        return torch.cuda.Stream(device=device)
+    h = ctypes.c_void_p()
+    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value) != 0 or not h.value:      # 1 = hipStreamNonBlocking
+        return torch.cuda.Stream(device=device)
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class Engine:
     """Forward + backward of encoder (+ decoder) (+ CTC head) for one minibatch on one GPU."""
 
@@ -294,11 +327,11 @@ class Engine:
         # latency-bound kernels of both chains fill each other's idle CUs.
         # the CTC branch of the joint model runs on its own stream beside the decoder's forward pass (ctc_branch_async);
         # off in deterministic mode (the weight gradients then share one scratch buffer on whatever stream is current)
-        self.ctc_stream = torch.cuda.Stream(device=flat.device)
+        self.ctc_stream = _shared_stream(flat.device, "aux")
         self.ws_ctc = K.Workspace(flat.device)
         self.overlap_ctc = os.environ.get("ASR_CTC_OVERLAP", "1") == "1"
         self.aux_overlap = os.environ.get("ASR_AUX_OVERLAP", "1") == "1" and not K.deterministic()   # cross-attention K|V work on that stream too
-        self.side = torch.cuda.Stream(device=flat.device)
+        self.side = _shared_stream(flat.device, "wgrad")
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
         self.overlap_wgrad = os.environ.get("ASR_WGRAD_OVERLAP", "1") == "1"      # 0: weight gradients on the main stream (A/B runs)

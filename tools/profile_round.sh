@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profiles of the headline bench command (run on the GPU box):  bash tools/profile_round.sh <tag>
+# kernel trace + stats, then separate --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) as MI355X_MICROARCH.md prescribes.
+# Writes the summaries under gpurun_out/prof_<tag>/ ; copy the ones to keep into profiles/.
+set -e
+TAG=${1:-r2}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 40 --warmup 10 --no-extras --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o p --output-format csv -- python3 $R/bench.py $ARGS > $OUT/bench_profiled.json 2> $OUT/trace.err
+echo "trace done"
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- python3 $R/bench.py $ARGS --no-kernel-timer > /dev/null 2> $OUT/fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o p --output-format csv -- python3 $R/bench.py $ARGS --no-kernel-timer > /dev/null 2> $OUT/write.err
+echo "write done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o p --output-format csv -- python3 $R/bench.py $ARGS --no-kernel-timer > /dev/null 2> $OUT/mfma.err
+echo "mfma done"
+cd $R
+python3 tools/trace_stats.py $(find $OUT/trace -name "*kernel_trace.csv") $OUT/kernel_stats_per_step.csv > $OUT/kernel_stats_per_step.txt
+cp $(find $OUT/trace -name "*kernel_stats.csv") $OUT/kernel_stats.csv
+python3 tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
+python3 tools/mfma_util.py $(find $OUT/mfma -name "*counter_collection.csv") $OUT/mfma_util.json
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
+ls -la $OUT
