@@ -565,20 +565,45 @@ static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bia
 //   TB = true : B is (K, N), N-contiguous: C = A B              (input gradient: dx = dy W; W as stored, no transposed copy:
 //               the operand fragments come from transposed LDS reads in natural k order)
 // mask (TB only): C = 0 where mask <= 0 (the ReLU backward of module.py:70-71 in the store tail).
-constexpr int SM = 64, SS = 72;      // tile edge, LDS row stride (elements)
-struct Stage2 { u32x4 v[2]; };
-__device__ __forceinline__ void sm_load(Stage2& st, const bf16_t* __restrict__ base, size_t ld, int row0, int rows, int c0, int cols, int tid) {
+constexpr int SM = 64, SS = 72;      // tile edge, LDS row stride (elements) of a 64-column tile
+// k-step: 256.  With 64-deep steps the kernel ran one global-load round trip per step (the next step's loads are only
+// covered by 4 MFMAs): 8 .. 24 round trips, 13 us on average.  A 256-deep step is 2 .. 6 round trips; the step's operands
+// (A 64 x 256, B 64 x 256 or 256 x 64) are 16 16-byte loads per thread, in flight together.
+constexpr int SK = 256;
+constexpr int SAS = SK + 8;          // row stride (elements) of a K-contiguous 64 x 256 tile: 528 B, rows 4 banks apart
+constexpr int S_A = SM * SAS;        // elements of the A tile (and of a K-contiguous B tile)
+constexpr int S_BT = SK * SS;        // elements of a [k][n] B tile
+struct StageK { u32x4 v[8]; };
+// rows [row0, row0+64) x columns [c0, c0+256) of a (rows, ld) matrix; OOB -> 0
+__device__ __forceinline__ void sk_load_rows(StageK& st, const bf16_t* __restrict__ base, size_t ld, int row0, int rows, int c0, int cols, int tid) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 8; ++c) {
+        const int id = tid + 256 * c, row = id >> 5, ch = id & 31;
+        const int gr = row0 + row, gc = c0 + ch * 8;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        st.v[c] = (gr < rows && gc < cols) ? *(const u32x4*)(base + (size_t)gr * ld + gc) : z;
+    }
+}
+__device__ __forceinline__ void sk_store_rows(const StageK& st, bf16_t* tile, int tid) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int id = tid + 256 * c, row = id >> 5, ch = id & 31;
+        *(u32x4*)(tile + row * SAS + ch * 8) = st.v[c];
+    }
+}
+// rows (= k) [row0, row0+256) x columns (= n) [c0, c0+64)
+__device__ __forceinline__ void sk_load_cols(StageK& st, const bf16_t* __restrict__ base, size_t ld, int row0, int rows, int c0, int cols, int tid) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
         const int id = tid + 256 * c, row = id >> 3, ch = id & 7;
         const int gr = row0 + row, gc = c0 + ch * 8;
         const u32x4 z = {0u, 0u, 0u, 0u};
         st.v[c] = (gr < rows && gc < cols) ? *(const u32x4*)(base + (size_t)gr * ld + gc) : z;
     }
 }
-__device__ __forceinline__ void sm_store(const Stage2& st, bf16_t* tile, int tid) {
+__device__ __forceinline__ void sk_store_cols(const StageK& st, bf16_t* tile, int tid) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 8; ++c) {
         const int id = tid + 256 * c, row = id >> 3, ch = id & 7;
         *(u32x4*)(tile + row * SS + ch * 8) = st.v[c];
     }
@@ -592,46 +617,71 @@ __device__ __forceinline__ bf16x8 sm_frag_tr(const bf16_t* tile, int col0, int s
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+template <bool TB>
+constexpr int small_lds_bytes() { return 2 * (S_A + (TB ? S_BT : S_A)) * 2; }
+
 template <bool TB, int ACT>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bm, const float* __restrict__ bias,
                                                          const bf16_t* __restrict__ mask, bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                          int ldc, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * SM * SS];      // [2 buffers][A | B]
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];      // [2 buffers][A | B]
+    constexpr int BUF = S_A + (TB ? S_BT : S_A);
+    bf16_t* smem = (bf16_t*)smem_s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
     const int m0 = tm * SM, n0 = tn * SM;
     const int wm = w >> 1, wn = w & 1, r = lane & 31, hh = lane >> 5;
-    f32x16 acc;   // C^T block: n in registers, m on the lane
+    f32x16 acc[2];   // C^T block: n in registers, m on the lane; two accumulators (even / odd k-steps) halve the dependent MFMA chain
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    Stage2 sa, sb;
-    auto load = [&](int k0) {
-        sm_load(sa, A, lda, m0, M, k0, K, tid);
-        if (TB) sm_load(sb, Bm, ldb, k0, K, n0, N, tid);     // rows = k, columns = n
-        else sm_load(sb, Bm, ldb, n0, N, k0, K, tid);        // rows = n, columns = k
-    };
-    load(0);
-    sm_store(sa, smem, tid);
-    sm_store(sb, smem + SM * SS, tid);
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+    // two register stages: the loads of steps kt + 1 AND kt + 2 are in flight under the MFMAs of step kt (a workgroup is one
+    // wave per SIMD and nothing else hides the global latency)
+    StageK sa0, sb0, sa1, sb1;
+#define SK_LOAD(SA_, SB_, K0_)                                                                 \
+    {                                                                                          \
+        sk_load_rows(SA_, A, lda, m0, M, (K0_), K, tid);                                       \
+        if (TB) sk_load_cols(SB_, Bm, ldb, (K0_), K, n0, N, tid); /* rows = k, columns = n */   \
+        else sk_load_rows(SB_, Bm, ldb, n0, N, (K0_), K, tid);    /* rows = n, columns = k */   \
+    }
+#define SK_STORE(SA_, SB_, BUF_)                                                               \
+    {                                                                                          \
+        sk_store_rows(SA_, (BUF_), tid);                                                       \
+        if (TB) sk_store_cols(SB_, (BUF_) + S_A, tid);                                         \
+        else sk_store_rows(SB_, (BUF_) + S_A, tid);                                            \
+    }
+#define SK_MMA(KT_)                                                                                                                   \
+    {                                                                                                                                 \
+        const bf16_t* As = smem + ((KT_) & 1) * BUF;                                                                                  \
+        const bf16_t* Bs = As + S_A;                                                                                                  \
+        /* all 16 MFMA steps, unrolled: the loads zero-pad a partial last step, and a run-time trip count made acc[ks & 1] a   */     \
+        /* run-time register index (s_set_gpr_idx + 32 register copies per MFMA: 4.3 us per step)                            */     \
+        _Pragma("unroll") for (int ks = 0; ks < SK / 16; ++ks) {                                                                      \
+            const bf16x8 af = *(const bf16x8*)(As + (wm * 32 + r) * SAS + 16 * ks + 8 * hh);                                          \
+            const bf16x8 bf = TB ? sm_frag_tr(Bs, wn * 32, ks, lane) : *(const bf16x8*)(Bs + (wn * 32 + r) * SAS + 16 * ks + 8 * hh); \
+            acc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc[ks & 1], 0, 0, 0);                                      \
+        }                                                                                                                             \
+    }
+    const int nk = (K + SK - 1) / SK;
+    SK_LOAD(sa0, sb0, 0);
+    if (nk > 1) SK_LOAD(sa1, sb1, SK);
+    SK_STORE(sa0, sb0, smem);
     __syncthreads();
-    const int nk = (K + SM - 1) / SM;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bf16_t* As = smem + (kt & 1) * 2 * SM * SS;
-        const bf16_t* Bs = As + SM * SS;
-        if (kt + 1 < nk) load((kt + 1) * SM);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 af = *(const bf16x8*)(As + (wm * 32 + r) * SS + 16 * ks + 8 * hh);
-            const bf16x8 bf = TB ? sm_frag_tr(Bs, wn * 32, ks, lane) : *(const bf16x8*)(Bs + (wn * 32 + r) * SS + 16 * ks + 8 * hh);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc, 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            bf16_t* nx = smem + ((kt + 1) & 1) * 2 * SM * SS;      // last read in step kt - 1, before the barrier below of that step
-            sm_store(sa, nx, tid);
-            sm_store(sb, nx + SM * SS, tid);
-        }
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: buffer 0 holds step kt, stage 1 holds step kt + 1
+        if (kt + 2 < nk) SK_LOAD(sa0, sb0, (kt + 2) * SK);
+        SK_MMA(kt);
+        if (kt + 1 < nk) SK_STORE(sa1, sb1, smem + BUF);      // buffer 1 was last read in step kt - 1, before that step's barrier
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: buffer 1 holds step kt + 1, stage 0 holds step kt + 2
+        if (kt + 3 < nk) SK_LOAD(sa1, sb1, (kt + 3) * SK);
+        SK_MMA(kt + 1);
+        if (kt + 2 < nk) SK_STORE(sa0, sb0, smem);
         __syncthreads();
     }
+#undef SK_LOAD
+#undef SK_STORE
+#undef SK_MMA
     const int m = m0 + wm * 32 + r;
     if (m >= M) return;
 #pragma unroll
@@ -641,7 +691,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const bf16_t* __restric
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = acc[4 * g4 + e] + (bias ? bias[n + e] : 0.f);
+            float x = acc[0][4 * g4 + e] + acc[1][4 * g4 + e] + (bias ? bias[n + e] : 0.f);
             if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
             o[e] = x;
         }
@@ -1550,7 +1600,17 @@ extern "C" int asr_gemm_small_bf16(const void* A, const void* Bm, const float* b
     const int tiles_n = ceil_div(N, SM), grid = tiles_n * ceil_div(M, SM);
     const bf16_t *a = (const bf16_t*)A, *b = (const bf16_t*)Bm, *mk = (const bf16_t*)mask;
     bf16_t* c = (bf16_t*)C;
-#define SMALL(TB_, ACT_) gemm_small_kernel<TB_, ACT_><<<grid, 256, 0, st>>>(a, b, bias, mk, c, M, N, K, lda, ldb, ldc, tiles_n)
+    static bool attr = false;
+    if (!attr) {      // 135 / 141 KiB of dynamic LDS
+        (void)hipFuncSetAttribute((const void*)gemm_small_kernel<true, ASR_ACT_RELU_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_bytes<true>());
+        (void)hipFuncSetAttribute((const void*)gemm_small_kernel<true, ASR_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_bytes<true>());
+        (void)hipFuncSetAttribute((const void*)gemm_small_kernel<true, ASR_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_bytes<true>());
+        (void)hipFuncSetAttribute((const void*)gemm_small_kernel<false, ASR_ACT_RELU_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_bytes<false>());
+        (void)hipFuncSetAttribute((const void*)gemm_small_kernel<false, ASR_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_bytes<false>());
+        (void)hipFuncSetAttribute((const void*)gemm_small_kernel<false, ASR_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_bytes<false>());
+        attr = true;
+    }
+#define SMALL(TB_, ACT_) gemm_small_kernel<TB_, ACT_><<<grid, 256, small_lds_bytes<TB_>(), st>>>(a, b, bias, mk, c, M, N, K, lda, ldb, ldc, tiles_n)
     if (trans_b) {
         if (act == ASR_ACT_RELU_MASK) SMALL(true, ASR_ACT_RELU_MASK);
         else if (act == ASR_ACT_RELU) SMALL(true, ASR_ACT_RELU);
