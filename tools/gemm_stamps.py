@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from asr_chinese_e2e_amd import kernels as K
 M = 16000
-for N, Kd, name in [(512, 512, "fc")]:
+for N, Kd, name in [(512, 512, "fc"), (1536, 512, "qkv"), (512, 1024, "w2")]:
     x = torch.randn(M, Kd, device="cuda").bfloat16(); w = (torch.randn(N, Kd, device="cuda") * 0.05).bfloat16()
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     st = torch.zeros(256 * 16 * 2, device="cuda", dtype=torch.float32)   # 256 x 16 uint64
