@@ -1,6 +1,8 @@
 """Epoch / step loop with the reference's shape (Trainer/trainer11.py:14-132): iterate() per
-minibatch, checkpoints named e{epoch}_s{step}.model/.opt, periodic evaluation.  TensorBoard is
-replaced by JSON lines (tensorboard is not a dependency of the hot path)."""
+minibatch, checkpoints named e{epoch}_s{step}.model/.opt, periodic evaluation.  Scalars go where the reference's
+`SummaryWriter(self.exp_root).add_scalar(tag, value, global_step)` puts them - a TensorBoard event file under
+exp_root (`self.summary_writer`, written by Utils/tfevents.py: the tensorboard package is not a dependency) -
+and, for scripts, to scalars.jsonl beside it."""
 import datetime
 import json
 import os
@@ -8,6 +10,8 @@ import shutil
 import time
 
 import torch
+
+from ..Utils.tfevents import EventFileWriter
 
 
 class Trainer11:
@@ -29,12 +33,18 @@ class Trainer11:
         self.config = self.model.config
         self.log_path = log_path or os.path.join(self.exp_root, "scalars.jsonl")
         self.history = []
+        self.summary_writer = EventFileWriter(self.exp_root)      # trainer11.py:38
+        self._log_file = open(self.log_path, "a")
 
     def add_scalar(self, tag, value, step):
         rec = {"tag": tag, "value": float(value), "step": int(step)}
         self.history.append(rec)
-        with open(self.log_path, "a") as f:
-            f.write(json.dumps(rec) + "\n")
+        self.summary_writer.add_scalar(tag, rec["value"], rec["step"])
+        self._log_file.write(json.dumps(rec) + "\n")
+
+    def flush_logs(self):
+        self.summary_writer.flush()
+        self._log_file.flush()
 
     def train(self, from_ckpt=None, from_epoch=None, from_step=None):
         if from_ckpt is not None and from_epoch is not None and from_step is not None:
@@ -62,6 +72,7 @@ class Trainer11:
         dt = time.time() - t0
         self.add_scalar("train/utt_per_s", utts / max(dt, 1e-9), self.global_step)
         self.add_scalar("train/frames_per_s", frames / max(dt, 1e-9), self.global_step)
+        self.flush_logs()
         self.save_ckpt()
         if self.test_iter is not None:
             self.evaluate(self.test_iter, "test/")

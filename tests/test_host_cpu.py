@@ -396,3 +396,42 @@ def test_bench_launcher_starts_n_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stdout + p.stderr)
+
+
+def test_tensorboard_event_file_format(tmp_path):
+    """Utils/tfevents.py writes what torch.utils.tensorboard.SummaryWriter.add_scalar writes for the reference's trainers
+    (Trainer/trainer11.py:38, 59, 112): TFRecord framing with masked CRC-32C, Event{wall_time, step, summary{value{tag,
+    simple_value}}}, a file-version record first.  Known answers: the CRC-32C check value, the mask constant applied to it,
+    and the exact bytes of one event."""
+    import struct
+    from asr_chinese_e2e_amd.Utils import tfevents as T
+    assert T.crc32c(b"123456789") == 0xE3069283                 # CRC-32C (Castagnoli) check value
+    assert T.crc32c(b"") == 0 and T.masked_crc(b"") == 0xA282EAD8
+    c = 0xE3069283
+    assert T.masked_crc(b"123456789") == (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    ev = T.encode_scalar_event("lr", 0.5, 300, 2.0)
+    want = (b"\x09" + struct.pack("<d", 2.0)            # 1: wall_time, 64-bit
+            + b"\x10\xac\x02"                           # 2: step = 300, varint
+            + b"\x2a\x0b"                               # 5: summary, 11 bytes
+            + b"\x0a\x09"                               #    1: value, 9 bytes
+            + b"\x0a\x02lr"                             #       1: tag
+            + b"\x15" + struct.pack("<f", 0.5))         #       2: simple_value, 32-bit
+    assert ev == want
+    rec = T.record(ev)
+    assert rec[:8] == struct.pack("<Q", len(ev)) and len(rec) == len(ev) + 16
+    w = T.EventFileWriter(str(tmp_path))
+    w.add_scalar("lr", 1e-4, 3)
+    w.add_scalar("train/loss", 12.5, 100)
+    w.add_scalar("x", -1.0, -2)                                 # negative int64 step: ten-byte varint
+    w.close()
+    assert os.path.basename(w.path).startswith("events.out.tfevents.")
+    got = T.read_events(w.path)
+    assert got[0]["file_version"] == "brain.Event:2"
+    assert [(e["tag"], e["step"]) for e in got[1:]] == [("lr", 3), ("train/loss", 100), ("x", -2)]
+    assert abs(got[1]["value"] - 1e-4) < 1e-10 and got[2]["value"] == 12.5 and got[3]["value"] == -1.0
+    raw = bytearray(open(w.path, "rb").read())
+    raw[40] ^= 1                                                # one flipped bit is caught by the record checksums
+    bad = tmp_path / "bad"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ValueError):
+        T.read_events(str(bad))

@@ -42,6 +42,13 @@ def test_trainer_checkpoint_and_eval(tmp_path):
     assert {"lr", "train/loss", "dev/loss", "test/loss", "train/utt_per_s"} <= tags
     losses = [h["value"] for h in tr.history if h["tag"] == "train/loss"]
     assert all(np.isfinite(losses))
+    # the scalars are also in a TensorBoard event file under exp_root, where the reference's SummaryWriter puts them (trainer11.py:38, 59, 112)
+    from asr_chinese_e2e_amd.Utils import read_events
+    tr.flush_logs()
+    ev = [e for e in read_events(tr.summary_writer.path) if "tag" in e]
+    assert os.path.dirname(tr.summary_writer.path) == str(tmp_path / "exp")
+    assert [(e["tag"], e["step"]) for e in ev] == [(h["tag"], h["step"]) for h in tr.history]
+    assert all(abs(e["value"] - h["value"]) <= 1e-6 * abs(h["value"]) + 1e-30 for e, h in zip(ev, tr.history))
     # files named like the reference (trainer11.py:93-99)
     assert os.path.isfile(tmp_path / "exp" / "e1_s6.model") and os.path.isfile(tmp_path / "exp" / "e1_s6.opt")
     # resume: a fresh model + optimizer loaded from the checkpoint continues identically
