@@ -235,7 +235,10 @@ static int ln_grid_fwd(int rows) {
     return g < cap ? g : cap;
 }
 static int ln_grid(int rows) {
-    static const int cap = getenv("ASR_LN_GRID") ? atoi(getenv("ASR_LN_GRID")) : 1024;   // measured: 256 -> 29.7, 512 -> 21.3, 1024 -> 19.4, 2048 -> 23.5 us
+    // round 1 (one row per wave and trip), stand-alone: 256 -> 29.7, 512 -> 21.3, 1024 -> 19.4, 2048 -> 23.5 us.  With two rows per
+    // trip the step decides (tools/env_sweep.sh, ms per step): 256 -> 3.49, 384 -> 3.39, 512 -> 3.35, 1024 -> 3.38, 2048 -> 3.54
+    // (half the partial sums to write and to reduce, and the kernel holds fewer CUs beside the weight-gradient stream)
+    static const int cap = getenv("ASR_LN_GRID") ? atoi(getenv("ASR_LN_GRID")) : 512;
     int g = ceil_div(rows, LN_WAVES);
     return g < cap ? g : cap;
 }

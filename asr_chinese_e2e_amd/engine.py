@@ -103,6 +103,8 @@ class Linear:
 
     def __init__(self, flat, w_names, b_names, N, Kdim):
         self.flat, self.N, self.K = flat, N, Kdim
+        last = w_names[0].split(".")[-2]
+        self.tag = {"w_qs": "qkv", "w_1": "w1", "w_2": "w2"}.get(last, last)      # short role name (qkv, fc, w1, w2, ...)
         self.w32 = flat.span(flat.p, w_names[0], w_names[-1], (N, Kdim))
         self.gw = flat.span(flat.g, w_names[0], w_names[-1], (N, Kdim))
         self.wlp = flat.span(flat.lp, w_names[0], w_names[-1], (N, Kdim)) if flat.lp is not None else None
@@ -118,6 +120,7 @@ class Linear:
         """A Linear over output rows [lo, hi) of this one (e.g. the K|V part of Q|K|V)."""
         sub = object.__new__(Linear)
         sub.flat, sub.N, sub.K = self.flat, hi - lo, self.K
+        sub.tag = self.tag + "_rows"
         sub.w32, sub.gw = self.w32[lo:hi], self.gw[lo:hi]
         sub.wlp = self.wlp[lo:hi] if self.wlp is not None else None
         sub.b32 = self.b32[lo:hi] if self.b32 is not None else None
@@ -353,6 +356,9 @@ class Engine:
         self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "decoder")
         self.group_wgrad = None if (self.group_wgrad == "0" or self.deterministic) else self.group_wgrad
         self._pending = []
+        self._deferred = []
+        self.defer_wgrad = tuple(t for t in os.environ.get("ASR_WGRAD_DEFER", "fc").split(",") if t)
+        self._defer_point = os.environ.get("ASR_WGRAD_DEFER_POINT", "before")      # release before / after the attention backward launch
         self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
         self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
         self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
@@ -457,6 +463,7 @@ class Engine:
 
     def join_side(self):
         """Main stream waits for every weight-gradient kernel issued so far."""
+        self._release_deferred()
         self.flush_wgrads()
         if self.overlap_wgrad:
             torch.cuda.current_stream().wait_stream(self.side)
@@ -481,8 +488,26 @@ class Engine:
                 dy.record_stream(self.side)
                 x.record_stream(self.side)
 
+    def _release_deferred(self):
+        """Launch the weight gradients held back by ASR_WGRAD_DEFER (see _wgrad)."""
+        if self._deferred:
+            items, self._deferred = self._deferred, []
+            hold, self.defer_wgrad = self.defer_wgrad, ""
+            try:
+                for lin, dy, x, bias_from in items:
+                    self._wgrad(lin, dy, x, bias_from)
+            finally:
+                self.defer_wgrad = hold
+
     def _wgrad(self, lin, dy, x, bias_from=None):
         """lin.gw += dy^T x (and lin.gb += colsum(bias_from)) on the side stream."""
+        if self.defer_wgrad and self.overlap_wgrad and not self._in_decoder and lin.tag in self.defer_wgrad:
+            # ASR_WGRAD_DEFER (default "fc"): hold this projection's weight gradient until the layer's attention backward is
+            # about to be launched.  For the out-projection that takes it from beside its own (short) dgrad GEMM to beside the
+            # 83-us attention kernel: step 3.53 -> 3.50 ms.  Holding back any other projection (w1, w2, qkv) or releasing after
+            # the attention launch is slower (3.56 .. 3.73 ms, tools/env_sweep.sh): the side stream has no slack to give.
+            self._deferred.append((lin, dy, x, bias_from))
+            return
         fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
         if self.group_wgrad and (self.group_wgrad != "decoder" or self._in_decoder) and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
                 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
@@ -554,8 +579,12 @@ class Engine:
         if not c["cross"]:
             qkv = c["qkv"]
             dqkv = torch.empty_like(qkv)
+            if self._defer_point != "after":
+                self._release_deferred()
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
                        dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa)
+            if self._defer_point == "after":
+                self._release_deferred()
             self._wgrad(m.qkv, dqkv, c["x"], bias_from=dqkv)
             dx = m.qkv.dgrad(dqkv)
         else:
@@ -613,6 +642,7 @@ class Engine:
     def encoder_fwd(self, wave, wave_len, window=-1):
         """wave (B,T,F) in the compute dtype, wave_len (B) int32.  transformer_official.py:158-189."""
         B, T, F = wave.shape
+        self._deferred.clear()
         self._pending.clear()        # work queued by a step that did not finish (an exception between backward and
         self._ln_pending.clear()     # its flush) must not be launched into this step's gradients
         x_in = wave.reshape(B * T, F)
