@@ -1737,6 +1737,8 @@ static TnPlan tn_plan(int M, int N, int K) {
         const int s_floor = cus / tiles > 0 ? cus / tiles : 1;
         if (tiles * s_floor * 5 >= cus * 4) { splits = s_floor; ring = 4; }   // "4" = the one-per-CU form <2, 2>
         else { splits = ceil_div(2 * cus, tiles) > 1 ? (2 * cus) / tiles : 1; ring = 2; }
+        static const int split_pct = getenv("ASR_GEMM_TN_SPLIT_PCT") ? atoi(getenv("ASR_GEMM_TN_SPLIT_PCT")) : 100;   // tuning: fewer, longer workgroups
+        splits = splits * split_pct / 100;
         if (splits > max_s) splits = max_s;
         if (splits < 1) splits = 1;
     }
