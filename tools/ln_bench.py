@@ -25,3 +25,6 @@ ws = torch.empty(K.add_ln_bwd_workspace_bytes(rows, d), dtype=torch.uint8, devic
 dz = torch.empty_like(dy)
 t = timeit(lambda: K.add_ln_bwd(dy, None, xhat, rstd, g, lens, dg, db, None, B, T, ws, dz=dz, partials=ws))
 print(f"add_ln_bwd (partials only)  {t:6.1f} us  {3 * rows * d * 2 / t / 1e6:5.2f} TB/s")
+dy2 = torch.randn_like(x)
+t = timeit(lambda: K.add_ln_bwd(dy, dy2, xhat, rstd, g, lens, dg, db, None, B, T, ws, dz=dz, partials=ws))
+print(f"add_ln_bwd with the residual-path gradient (dy2)  {t:6.1f} us  {4 * rows * d * 2 / t / 1e6:5.2f} TB/s")
