@@ -329,6 +329,10 @@ def main():
         }
         if wire is not None:
             out["all_reduce"] = wire
+        if world > 1 and joint:
+            # the N = 1 line is quoted on configs[1] (CTC-only, a 1.6x lighter step): scale THIS workload against the N = 1 line's
+            # `joint_utterances_per_s`, not against its `value`
+            out["scaling_reference"] = {"n1_key": "joint_utterances_per_s", "workload": "joint CTC/attention model, same per-GPU batch"}
         out.update(extras)
         if summary:
             fam = {k: v for k, v in summary.items() if k in ("gemm_nt", "gemm_tn", "lib_gemm_dgrad")}
