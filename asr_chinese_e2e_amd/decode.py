@@ -13,6 +13,7 @@ following the parents, in the order the reference's lists would have (steps asce
 inside a step, stable sort by score).
 """
 import math
+import os
 
 import torch
 
@@ -67,6 +68,9 @@ def _search(model, eng, input, beam, nbest, decode_max_len, check_every):
     row_bytes = 2 * hd * caches[0].element_size()
     cur = 0
     steps_done = 0
+    use_sdpa = dk == 64 and eng.dtype == torch.bfloat16 and os.environ.get("ASR_DECODE_SDPA", "1") == "1"
+    o_buf = torch.empty(R, hd, dtype=eng.dtype, device=dev) if use_sdpa else None
+    lse_buf = None
     for i in range(Lcap):
         cache = caches[cur]
         y = K.embed_pe_fwd(last_tok.reshape(-1), eng.emb32, eng.pe[i:i + 1], d ** -0.5, R, 1, eng.dtype)   # :369-371
@@ -78,7 +82,13 @@ def _search(model, eng, input, beam, nbest, decode_max_len, check_every):
             y, _, _ = K.add_ln_fwd(slf.fc.fwd(o), y, slf.ln.g, slf.ln.b, None, None, R, 1)
             q = cross.q.fwd(y)
             ckv = cross_kv[l]
-            o = K.decode_attn(q, ckv[:, :hd], ckv[:, hd:], H, dk, T, kv_div=beam, k_len=wave_len, len_div=beam)
+            if use_sdpa:
+                # the beams of an utterance are `beam` query rows against the SAME encoder keys / values: that is the training
+                # attention kernel at Tq = beam (one workgroup per (utterance, head), K / V fetched once for all beams, MFMA) -
+                # 11 us against ~220 us for the one-wave-per-(row, head) decode kernel, which was 48 of the 65 ms of a search
+                o, lse_buf = K.sdpa_fwd(q, ckv[:, :hd], ckv[:, hd:], wave_len, B, H, beam, T, dk, o=o_buf, lse=lse_buf)
+            else:
+                o = K.decode_attn(q, ckv[:, :hd], ckv[:, hd:], H, dk, T, kv_div=beam, k_len=wave_len, len_div=beam)
             y, _, _ = K.add_ln_fwd(cross.fc.fwd(o), y, cross.ln.g, cross.ln.b, None, None, R, 1)
             h = ffn.w1.fwd(y, act=1)
             y, _, _ = K.add_ln_fwd(ffn.w2.fwd(h), y, ffn.ln.g, ffn.ln.b, None, None, R, 1)
@@ -97,20 +107,24 @@ def _search(model, eng, input, beam, nbest, decode_max_len, check_every):
 
 def _backtrace(rec_tok, rec_par, rec_end, rec_score, B, beam, nbest):
     steps = rec_tok.shape[0]
+    # plain nested lists: element access on a tensor costs ~1 us each, and this walk touches ~50 k of them per batch
+    # (33 of the 97 ms of a B = 32, beam 5 search before)
+    rec_tok, rec_par, rec_end, rec_score = rec_tok.tolist(), rec_par.tolist(), rec_end.tolist(), rec_score.tolist()
     out = []
     for b in range(B):
         ended = []                                           # in the order the reference appends to ended_hyps
         for i in range(steps):
+            end_i = rec_end[i][b]
             for k in range(beam):
-                e = int(rec_end[i, b, k])
+                e = end_i[k]
                 if not e:
                     continue
                 seq, kk = [], k
                 for s in range(i, -1, -1):
-                    seq.append(int(rec_tok[s, b, kk]))
-                    kk = int(rec_par[s, b, kk])
+                    seq.append(rec_tok[s][b][kk])
+                    kk = rec_par[s][b][kk]
                 seq = [SOS_ID] + seq[::-1] + ([EOS_ID] if e == 2 else [])
-                ended.append((float(rec_score[i, b, k]), seq))
+                ended.append((rec_score[i][b][k], seq))
         ended = sorted(ended, key=lambda h: h[0], reverse=True)[: min(len(ended), nbest)]
         out.append([{"yseq": seq, "score": sc} for sc, seq in ended])
     return out
