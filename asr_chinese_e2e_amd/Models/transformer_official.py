@@ -300,11 +300,11 @@ class _SpeechTransformer(BaseModel):
             return decode.joint_beam_search(self, input, beam_size, nbest, decode_max_len, ctc_weight)
         return decode.beam_search(self, input, beam_size, nbest, decode_max_len)
 
-    def ctc_prefix_beam_search(self, input, beam_size=5, nbest=1, frame_topk=10):
+    def ctc_prefix_beam_search(self, input, beam_size=5, nbest=1, frame_topk=10, on_device=None):
         """CTC prefix beam search over the CTC head (decode.ctc_prefix_beam_search): per utterance at most `nbest`
-        {'yseq': [ids], 'score': log p(yseq | x)}."""
+        {'yseq': [ids], 'score': log p(yseq | x)}.  on_device: None = the device kernel when beam * (frame_topk + 1) <= 64."""
         from .. import decode
-        return decode.ctc_prefix_beam_search(self, input, beam_size, nbest, frame_topk)
+        return decode.ctc_prefix_beam_search(self, input, beam_size, nbest, frame_topk, on_device)
 
     def ctc_greedy_search(self, input):
         """Best-path CTC hypotheses of a batch: list of id lists (repeats merged, blanks removed)."""

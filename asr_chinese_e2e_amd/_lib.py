@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -60,6 +60,8 @@ SIGNATURES = {
     "asr_decode_attn": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
     "asr_logsoftmax_topk": (I, [P, P, P, I, I, I, I, I, P]),
     "asr_ctc_frame_topk": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "asr_ctc_prefix_beam_workspace_bytes": (Z, [I, I, I]),
+    "asr_ctc_prefix_beam": (I, [P, P, P, P, P, Z, P, P, P, I, I, I, I, I, I, I, P]),
     "asr_beam_step": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "asr_cache_gather": (I, [P, P, P, I, I, I, I, I, I, P]),
     "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),

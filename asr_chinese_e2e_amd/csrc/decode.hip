@@ -336,6 +336,162 @@ extern "C" int asr_cache_gather(const void* src, void* dst, const int32_t* paren
 }
 
 // ---------------------------------------------------------------------------------------------
+// CTC prefix beam search on the device (Hannun et al. 2014, algorithm 1 without a language model; the restatement the tests
+// check against is oracle/decode_ref.py::ctc_prefix_beam_search).  One wave per utterance walks the frames; the prefixes of the
+// beam are nodes of a trie kept in global scratch (parent, token), so "the same string" is "the same (parent node, token)".
+// Per frame and beam entry l = (node, last token e, log pb, log pnb), tot = pb (+) pnb:
+//     slot 0       stay:       pb' = tot + lp(blank);  pnb' = pnb + lp(e) if e is among the frame's k candidates
+//     slot m >= 1  extend c:   pnb' = (c == e ? pb : tot) + lp(c)         (c = m-th candidate, blank skipped)
+// An extension (node_l, c) that spells a prefix already in the beam (entry i with parent node_l and token c) is merged into that
+// entry's stay slot; the beam * (k + 1) <= 64 slots are ranked (ties: lower slot first, as the stable host sort) and the best
+// `beam` form the next beam in rank order; extensions that survive get a new trie node.  Log-probabilities in fp64: rankings
+// must not flip against the fp64 host restatement on near ties.  Results: the n best prefixes, spelled by walking parents.
+namespace {
+
+__device__ __forceinline__ double pb_logadd(double a, double b) {
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const double m = a > b ? a : b;
+    return m + log(exp(a - m) + exp(b - m));
+}
+
+constexpr int PB_MAX_BEAM = 16, PB_MAX_K = 32;
+
+__global__ __launch_bounds__(64) void ctc_prefix_beam_kernel(const float* __restrict__ vals, const int32_t* __restrict__ ids, const float* __restrict__ blank_lp,
+                                                             const int32_t* __restrict__ in_len, int32_t* __restrict__ nodes, int32_t* __restrict__ out_tok,
+                                                             int32_t* __restrict__ out_len, float* __restrict__ out_score, int T, int k, int beam, int nbest,
+                                                             int Lcap, int blank) {
+    __shared__ double s_pb[PB_MAX_BEAM], s_pnb[PB_MAX_BEAM], s_merge[PB_MAX_BEAM], s_sc[64], s_npb[64], s_npnb[64];
+    __shared__ int s_node[PB_MAX_BEAM], s_tok[PB_MAX_BEAM], s_par[PB_MAX_BEAM], s_id[PB_MAX_K], s_nnode[64], s_ntok[64], s_npar[64], s_rank[64];
+    __shared__ float s_lp[PB_MAX_K];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int cap_nodes = T * beam + 1;                  // node 0 = the empty prefix; at most `beam` new nodes per frame
+    int32_t* npar = nodes + (size_t)b * 2 * cap_nodes;   // [parent | token] per node
+    int32_t* ntok = npar + cap_nodes;
+    const int len = min(in_len ? in_len[b] : T, T);
+    if (lane == 0) {
+        npar[0] = -1;
+        ntok[0] = -1;
+        s_node[0] = 0; s_tok[0] = -1; s_par[0] = -1; s_pb[0] = 0.0; s_pnb[0] = -INFINITY;
+    }
+    int nb = 1, next_node = 1;                           // wave-uniform copies
+    __syncthreads();
+    const int per = k + 1;
+    for (int t = 0; t < len; ++t) {
+        const size_t row = (size_t)b * T + t;
+        if (lane < k) { s_id[lane] = ids[row * k + lane]; s_lp[lane] = vals[row * k + lane]; }
+        if (lane < PB_MAX_BEAM) s_merge[lane] = -INFINITY;
+        __syncthreads();
+        const double lb = (double)blank_lp[row];
+        const int j = lane / per, m = lane - j * per;
+        bool valid = j < nb;
+        double pb2 = -INFINITY, pnb2 = -INFINITY;
+        int c = -1, ident_par = -1;
+        if (valid) {
+            const double pb = s_pb[j], pnb = s_pnb[j], tot = pb_logadd(pb, pnb);
+            const int e = s_tok[j];
+            if (m == 0) {                                // stay
+                pb2 = tot + lb;
+                for (int q = 0; q < k; ++q)
+                    if (s_id[q] == e && e != blank) pnb2 = pb_logadd(pnb2, pnb + (double)s_lp[q]);
+                c = e;
+                ident_par = s_par[j];
+            } else {                                     // extend with the (m-1)-th candidate
+                c = s_id[m - 1];
+                if (c == blank) valid = false;
+                else {
+                    pnb2 = (c == e ? pb : tot) + (double)s_lp[m - 1];
+                    ident_par = s_node[j];
+                }
+            }
+        }
+        // an extension that spells a prefix of the current beam goes into that entry's stay slot
+        if (valid && m > 0) {
+            for (int i = 0; i < nb; ++i)
+                if (s_par[i] == ident_par && s_tok[i] == c) {
+                    s_merge[i] = pnb2;                   // at most one extension matches an entry (parent and token are unique)
+                    valid = false;
+                    break;
+                }
+        }
+        __syncthreads();
+        if (valid && m == 0) pnb2 = pb_logadd(pnb2, s_merge[j]);
+        const double sc = valid ? pb_logadd(pb2, pnb2) : -INFINITY;
+        // a slot whose whole probability is zero cannot enter the beam (the host dictionary would hold it with -inf, ranked last)
+        valid = valid && sc > -INFINITY;
+        s_sc[lane] = sc;
+        __syncthreads();
+        int rank = 0;
+        if (valid) {
+            for (int o = 0; o < 64; ++o) {
+                const double so = s_sc[o];
+                if (so > sc || (so == sc && o < lane && so > -INFINITY)) ++rank;
+            }
+        }
+        const bool keep = valid && rank < beam;
+        const unsigned long long keep_mask = __ballot(keep);
+        const unsigned long long ext_mask = __ballot(keep && m > 0);
+        s_rank[lane] = keep ? rank : -1;
+        if (keep) {
+            int node = m == 0 ? s_node[j] : next_node + __popcll(ext_mask & ((1ull << lane) - 1ull));
+            if (m > 0) { npar[node] = ident_par; ntok[node] = c; }
+            s_nnode[rank] = node;
+            s_ntok[rank] = c;
+            s_npar[rank] = ident_par;
+            s_npb[rank] = pb2;
+            s_npnb[rank] = pnb2;
+        }
+        __syncthreads();
+        nb = __popcll(keep_mask);
+        next_node += __popcll(ext_mask);
+        if (lane < nb) {
+            s_node[lane] = s_nnode[lane]; s_tok[lane] = s_ntok[lane]; s_par[lane] = s_npar[lane];
+            s_pb[lane] = s_npb[lane]; s_pnb[lane] = s_npnb[lane];
+        }
+        __syncthreads();
+    }
+    // the beam is in rank order of its total probability: spell the n best
+    if (lane < nbest) {
+        int32_t* dst = out_tok + ((size_t)b * nbest + lane) * Lcap;
+        if (lane < nb) {
+            int n = 0;
+            for (int nd = s_node[lane]; nd > 0; nd = npar[nd]) ++n;
+            out_len[b * nbest + lane] = n;
+            out_score[b * nbest + lane] = (float)pb_logadd(s_pb[lane], s_pnb[lane]);
+            int pos = min(n, Lcap);
+            int skip = n - pos;                          // a prefix longer than the output row keeps its first Lcap tokens
+            for (int nd = s_node[lane]; nd > 0; nd = npar[nd]) {
+                if (skip > 0) { --skip; continue; }
+                dst[--pos] = ntok[nd];
+            }
+        } else {
+            out_len[b * nbest + lane] = -1;              // fewer prefixes than asked for
+            out_score[b * nbest + lane] = -INFINITY;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t asr_ctc_prefix_beam_workspace_bytes(int B, int T, int beam) {
+    if (B <= 0 || T <= 0 || beam <= 0) return 0;
+    return (size_t)B * 2 * ((size_t)T * beam + 1) * sizeof(int32_t);
+}
+
+extern "C" int asr_ctc_prefix_beam(const float* vals, const int32_t* ids, const float* blank_lp, const int32_t* in_len, void* ws, size_t ws_bytes,
+                                   int32_t* out_tok, int32_t* out_len, float* out_score, int B, int T, int k, int beam, int nbest, int Lcap, int blank,
+                                   void* stream) {
+    if (!vals || !ids || !blank_lp || !ws || !out_tok || !out_len || !out_score) ASR_FAIL(ASR_EINVAL, "asr_ctc_prefix_beam: null pointer");
+    if (B <= 0 || T <= 0 || k <= 0 || beam <= 0 || nbest <= 0 || Lcap <= 0) ASR_FAIL(ASR_EINVAL, "asr_ctc_prefix_beam: bad shape B=%d T=%d k=%d beam=%d nbest=%d Lcap=%d", B, T, k, beam, nbest, Lcap);
+    if (beam > PB_MAX_BEAM || k > PB_MAX_K || beam * (k + 1) > 64 || nbest > beam)
+        ASR_FAIL(ASR_EINVAL, "asr_ctc_prefix_beam: one wave ranks the beam * (k + 1) candidates of a frame: beam * (k + 1) <= 64, beam <= %d, nbest <= beam (beam=%d k=%d nbest=%d)", PB_MAX_BEAM, beam, k, nbest);
+    if (ws_bytes < asr_ctc_prefix_beam_workspace_bytes(B, T, beam) || ((uintptr_t)ws % 4)) ASR_FAIL(ASR_EWORKSPACE, "asr_ctc_prefix_beam: workspace of %zu bytes needed (got %zu)", asr_ctc_prefix_beam_workspace_bytes(B, T, beam), ws_bytes);
+    ctc_prefix_beam_kernel<<<B, 64, 0, (hipStream_t)stream>>>(vals, ids, blank_lp, in_len, (int32_t*)ws, out_tok, out_len, out_score, T, k, beam, nbest, Lcap, blank);
+    ASR_CHECK_LAUNCH("asr_ctc_prefix_beam");
+    return ASR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Character error rate on the device (Predictor/Utils/score.py:4-13 with the strings of
 // data_handler/vocab.py:75-79): one wave per utterance.  The two strings are assembled in LDS as code points
 // (ids != pad, token strings joined by one space), then the Levenshtein rows are computed 64 columns at

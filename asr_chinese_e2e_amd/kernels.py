@@ -326,6 +326,23 @@ def ctc_frame_topk(logits, k, blank=0):
     return vals, ids, blank_lp
 
 
+def ctc_prefix_beam(vals, ids, blank_lp, in_len, B, T, beam, nbest, blank=0, max_len=None):
+    """CTC prefix beam search on the device over the per-frame candidates of ctc_frame_topk (include/asr_hip.h).
+    Returns (tokens (B, nbest, Lcap) int32, lengths (B, nbest) int32 with -1 for missing ranks, scores (B, nbest) float32)."""
+    k = vals.shape[1]
+    assert vals.shape == (B * T, k) and ids.shape == (B * T, k) and blank_lp.numel() == B * T
+    _chk_f32(vals, blank_lp)
+    _chk_i32(ids, in_len)
+    Lcap = int(T if max_len is None else max_len)
+    ws = torch.empty(lib.asr_ctc_prefix_beam_workspace_bytes(B, T, beam), dtype=torch.uint8, device=vals.device)
+    out_tok = torch.zeros(B, nbest, Lcap, dtype=torch.int32, device=vals.device)
+    out_len = torch.empty(B, nbest, dtype=torch.int32, device=vals.device)
+    out_score = torch.empty(B, nbest, dtype=torch.float32, device=vals.device)
+    check(lib.asr_ctc_prefix_beam(_p(vals), _p(ids), _p(blank_lp), _p(in_len), _p(ws), ws.numel(), _p(out_tok), _p(out_len), _p(out_score),
+                                  B, T, k, int(beam), int(nbest), Lcap, int(blank), _stream()), "asr_ctc_prefix_beam")
+    return out_tok, out_len, out_score
+
+
 def beam_step(top_vals, top_ids, score, alive, last_tok, parent, rec_tok, rec_par, rec_end, rec_score, maxlen, alive_total, B, beam, step, eos):
     _chk_f32(top_vals, score, rec_score)
     _chk_i32(top_ids, alive, last_tok, parent, rec_tok, rec_par, rec_end, maxlen, alive_total)

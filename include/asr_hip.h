@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 3
+#define ASR_ABI_VERSION 4
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -211,10 +211,21 @@ int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* ou
 /* asr_ctc_frame_topk: per frame (row) of the CTC head's logits, the k largest log_softmax entries (as asr_logsoftmax_topk) and the
  *   log_softmax of the blank class: the per-frame candidates of CTC prefix beam search (the reference has
  *   no CTC and leaves greedy_search / beam_search as empty stubs, transformer_official.py:106-110).  The prefix bookkeeping
- *   (merging paths that spell the same prefix) runs on the host over these k candidates per frame, as the reference's own
- *   search is a host loop. */
+ *   (merging paths that spell the same prefix) runs over these k candidates per frame.
+ * asr_ctc_prefix_beam (ABI 4): that bookkeeping on the device - CTC prefix beam search (Hannun et al. 2014, algorithm 1 without a
+ *   language model) for B utterances, one wave per utterance.  vals / ids: (B*T, k) from asr_ctc_frame_topk, blank_lp: (B*T),
+ *   in_len: (B) frames per utterance (NULL = T).  The beam's prefixes are nodes of a trie in `ws`
+ *   (asr_ctc_prefix_beam_workspace_bytes); beam * (k + 1) <= 64 (one wave ranks a frame's candidates), nbest <= beam.
+ *   Out, per utterance and rank r < nbest, best first: out_tok[(b*nbest + r)*Lcap ..] the prefix (its first Lcap tokens),
+ *   out_len its length (-1: fewer than nbest prefixes have non-zero probability), out_score log p(prefix | x) summed over
+ *   alignments (fp64 inside).  Same results as the host restatement oracle/decode_ref.py::ctc_prefix_beam_search with the same
+ *   per-frame candidates. */
 int asr_ctc_frame_topk(const void* logits, float* vals, int32_t* ids, float* blank_lp, int R, int V, int ld, int k,
                        int blank, int dtype, void* stream);
+size_t asr_ctc_prefix_beam_workspace_bytes(int B, int T, int beam);
+int asr_ctc_prefix_beam(const float* vals, const int32_t* ids, const float* blank_lp, const int32_t* in_len, void* ws, size_t ws_bytes,
+                        int32_t* out_tok, int32_t* out_len, float* out_score, int B, int T, int k, int beam, int nbest, int Lcap,
+                        int blank, void* stream);
 int asr_decode_attn(const void* q, const void* k, const void* v, void* o, const int32_t* k_len,
                     int k_len_uniform, int len_div, int R, int H, int dk, int Tk_cap, int kv_div,
                     int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);

@@ -949,3 +949,36 @@ def test_embed_dropout(K):
     K.embed_bwd(ids.to(DEV).reshape(-1), dy.to(DEV), demb, d ** -0.5, drop_p=p, drop_seed=seed)
     refg = torch.zeros(V, d).index_add_(0, ids.long().reshape(-1), dy * mask * d ** -0.5)
     close(demb, refg, rtol=1e-5, atol=1e-5, what="embed dropout bwd")
+
+
+@pytest.mark.parametrize("B,T,V,k,beam,nbest,peak", [(3, 60, 12, 6, 5, 5, 3.0), (2, 200, 50, 10, 5, 3, 1.0), (4, 37, 9, 8, 7, 7, 0.3), (1, 500, 40, 3, 16, 4, 2.0)])
+def test_ctc_prefix_beam_kernel_matches_host_restatement(K, B, T, V, k, beam, nbest, peak):
+    """asr_ctc_prefix_beam against oracle/decode_ref.ctc_prefix_beam_search (fp64 dictionaries of prefixes) fed with the same
+    per-frame candidates: same n-best prefixes in the same order, scores to 1e-5 relative.  Ragged lengths, peaky and flat
+    posteriors (flat ones keep many near-equal prefixes alive: the merge of an extension into an existing beam entry and the
+    repeated-symbol rule are exercised on every frame), beam up to the kernel's maximum."""
+    from oracle import decode_ref as D
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    logits = torch.randn(B, T, V, generator=g) * peak
+    lens = torch.randint(max(1, T // 2), T + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = T
+    vals, ids, blank_lp = K.ctc_frame_topk(logits.reshape(B * T, V).to(DEV), k, 0)
+    tok, ln, sc = K.ctc_prefix_beam(vals, ids, blank_lp, lens.to(DEV), B, T, beam, nbest, 0)
+    tok, ln, sc = tok.cpu(), ln.cpu(), sc.cpu()
+    logp = torch.log_softmax(logits.double(), -1).numpy()
+    ids_h = ids.view(B, T, k).cpu().numpy()
+    for b in range(B):
+        Tb = int(lens[b])
+        want = D.ctc_prefix_beam_search(logp[b, :Tb], beam, candidates=[list(ids_h[b, t]) for t in range(Tb)])[:nbest]
+        want = [(p, s_) for p, s_ in want if s_ > -1e300]
+        got = [(tuple(tok[b, r, : int(ln[b, r])].tolist()), float(sc[b, r])) for r in range(nbest) if int(ln[b, r]) >= 0]
+        assert [p for p, _ in got] == [p for p, _ in want], (b, got, want)
+        for (_, a), (_, w) in zip(got, want):
+            assert abs(a - w) < 1e-5 * max(1.0, abs(w)), (a, w)
+
+
+def test_ctc_prefix_beam_refuses_what_one_wave_cannot_rank(K):
+    from asr_chinese_e2e_amd._lib import AsrHipError
+    vals = torch.zeros(4, 10, device=DEV); ids = torch.zeros(4, 10, dtype=torch.int32, device=DEV); bl = torch.zeros(4, device=DEV)
+    with pytest.raises(AsrHipError):
+        K.ctc_prefix_beam(vals, ids, bl, None, 1, 4, 8, 1, 0)      # 8 * 11 > 64

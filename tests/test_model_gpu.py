@@ -595,15 +595,17 @@ def _decode_case(dtype="fp32"):
     return model, to_pack(batch), batch
 
 
+@pytest.mark.parametrize("on_device", [True, False])
 @pytest.mark.parametrize("frame_topk", [14, 4])
-def test_ctc_prefix_beam_search_matches_oracle(frame_topk):
-    """model.ctc_prefix_beam_search (GPU: encoder, CTC head, per-frame top-k log-softmax + blank; host: prefix merging) against
+def test_ctc_prefix_beam_search_matches_oracle(frame_topk, on_device):
+    """model.ctc_prefix_beam_search (GPU: encoder, CTC head, per-frame top-k log-softmax + blank, and - on_device - the prefix
+    bookkeeping kernel asr_ctc_prefix_beam; otherwise the host loop over the same candidates) against
     oracle/decode_ref.ctc_prefix_beam_search fed with the same posteriors - with every class as a candidate and with the
     same per-frame pruning.  The oracle itself is pinned by brute-force enumeration (tests/test_oracle_ctc.py); nothing in the
     reference covers CTC decoding (parity unpinned by the reference)."""
     from oracle import decode_ref as D
     model, pack, batch = _decode_case()
-    got = model.ctc_prefix_beam_search(pack, beam_size=4, nbest=3, frame_topk=frame_topk)
+    got = model.ctc_prefix_beam_search(pack, beam_size=4, nbest=3, frame_topk=frame_topk, on_device=on_device)
     with torch.no_grad():
         logits = model.forward(pack).ctc_logits.double().cpu()
     logp = torch.log_softmax(logits, -1).numpy()
