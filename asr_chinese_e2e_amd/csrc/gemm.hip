@@ -319,6 +319,7 @@ static void launch_nt_dma(const bf16_t* a, const bf16_t* w, const float* bias, b
 //   * orders each XCD's tiles so that the 32 CUs of an XCD work on consecutive tiles (shared A
 //     row-panels and W served by that XCD's L2).
 constexpr int PBM = 256, PBN = 128, PBK = 64, PRING = 3;
+constexpr int NT_ACT_ADD_RES = 3;      // kernel-internal: ASR_ACT_NONE with a residual operand (C = A W^T + bias + res; res may be C itself)
 constexpr int PSTAGE = (PBM + PBN) * 128;          // 49152 B
 constexpr int PLDS = PRING * PSTAGE;               // 147456 B
 template <int NW> struct PCfg {                    // NW waves as (NW/2) x 2; wave tile (32*MI) x 64
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
             }
             __builtin_amdgcn_s_barrier();   // every wave's part of item i landed; nobody still reads the slot refilled during this step
             if (DBG == 5 && tid == 0 && i < 12) stamps[1 + i] = __builtin_amdgcn_s_memrealtime();
-            if (ACT == ASR_ACT_RELU_MASK && c_k == nk - 1) load_masks();
+            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && c_k == nk - 1) load_masks();
             k_step(issued < total);
         }
         // ---- store tail of tile c_tile: activation in registers, transpose through wave-private LDS
@@ -512,6 +513,17 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
             for (int q = 0; q < 4 * RM; ++q) {
                 const int row = q * 8 + srow, ch = lane & 7;
                 v[q] = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+            if (ACT == NT_ACT_ADD_RES) {      // C = A W^T + bias + res: the residual tile was fetched under the last k-step like the ReLU mask
+#pragma unroll
+                for (int q = 0; q < 4 * RM; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t a = v[q][e], r2 = hm[round][q][e];
+                        const bf16_t lo = (bf16_t)(__uint_as_float(a << 16) + __uint_as_float(r2 << 16));
+                        const bf16_t hi = (bf16_t)(__uint_as_float(a & 0xffff0000u) + __uint_as_float(r2 & 0xffff0000u));
+                        v[q][e] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+                    }
             }
             if (ACT == ASR_ACT_RELU_MASK) {
 #pragma unroll
@@ -1539,6 +1551,12 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         if (!res || (uintptr_t)res % 16 || K % DBK || K < 2 * PBK || N % 8 || ldc % 8 || ((uintptr_t)C % 16))
             ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: ASR_ACT_RELU_MASK needs the mask in `res`, K %% 64 == 0, K >= 128, N, ldc %% 8 == 0 and 16-byte aligned pointers");
         launch_nt_persist<ASR_ACT_RELU_MASK, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+        ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
+        return ASR_OK;
+    }
+    if (res && act == ASR_ACT_NONE && K % DBK == 0 && K >= 2 * PBK && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)res % 16) == 0) {
+        // residual add in the persistent kernel's store tail (res = C accumulates in place: every element is read and written by one lane)
+        launch_nt_persist<NT_ACT_ADD_RES, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }

@@ -169,6 +169,9 @@ class Linear:
             # few rows (decoder): dX = dY W straight from the weight as stored, on the 64 x 64-tile kernel (no library call, no transposed copy)
             out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
             return K.gemm_small(dy, self.wlp, None, out, trans_b=True, act=ACT_RELU_MASK if relu_mask is not None else ACT_NONE, mask=relu_mask)
+        if accumulate and out is not None and relu_mask is None and self.own_dgrad(dy) and out.dtype == torch.bfloat16 and out.stride(0) % 8 == 0 \
+                and out.data_ptr() % 16 == 0:
+            return K.gemm_nt(dy, self.wlpT, None, out, res=out)      # out += dY W: residual add in the store tail, in place
         if self.own_dgrad(dy, accumulate):
             # dX = dY W as an NT product with the transposed weight copy: own MFMA kernel instead of the library GEMM
             out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
@@ -316,12 +319,18 @@ class Engine:
             # encoder projections only: the decoder's B*To ~ 500 rows are better served by the library's small tiles
             # (joint config 5.93 ms with its projections on the persistent kernel too, 5.74 with the library)
             lins = [l for mha, ffn in self.enc for l in (mha.qkv, mha.fc, ffn.w1, ffn.w2)]
-            lins = [l for l in lins if l.N % 64 == 0 and l.K % 8 == 0]
+            # ... and the decoder's cross-attention Q|K|V weights: their K|V half multiplies all B*T encoder frames in the
+            # accumulating input gradient d_enc += dK|dV W_kv (the residual-add store tail of the own kernel, no library call)
+            cross_qkv = [cross.qkv for _, cross, _ in self.dec] if getattr(self, "dec", None) else []
+            lins = [l for l in lins + cross_qkv if l.N % 64 == 0 and l.K % 8 == 0]
             flat.lpT = torch.zeros_like(flat.lp)
             tiles = []
             for l in lins:
                 l.wlpT = flat.lpT[l.w_off:l.w_off + l.N * l.K].view(l.K, l.N)
                 tiles += [[l.w_off, l.N, l.K, (r << 16) | c] for r in range((l.N + 63) // 64) for c in range((l.K + 63) // 64)]
+            for _, cross, _ in (self.dec if getattr(self, "dec", None) else []):
+                if cross.qkv.wlpT is not None:
+                    cross.kv.wlpT = cross.qkv.wlpT[:, cross.H * cross.dk:]      # (d, 2 H dk) view, row stride 3 H dk
             self._tr_tiles = torch.tensor(tiles, dtype=torch.int32, device=flat.device)
             self._tr_event = torch.cuda.Event()
             self._tr_pending = False

@@ -592,24 +592,31 @@ def gemm_tn(dy, x, dw, accumulate=True, dbias=None, ws=None):
     return dw
 
 
+_TN_SIZE = ctypes.sizeof(TnProblem)
+_TN_BUF = (ctypes.c_char * (_TN_SIZE * TN_GROUP_MAX))()
+_TN_ADDR = ctypes.addressof(_TN_BUF)
+_TN_PACK = __import__("struct").Struct("<QQQQiiiiii").pack_into
+assert _TN_SIZE == 56      # asr_tn_problem: four pointers, six ints
+
+
 def gemm_tn_grouped(problems, accumulate=True):
     """problems: list of (dy (M,N) bf16, x (M,K) bf16, dw (N,K) f32, dbias (N) f32 or None);
     dw_p (+)= dy_p^T @ x_p and dbias_p += column sums of dy_p for all of them, TN_GROUP_MAX per launch."""
     for i in range(0, len(problems), TN_GROUP_MAX):
         chunk = problems[i:i + TN_GROUP_MAX]
-        arr = (TnProblem * len(chunk))()
         flops = 0.0
-        for q, (dy, x, dw, dbias) in zip(arr, chunk):
+        for j, (dy, x, dw, dbias) in enumerate(chunk):
             assert dy.dtype == x.dtype == torch.bfloat16 and dw.dtype == torch.float32
             M, N = dy.shape
             Kd = x.shape[1]
             assert x.shape[0] == M and dw.shape == (N, Kd) and dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
             _chk_f32(dbias)
             assert dbias is None or dbias.numel() == N
-            q.dY, q.X, q.dW, q.dbias = _p(dy), _p(x), _p(dw), _p(dbias)
-            q.M, q.N, q.K, q.ldy, q.ldx, q.ldw = M, N, Kd, dy.stride(0), x.stride(0), dw.stride(0)
+            # one pack per problem into a reused host buffer (the launch copies the descriptors into kernel arguments before it
+            # returns): field-by-field ctypes stores cost ~25 us per decoder layer, in the host-bound part of the joint step
+            _TN_PACK(_TN_BUF, j * _TN_SIZE, _p(dy), _p(x), _p(dw), _p(dbias) or 0, M, N, Kd, dy.stride(0), x.stride(0), dw.stride(0))
             flops += 2.0 * M * N * Kd
-        timed("gemm_tn", flops, lambda: check(lib.asr_gemm_tn_grouped_bf16(ctypes.addressof(arr), len(chunk), int(accumulate), _stream()),
+        timed("gemm_tn", flops, lambda: check(lib.asr_gemm_tn_grouped_bf16(_TN_ADDR, len(chunk), int(accumulate), _stream()),
                                               "asr_gemm_tn_grouped_bf16"))
 
 

@@ -982,3 +982,27 @@ def test_ctc_prefix_beam_refuses_what_one_wave_cannot_rank(K):
     vals = torch.zeros(4, 10, device=DEV); ids = torch.zeros(4, 10, dtype=torch.int32, device=DEV); bl = torch.zeros(4, device=DEV)
     with pytest.raises(AsrHipError):
         K.ctc_prefix_beam(vals, ids, bl, None, 1, 4, 8, 1, 0)      # 8 * 11 > 64
+
+
+@pytest.mark.parametrize("M,N,Kd,ldb_extra,inplace", [(1000, 512, 1024, 512, True), (700, 384, 128, 0, False), (16000, 512, 1024, 512, True)])
+def test_gemm_nt_residual_add_store_tail(K, M, N, Kd, ldb_extra, inplace):
+    """asr_gemm_nt_bf16 with a residual operand on the persistent kernel: C = A W^T + bias + res in the store tail, also in place
+    (res = C: the accumulating cross-attention K|V input gradient d_enc += dKV W_kv, where W is a column slice of a wider
+    transposed weight copy - row stride > K)."""
+    torch.manual_seed(M + N)
+    a = torch.randn(M, Kd).bfloat16()
+    wfull = (torch.randn(N, Kd + ldb_extra) * 0.05).bfloat16()
+    w = wfull[:, ldb_extra:]                       # (N, Kd) view, row stride Kd + ldb_extra
+    bias = None if inplace else torch.randn(N)
+    res = torch.randn(M, N).bfloat16()
+    prod = a.double() @ w.double().t() + (0 if bias is None else bias.double())
+    want = prod + res.double()
+    ad, wd, rd = a.to(DEV), wfull.to(DEV)[:, ldb_extra:], res.to(DEV)
+    out = rd.clone() if inplace else torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(ad, wd, None if bias is None else bias.to(DEV), out, res=out if inplace else rd)
+    got = out.double().cpu()
+    # two bf16 roundings: the product (+ bias) when it crosses the LDS transpose of the store tail, then the sum - each within half an
+    # ulp (2^-9 relative) of its own magnitude, so the bound is elementwise in |product| and |sum| (they differ where res cancels)
+    err = (got - want).abs()
+    tol = 2.0 ** -8 * (prod.abs() + want.abs()) + 1e-3
+    assert bool((err <= tol).all()), f"{int((err > tol).sum())}/{err.numel()} off, max err {float(err.max()):.3e}"
