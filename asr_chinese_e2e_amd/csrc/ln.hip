@@ -35,8 +35,17 @@ template <typename T, int N, bool VEC8> struct RowSlice {
     }
     // v[i] = keep(row, col) ? v[i] * scale : 0   (dropout mask regenerated from the counter hash)
     static __device__ __forceinline__ void dropout(float (&v)[N], uint32_t row_base, int lane, uint32_t seed, uint32_t thr, float scale) {
+        if constexpr (VEC8) {      // a lane's values are runs of 8 consecutive columns: one hash per element PAIR (row_base and the run start are even)
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = drop_keep_at(row_base + (uint32_t)col(i, lane), seed, thr) ? v[i] * scale : 0.f;
+            for (int i = 0; i < N; i += 2) {
+                const uint32_t h = drop_hash((row_base + (uint32_t)col(i, lane)) >> 1, seed);
+                v[i] = drop_keep(h, 0, thr) ? v[i] * scale : 0.f;
+                v[i + 1] = drop_keep(h, 1, thr) ? v[i + 1] * scale : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = drop_keep_at(row_base + (uint32_t)col(i, lane), seed, thr) ? v[i] * scale : 0.f;
+        }
     }
     static __device__ __forceinline__ void loadf(const float* p, int d, int lane, float (&v)[N]) {
         RowSlice<float, N, VEC8>::load(p, d, lane, v);

@@ -949,13 +949,28 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
             for (int g4 = 0; g4 < 4; ++g4) {
                 f32x4_t d4 = {0.f, 0.f, 0.f, 0.f};
                 if (DROP) d4 = *(const f32x4_t*)(s_d + 8 * g4 + 4 * hh);
+                // dropout mask: one hash serves the element PAIR (key 2m, key 2m + 1) of a query, and the two keys of a pair sit in
+                // neighbouring lanes here - each lane hashes for one of two consecutive queries and takes the other from its
+                // neighbour (8 hashes + 8 lane swaps per 16 elements instead of 16 hashes: 3 integer multiplies each)
+                uint32_t hsh[4] = {0u, 0u, 0u, 0u};
+                if (DROP) {
+                    const uint32_t kcl = (uint32_t)min(kj, Tk - 1), tkp = (uint32_t)((Tk + 1) & ~1), bhq = ((uint32_t)(b * H + h)) * Tq;
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int em = e + (lane & 1);
+                        const uint32_t el_m = (bhq + min(qt0 + 8 * g4 + 4 * hh + em, Tq - 1)) * tkp + kcl;
+                        const uint32_t h_m = drop_hash(el_m >> 1, dseed);
+                        const uint32_t h_o = (uint32_t)__shfl_xor((int)h_m, 1, 64);      // the neighbour hashed the other query of the two for this key pair
+                        hsh[e] = (lane & 1) ? h_o : h_m;
+                        hsh[e + 1] = (lane & 1) ? h_m : h_o;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g4 + e;
                     const float p = __builtin_amdgcn_exp2f(st[i]);
                     if (DROP) {
-                        const uint32_t el = (((uint32_t)(b * H + h)) * Tq + min(qt0 + 8 * g4 + 4 * hh + e, Tq - 1)) * ((Tk + 1) & ~1) + min(kj, Tk - 1);
-                        const float keepf = drop_keep_at(el, dseed, dthr) ? dscale : 0.f;
+                        const float keepf = drop_keep(hsh[e], min(kj, Tk - 1) & 1, dthr) ? dscale : 0.f;
                         dp[i] = p * (dp[i] * keepf + d4[e]);     // dS / scale (d4 = -delta)
                         st[i] = p * keepf;                       // dropped probabilities feed dV
                     } else {
