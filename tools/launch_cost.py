@@ -16,6 +16,9 @@ def t(fn, n=2000):
 print("gemm_small wrapper      %.2f us" % t(lambda: K.gemm_small(x, w, b, out)))
 args = (K._p(x), K._p(w), K._p(b), None, K._p(out), 64, 512, 512, 512, 512, 512, 0, 0)
 print("bare ctypes call         %.2f us" % t(lambda: lib.asr_gemm_small_bf16(*args, K._stream())))
+fast = _lib.fast
+print("fastcall, fixed stream   %.2f us" % t(lambda: fast.asr_gemm_small_bf16(*args, K._stream())))
+print("fastcall asr_abi_version %.2f us (no launch: the trampoline alone)" % t(lambda: fast.asr_abi_version()))
 st = K._stream()
 print("bare ctypes, fixed strm  %.2f us" % t(lambda: lib.asr_gemm_small_bf16(*args, st)))
 print("_stream()                %.2f us" % t(lambda: K._stream()))
