@@ -725,6 +725,10 @@ def _tn_problem(M, N, K_, with_bias, seed, strided=False):
 def test_gemm_tn_grouped(K, shapes):
     """All weight gradients of a layer in one launch == the fp32 GEMM of each, bias gradients included."""
     probs = [_tn_problem(M, N, K_, wb, 31 * i + M, strided=(i % 2 == 1)) for i, (M, N, K_, wb) in enumerate(shapes)]
+    if K.deterministic():      # ASR_DETERMINISTIC=1 for the whole run: the grouped kernel (fp32 atomics only) must refuse
+        with pytest.raises(RuntimeError):
+            K.gemm_tn_grouped(probs, accumulate=True)
+        return
     for rep in range(2):                            # second launch accumulates on top of the first
         K.gemm_tn_grouped(probs, accumulate=True)
     for (M, N, K_, wb), (dy, x, dw, db) in zip(shapes, probs):
