@@ -657,3 +657,50 @@ def test_joint_ctc_attention_rescoring_matches_oracle():
     assert reordered >= 0
     with pytest.raises(RuntimeError):
         build(R.default_cfg(n_mels=16, lfr_m=1, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=1), 14, "TransformerOffical", dtype="fp32").cuda().beam_search(pack, 2, 1, 4, ctc_weight=0.3)
+
+
+@pytest.mark.parametrize("which", ["edge_batch", "single_utterance"])
+def test_edge_batches_match_oracle(which):
+    """Edge cases of the batch contract (empty and ragged inputs): an EMPTY transcript (tgt_len = 0: the decoder sees
+    only <sos> -> <eos>, CTC scores the all-blank path), a transcript of three equal tokens on exactly the 5 frames CTC needs
+    for it (L + repeats: one feasible alignment family), a 5-frame utterance beside a 12-frame one, and a batch of ONE
+    utterance.  fp32 mode against the oracle: joint loss and both terms to 1e-4, every gradient."""
+    over = dict(d_model=32, hidden_size=8, num_head=4, ff_size=64, layer_num=2, ctc_weight=0.3)
+    B = 3 if which == "edge_batch" else 1
+    cfg, sd, batch = oracle_case(B, 12, 16, 40, 6, over, seed=21)
+    tgt = torch.zeros(B, 6, dtype=batch["tgt_for_input"].dtype)
+    if which == "edge_batch":
+        batch["wave_len"] = torch.tensor([12, 5, 5], dtype=batch["wave_len"].dtype)
+        batch["wave"][1, 5:] = 0
+        batch["wave"][2, 5:] = 0
+        tgt[0, :4] = torch.tensor([9, 4, 4, 17])
+        tgt[2, :3] = torch.tensor([7, 7, 7])
+        batch["tgt_len"] = torch.tensor([4, 0, 3], dtype=batch["tgt_len"].dtype)
+    else:
+        batch["wave_len"] = torch.tensor([12], dtype=batch["wave_len"].dtype)
+        tgt[0, :2] = torch.tensor([5, 5])
+        batch["tgt_len"] = torch.tensor([2], dtype=batch["tgt_len"].dtype)
+    batch["tgt_for_input"] = tgt
+    tr = R.RefTrainer(sd, cfg, warmup=25)
+    ref = tr.iterate(batch)
+    assert np.isfinite(float(ref["loss"]))
+    model = build(cfg, 40, "TransformerOffical", dtype="fp32").cuda()
+    model.load_state_dict({k: v for k, v in sd.items()})
+    pack = to_pack(batch)
+    model._ensure_engine(DEV)
+    model.zero_flat_grads()
+    loss, _ = model.train_step(pack)
+    assert abs(float(loss[0]) - float(ref["loss"])) < 1e-4 * abs(float(ref["loss"]))
+    assert abs(float(loss[2]) - float(ref["out"]["ctc"])) < 1e-4 * abs(float(ref["out"]["ctc"]))
+    assert abs(float(loss[1]) - float(ref["out"]["ce"])) < 1e-4 * abs(float(ref["out"]["ce"]))
+    gmax = max(float(g.abs().max()) for g in ref["grads"].values())
+    for n, p in model.named_parameters():
+        assert np.allclose(p.grad.cpu().numpy(), ref["grads"][n].numpy(), rtol=3e-4, atol=3e-6 * max(gmax, 1.0)), n
+    # the bf16 path on the same batch: finite, and the padded encoder rows stay exactly zero
+    m16 = build(cfg, 40, "TransformerOffical", dtype="bf16").cuda()
+    m16.load_state_dict({k: v for k, v in sd.items()})
+    m16._ensure_engine(DEV)
+    m16.zero_flat_grads()
+    l16, _ = m16.train_step(pack)
+    assert all(np.isfinite(l16.cpu().numpy()))
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m16.parameters())
