@@ -704,3 +704,27 @@ def test_edge_batches_match_oracle(which):
     l16, _ = m16.train_step(pack)
     assert all(np.isfinite(l16.cpu().numpy()))
     assert all(bool(torch.isfinite(p.grad).all()) for p in m16.parameters())
+
+
+@pytest.mark.parametrize("T", [70, 600])
+def test_beam_search_cross_attention_kernels_agree(T, monkeypatch):
+    """The beam search's cross attention on the training attention kernel (all beams of an utterance as Tq = beam queries; the LDS-
+    resident kernel at T <= 512, the tiled one beyond) gives the hypotheses of the single-query decode kernel (ASR_DECODE_SDPA=0):
+    same token sequences; scores within bf16 noise (the two kernels round differently)."""
+    over = dict(d_model=64, hidden_size=64, num_head=2, ff_size=128, layer_num=2)
+    cfg, sd, batch = oracle_case(3, T, 16, 24, 5, over, seed=13)
+    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 3.0
+    if "decoder.tgt_word_prj.weight" in sd:
+        sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    model = build(cfg, 24, dtype="bf16").cuda()
+    model.load_state_dict({k: v for k, v in sd.items()})
+    model.eval()
+    pack = to_pack(batch)
+    monkeypatch.setenv("ASR_DECODE_SDPA", "1")
+    a = model.beam_search(pack, 4, 2, 10)
+    monkeypatch.setenv("ASR_DECODE_SDPA", "0")
+    b = model.beam_search(pack, 4, 2, 10)
+    for ha, hb in zip(a, b):
+        assert len(ha) == len(hb)
+        assert abs(ha[0]["score"] - hb[0]["score"]) < 0.1 * max(1.0, abs(hb[0]["score"]))
+        assert ha[0]["yseq"] == hb[0]["yseq"] or abs(ha[0]["score"] - hb[0]["score"]) < 0.05       # a near tie may swap ranks
