@@ -15,11 +15,12 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p
 import torch  # noqa: F401  (side effect: loads libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasr_hip.so")
+# ASR_HIP_LIB: another build of the SAME library (the diagnostic twin `make debug` produces); never a different implementation
+LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -44,6 +45,7 @@ SIGNATURES = {
     "asr_abi_version": (I, []),
     "asr_last_error": (I, [c_char_p, Z]),
     "asr_stream_fork": (I, [P, P]),
+    "asr_stream_create": (I, [I, P]),
     "asr_get_deterministic": (I, []),
     "asr_set_deterministic": (I, [I]),
     "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, U, I, I, P]),
@@ -124,8 +126,18 @@ def _bind_fast():
     (~0.3 us against ~6.4 us of host time per launch; the joint step issues ~600).  Same addresses, same argument
     meaning; pointers, stream handles and sizes are passed as plain Python ints (None = NULL)."""
     try:
-        from . import _asr_fastcall
-    except ImportError as e:
+        alt = os.environ.get("ASR_FASTCALL_DIR")      # another build of the same trampolines (the AddressSanitizer twin: `make asan`)
+        if alt:
+            import glob
+            import importlib.machinery
+            import importlib.util
+            path = glob.glob(os.path.join(alt, "_asr_fastcall*.so"))[0]
+            loader = importlib.machinery.ExtensionFileLoader("_asr_fastcall", path)
+            _asr_fastcall = importlib.util.module_from_spec(importlib.util.spec_from_loader("_asr_fastcall", loader))
+            loader.exec_module(_asr_fastcall)
+        else:
+            from . import _asr_fastcall
+    except (ImportError, IndexError) as e:
         raise ImportError(f"asr_chinese_e2e_amd/_asr_fastcall*.so not found or not loadable ({e}): build it with "
                           "`make -C asr_chinese_e2e_amd/csrc` (it is part of the required native code; there is no slow path)") from e
     kind = {P: "P", I: "I", F: "F", Z: "Z", U: "U", c_char_p: "P"}

@@ -20,6 +20,19 @@
 
 namespace {
 
+// Switches that produce WRONG results (timing experiments: kernels with their atomics, DMA or MFMAs removed) exist only in
+// builds made with `make DEBUG_SWITCHES=1` (-DASR_DEBUG_SWITCHES); the shipped library ignores the variables, so a stray
+// environment variable cannot silently corrupt gradients.
+static int unsafe_debug_env(const char* name) {
+#ifdef ASR_DEBUG_SWITCHES
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
+
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int AS = 72;  // LDS row stride (elements) of the NT tiles
@@ -1561,7 +1574,7 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         return ASR_OK;
     }
     if (K % DBK == 0 && !res && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {   // LDS-DMA kernel: whole 64-wide k-tiles, 16-B row stores
-        static const int dbg = getenv("ASR_GEMM_DBG") ? atoi(getenv("ASR_GEMM_DBG")) : 0;
+        static const int dbg = unsafe_debug_env("ASR_GEMM_DBG");      // timing experiments (wrong results): debug builds only
         static const int cfg = getenv("ASR_GEMM_CFG") ? atoi(getenv("ASR_GEMM_CFG")) : 0;   // tuning experiments
         const bf16_t *a = (const bf16_t*)A, *wp = (const bf16_t*)W;
         bf16_t* c = (bf16_t*)C;
@@ -1699,7 +1712,7 @@ extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, 
         for (int i = 0; i < nprob; ++i) blocks += g.p[i].tiles * ceil_div(g.p[i].M, R);
         if (blocks <= cus || R >= max_m) break;
     }
-    static const int tn_noatomic = getenv("ASR_GEMM_TN_NOATOMIC") ? atoi(getenv("ASR_GEMM_TN_NOATOMIC")) : 0;   // timing experiments only (wrong results)
+    static const int tn_noatomic = unsafe_debug_env("ASR_GEMM_TN_NOATOMIC");   // timing experiments only (wrong results): debug builds only
     int begin = 0;
     for (int i = 0; i < nprob; ++i) {
         TnProb& t = g.p[i];
@@ -1719,7 +1732,7 @@ extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, 
     // stage rows x ring: 64 x 3 = 144 KiB is the fastest alone (0.67 PFLOP/s on a config-2 layer), but this GEMM runs
     // beside the main stream, whose attention / LayerNorm workgroups need the rest of the CU's LDS
     static const int cfg = getenv("ASR_GEMM_TNG_CFG") ? atoi(getenv("ASR_GEMM_TNG_CFG")) : 324;
-    static const int dbg = getenv("ASR_GEMM_TNG_DBG") ? atoi(getenv("ASR_GEMM_TNG_DBG")) : 0;
+    static const int dbg = unsafe_debug_env("ASR_GEMM_TNG_DBG");
 #define TNG_LAUNCH(ROWS_, RING_, DBG_)                                                                                                   \
     do {                                                                                                                                   \
         static bool attr = false;                                                                                                          \
@@ -1801,7 +1814,7 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
     if (((uintptr_t)dY | (uintptr_t)X) % 16) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     const int tiles_n = ceil_div(N, 128), tiles_k = ceil_div(K, 128), tiles = tiles_n * tiles_k;
-    static const int tn_noatomic = getenv("ASR_GEMM_TN_NOATOMIC") ? atoi(getenv("ASR_GEMM_TN_NOATOMIC")) : 0;   // timing experiments only (wrong results)
+    static const int tn_noatomic = unsafe_debug_env("ASR_GEMM_TN_NOATOMIC");   // timing experiments only (wrong results): debug builds only
     const TnPlan pl = tn_plan(M, N, K);
     const int tn_cfg = pl.tn_cfg, ring = pl.ring, rows_per_split = pl.rows_per_split, nsplit = pl.nsplit;
     const bool eight = pl.eight;

@@ -63,6 +63,21 @@ extern "C" int asr_stream_fork(void* from_stream, void* to_stream) {
     return ASR_OK;
 }
 
+// A stream of the HIP runtime this library is linked against (the one torch loaded first), at the lowest (priority < 0),
+// default (0) or highest (> 0) priority the device offers.
+extern "C" int asr_stream_create(int priority, void** out_stream) {
+    if (!out_stream) ASR_FAIL(ASR_EINVAL, "asr_stream_create: null output");
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);      // numerically: least >= greatest
+    if (e != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_create: %s", hipGetErrorString(e));
+    const int prio = priority < 0 ? least : priority > 0 ? greatest : 0;
+    hipStream_t st = nullptr;
+    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio);
+    if (e != hipSuccess || !st) ASR_FAIL(ASR_EHIP, "asr_stream_create: %s", hipGetErrorString(e));
+    *out_stream = (void*)st;
+    return ASR_OK;
+}
+
 namespace {
 
 constexpr int EW_BLOCK = 256;

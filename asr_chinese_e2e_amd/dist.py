@@ -20,7 +20,11 @@ MI355X-first design:
     it, and ranks may hold different local batch sizes (both kernels take their divisor from device memory);
   * the wire format of the buckets is bf16 for bf16 models (67.6 MB per step at 33.8 M parameters instead of
     135 MB; xGMI rings are per-link bound): cast on the communication stream, summed by RCCL, cast back into the
-    fp32 gradient buffer; fp32 models (parity mode) and ASR_DP_WIRE=fp32 keep fp32 on the wire;
+    fp32 gradient buffer; fp32 models (parity mode) and ASR_DP_WIRE=fp32 keep fp32 on the wire.  The bf16 wire ROUNDS:
+    each rank's gradient is rounded to 8 significant bits before the sum and the ring adds in bf16, so an element of the
+    reduced gradient differs from the fp32 sum by up to ~2^-8 * (number of ranks) of the largest addend (bound checked
+    by tests/test_train_loop_gpu.py::test_data_parallel_bf16_wire_two_ranks); with fp32 on the wire the summed
+    gradients equal a single-process run on the concatenated batch up to summation order;
   * the clip norm is computed on the reduced gradients, identical on every rank.
 """
 import os
@@ -41,9 +45,20 @@ def init(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29512")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:      # a default would collide with whatever else runs on the box; the launcher (torchrun, bench.py) sets it
+            raise RuntimeError("MASTER_PORT is not set: start the ranks through torch.distributed.run / bench.py --gpus N, or export it")
+        os.environ["MASTER_PORT"] = str(free_port())
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
+
+
+def free_port():
+    """A TCP port that was free a moment ago (bound to port 0, then released) - for single-node rendezvous."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def make_buckets(block_ranges, numel, bucket_elems, force_cuts=()):
@@ -84,6 +99,14 @@ class GradBucketer:
             self.wire = torch.empty(flat_g.numel(), dtype=wire_dtype, device=flat_g.device)
         self.next = 0
         self.works = []
+        # events are pooled and reused round-robin (a wait captures the record it follows), as the engine does: a fresh
+        # torch.cuda.Event per bucket and producer stream cost a hipEventCreate/Destroy pair each, every step
+        self._events = [torch.cuda.Event() for _ in range(64)] if self.cuda else []
+        self._ev_next = 0
+        # communication-exposure probe (bench.py, N > 1): timing events around the compute stream's final wait for the
+        # communication stream = the part of the all-reduce that backward did not cover
+        self.measure_exposed = False
+        self._exposed = []
         self.bytes_on_wire = sum((e - s) for s, e in self.buckets) * (self.wire.element_size() if self.wire is not None else flat_g.element_size())
 
     def begin(self):
@@ -97,7 +120,7 @@ class GradBucketer:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         for st in (streams or [torch.cuda.current_stream()]):   # producers of these gradients
-            ev = torch.cuda.Event()
+            ev = self._event()
             ev.record(st)
             self.comm_stream.wait_event(ev)
         with torch.cuda.stream(self.comm_stream):
@@ -111,6 +134,11 @@ class GradBucketer:
                 K.cast(view, w)
                 dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
                 K.cast(w, view)
+
+    def _event(self):
+        ev = self._events[self._ev_next]
+        self._ev_next = (self._ev_next + 1) & 63
+        return ev
 
     def ready(self, offset, streams=None):
         """Gradients at flat offsets >= offset are final (after the work already queued on
@@ -126,7 +154,25 @@ class GradBucketer:
             w.wait()
         self.works = []
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream()
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)                      # runs when backward's own work on the compute stream is done
+                cur.wait_stream(self.comm_stream)
+                e1.record(cur)                      # runs when the last bucket has arrived
+                self._exposed.append((e0, e1))
+            else:
+                cur.wait_stream(self.comm_stream)
+
+    def exposed_ms(self, reset=True):
+        """Mean time per step the compute stream spent waiting for the communication stream after backward had finished
+        (measure_exposed = True; call after a device synchronisation)."""
+        if not self._exposed:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+        if reset:
+            self._exposed = []
+        return ms
 
 
 class _Counts:
@@ -142,12 +188,12 @@ class _Counts:
         cur = torch.cuda.current_stream()
         self.buf[0:1].copy_(n_valid)
         self.buf[1].fill_(float(B))
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        self.comm.wait_event(ev)
+        if self.event is None:      # two events, reused every step (a wait captures the record it follows)
+            self._fork_ev, self.event = torch.cuda.Event(), torch.cuda.Event()
+        self._fork_ev.record(cur)
+        self.comm.wait_event(self._fork_ev)
         with torch.cuda.stream(self.comm):
             dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
-            self.event = torch.cuda.Event()
             self.event.record(self.comm)
         return self
 

@@ -267,18 +267,17 @@ def _side_stream(device):
     """The weight-gradient stream.  ASR_SIDE_PRIORITY=low (default) creates it at the LOWEST HIP stream priority: its
     GEMMs are off the critical path, and at equal priority they take CUs from the dgrad / attention / LayerNorm chain
     whenever both have workgroups pending (the LayerNorm backward ran 30 us beside them against 14 us alone).
-    torch.cuda.Stream only offers normal / high, so the stream comes from the HIP runtime torch has loaded and is
-    wrapped as an ExternalStream (host plumbing; it lives as long as the process)."""
+    torch.cuda.Stream only offers normal / high, so the stream comes from asr_stream_create (the HIP runtime the library and
+    torch share) and is wrapped as an ExternalStream (host plumbing; it lives as long as the process)."""
     if os.environ.get("ASR_SIDE_PRIORITY", "low") != "low":
         return torch.cuda.Stream(device=device)
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0 or least.value == greatest.value:
-        return torch.cuda.Stream(device=device)
-    h = ctypes.c_void_p()
-    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value) != 0 or not h.value:      # 1 = hipStreamNonBlocking
-        return torch.cuda.Stream(device=device)
+    from . import _lib
+    with torch.cuda.device(device):
+        h = ctypes.c_void_p()
+        # created inside libasr_hip.so, i.e. by the HIP runtime the kernels (and torch) are bound to: a second dlopen of
+        # libamdhip64 by bare name could map another runtime whose stream handles mean nothing to this one
+        _lib.check(_lib.lib.asr_stream_create(-1, ctypes.byref(h)), "asr_stream_create")
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
@@ -400,7 +399,11 @@ class Engine:
 
     def _ready(self, name):
         """Gradients at flat offsets >= this tensor's offset are final once the work queued so far
-        on BOTH streams has run: the consumer (dist.GradBucketer) waits on events of the two."""
+        on BOTH streams has run: the consumer (dist.GradBucketer) waits on events of the two.  Weight gradients held back by
+        ASR_WGRAD_DEFER are released first: a mark raised over a gradient that has not been launched yet would let the
+        bucketer all-reduce the bucket before that gradient is added (rank-divergent gradients under DataParallel)."""
+        if self.grad_ready is not None:
+            self._release_deferred()
         self.flush_wgrads()
         if self.grad_ready is not None:
             self.flush_ln_reduce()
@@ -779,7 +782,7 @@ class Engine:
             self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
         dx = dy + dy2  # gradient wrt the embedding output
         K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1])
-        if self.aux_overlap:
+        if self.aux_overlap and not torch.cuda.is_current_stream_capturing():      # nothing is forked to that stream while capturing
             torch.cuda.current_stream().wait_stream(self.ctc_stream)      # d_enc is complete (CTC branch + every cross-attention add)
         self._in_decoder = False
         self._ready("decoder.tgt_word_emb.weight")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 4
+#define ASR_ABI_VERSION 5
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -65,6 +65,10 @@ int asr_last_error(char* buf, size_t n);
  * synchronises every step (trainer11.py:73-74); the engine runs weight gradients / the CTC branch / communication on side
  * streams and forks ~50 times per step.  Must not be called while either stream is being captured into a hipGraph. */
 int asr_stream_fork(void* from_stream, void* to_stream);
+/* A non-blocking stream created by the HIP runtime THIS library is bound to: priority < 0 = the lowest priority the device
+ * offers (weight-gradient stream: off the critical path of the step), 0 = default, > 0 = the highest.  Lives as long as the
+ * process.  (The reference has one stream, trainer11.py:73-74; torch.cuda.Stream offers no low priority.) */
+int asr_stream_create(int priority, void** out_stream);
 int asr_get_deterministic(void);
 int asr_set_deterministic(int on);
 

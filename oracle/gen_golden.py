@@ -13,7 +13,8 @@ replaced by inert stubs: torchaudio, python_speech_featur
 seaborn, fire, tensorboard.  `Levenshtein` is replaced by a real pure-Python edit distance
 (only CER uses it).
 
-Usage:  python oracle/gen_golden.py            # writes tests/golden/*.npz
+Usage:  python oracle/gen_golden.py            # writes tests/golden/{model_small_*,ops}.npz
+        python oracle/gen_golden.py beam | augment | mfma     # the other fixtures, one group each
 """
 import os
 import sys
@@ -171,6 +172,64 @@ def model_case(name, cfg, B, T, Lmax, V, wave_len, tgt_len, seed, warm_up=25):
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB  loss={float(metrics.loss):.6f} "
           f"cer={float(metrics.cer):.3f} gnorm={float(total_norm):.5f}")
+
+
+def mfma_case():
+    """The MFMA geometry (the reference's DEFAULT width, transformer_official.py:115-122: d_model 512, 8 x 64 heads, ff 1024; one
+    encoder + one decoder layer, B = 3, T = 140 ragged) through the reference: weights and batch are functions of numpy seeds
+    (oracle/golden_inputs.py), only what the reference computes from them is stored - logits, sampled encoder rows, loss, CER,
+    per parameter SAMPLES gradient elements + norm + a full-tensor probe checksum, the clip norm, and the loss after one step."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import golden_inputs as GI
+    from Predictor import Models
+    from Predictor.data_handler import Vocab
+    from Predictor.Utils import Pack
+    from Trainer.optimizer import NoamOpt
+
+    case = GI.MFMA_CASE
+    Model = Models.TransformerOffical
+    config = Model.get_default_config()()
+    config.fn_build(dict(case["cfg"]))
+    model = Model(config, make_vocab(Vocab, case["V"]))
+    model.train()
+    sd = {k: torch.from_numpy(v) for k, v in GI.mfma_state_dict(case).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("positional_encoding.pe") for k in missing), (missing, unexpected)
+    assert model.decoder.tgt_word_prj.weight is model.decoder.tgt_word_emb.weight      # still tied after loading
+    b = GI.mfma_batch(case)
+    pack = Pack()
+    pack.add(wave=torch.from_numpy(b["wave"]), tgt_for_input=torch.from_numpy(b["tgt_for_input"]), tgt_for_metric=torch.from_numpy(b["tgt_for_input"]).clone(),
+             wave_len=torch.from_numpy(b["wave_len"]), tgt_len=torch.from_numpy(b["tgt_len"]))
+    out = {}
+    enc_out = model.encoder(pack.wave, pack.wave_len)[0]
+    output = model.forward(pack)
+    metrics = model.cal_metrics(output, pack)
+    out["fwd/enc_rows"] = np.arange(0, case["T"], 7)
+    out["fwd/enc_out_rows"] = _np(enc_out[:, ::7])
+    out["fwd/enc_out_abs_sum"] = np.float64(enc_out.double().abs().sum())
+    out["fwd/pred"] = _np(output.pred)
+    out["fwd/gold"] = _np(output.gold)
+    out["fwd/loss"] = _np(metrics.loss)
+    out["fwd/cer"] = _np(metrics.cer)
+    adam = torch.optim.Adam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9)
+    opt = NoamOpt(config.d_model, 1, case["warm_up"], adam)
+    opt.zero_grad()
+    metrics.loss.backward()
+    for n, p in model.named_parameters():
+        g = p.grad.detach().double().flatten().numpy()
+        out["grad_s/" + n] = g[GI.sample_index(n, g.size, case)].astype(np.float32)
+        out["grad_norm/" + n] = np.float64(np.sqrt((g * g).sum()))
+        out["grad_probe/" + n] = np.float64(g @ GI.probe(n, g.size, case))
+    total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+    out["step/grad_norm"] = _np(total_norm)
+    opt.step()
+    out["step/lr"] = np.float64(opt._rate)
+    m2, _ = model.iterate(pack, optimizer=opt, is_train=True)
+    out["step2/loss"] = _np(m2.loss)
+    path = os.path.join(OUT, case["name"] + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e3:.1f} kB  loss={float(metrics.loss):.6f} cer={float(metrics.cer):.3f} "
+          f"gnorm={float(total_norm):.5f} loss2={float(m2.loss):.6f}")
 
 
 def op_cases():
@@ -405,6 +464,9 @@ def main():
                 dropout=0.0, layer_num=2)
     if len(sys.argv) > 1 and sys.argv[1] == "augment":   # only the SpecAugment fixtures
         augment_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "mfma":      # only the d_model = 512 fixture (the others stay byte-identical)
+        mfma_case()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "beam":     # only the beam-search fixtures (the others stay byte-identical)
         beam_case("beam_small", base, B=3, T=20, V=12, wave_len=[20, 13, 7], seed=31, beam=3, nbest=3, decode_max_len=0)

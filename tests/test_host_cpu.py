@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import ROOT, golden_model_case, load_npz
+from tests.helpers import free_port, ROOT, golden_model_case, load_npz
 
 
 # ------------------------------------------------------------------------------------ C ABI
@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/asr_hip.h but not exported by libasr_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert _lib.lib.asr_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib.asr_abi_version() == _lib.ABI_VERSION == 5
     # argument counts of the binding match the header declarations
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "asr_hip.h")).read(), flags=re.S)
     for n in names:
@@ -279,7 +279,7 @@ print("rank", rank, "ok")
 def test_grad_bucketer_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=120)[0] for p in procs]
@@ -435,3 +435,24 @@ def test_tensorboard_event_file_format(tmp_path):
     bad.write_bytes(bytes(raw))
     with pytest.raises(ValueError):
         T.read_events(str(bad))
+
+
+def test_host_code_under_address_sanitizer():
+    """SURVEY section 5 (sanitizer build of the native host code): `make asan` compiles the host side of every translation unit
+    (argument validation, launch code, error reporting) and the vectorcall trampolines of csrc/fastcall.c with
+    -fsanitize=address (device code uninstrumented: GPU ASan is not available on this pool), and the tests that drive that
+    host code without a GPU run under it with the sanitizer runtime preloaded: any heap/stack/global overflow or
+    use-after-free in the shim aborts the child with a report."""
+    csrc = os.path.join(ROOT, "asr_chinese_e2e_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j8", "asan"], check=True, capture_output=True)
+    rt = subprocess.run(["make", "-s", "-C", csrc, "asan-rt"], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    asan_dir = os.path.join(ROOT, "asr_chinese_e2e_amd", "asan")
+    sym = subprocess.run(["nm", "-D", os.path.join(asan_dir, "libasr_hip.so")], capture_output=True, text=True).stdout
+    assert "__asan_init" in sym, "the sanitizer twin is not instrumented"
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", ASR_HIP_LIB=os.path.join(asan_dir, "libasr_hip.so"),
+               ASR_FASTCALL_DIR=asan_dir)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_host_cpu.py"), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "error_reporting_without_gpu or fastcall_trampolines or exports_every_declared_symbol"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "AddressSanitizer" not in p.stderr

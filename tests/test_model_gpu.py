@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_model as R  # noqa: E402
-from tests.helpers import golden_model_case  # noqa: E402
+from tests.helpers import golden_model_case, mfma_golden_case  # noqa: E402
 
 DEV = "cuda"
 
@@ -222,6 +222,74 @@ def test_bf16_mfma_path_matches_oracle(mode):
     assert rel < BF16_LOSS_RTOL, (float(loss[0]), float(ref["loss"]))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_default_width_matches_reference_golden(dtype):
+    """The kernels the bench times, against the REFERENCE directly (no oracle in between): TransformerOffical at its default
+    width (d_model 512, 8 heads x 64, ff 1024; transformer_official.py:115-122), one encoder + one decoder layer, ragged B = 3,
+    T = 140.  Weights and batch are rebuilt from numpy seeds (oracle/golden_inputs.py); expected values are what the reference
+    computed from the same arrays (tests/golden/model_mfma_d512.npz: `python oracle/gen_golden.py mfma`).
+    bf16 (MFMA GEMMs + fused MFMA attention): the SURVEY 8(d) bf16 gates - logits 2e-2 abs + 1e-2 rel, loss 1e-3 rel, per-tensor
+    gradient cosine >= 0.999 on the sampled elements (same relaxed classes as bf16_gradient_gate, with the reasons stated
+    there), norm within 3 %, clip norm within 1 %.  fp32 (own fp32 kernels): logits 1e-4, loss 1e-5, gradients 3e-4."""
+    cfg, sd, batch, z, GI = mfma_golden_case()
+    V = GI.MFMA_CASE["V"]
+    model = build(cfg, V, dtype=dtype)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    pack = to_pack(batch)
+    out = model.forward(pack)
+    pred, want = out.pred.float().cpu().numpy(), z["fwd/pred"]
+    assert np.array_equal(out.gold.cpu().numpy(), z["fwd/gold"])
+    if dtype == "fp32":
+        assert np.allclose(pred, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+    else:
+        assert np.allclose(pred, want, rtol=1e-2, atol=2e-2), float(np.abs(pred - want).max())
+    opt = make_opt(model, cfg, GI.MFMA_CASE["warm_up"])
+    model._ensure_engine(DEV)
+    model.zero_flat_grads()
+    loss, _ = model.train_step(pack)
+    rel = abs(float(loss[0]) - float(z["fwd/loss"])) / abs(float(z["fwd/loss"]))
+    assert rel < (1e-5 if dtype == "fp32" else BF16_LOSS_RTOL), (float(loss[0]), float(z["fwd/loss"]))
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("grad_s/"))
+    worst, worst_name, worst_ratio, worst_relaxed, sq = 1.0, "", 1.0, 1.0, 0.0
+    for n, p in model.named_parameters():
+        g = p.grad.double().flatten().cpu().numpy()
+        sq += float((g * g).sum()) if not n.endswith("tgt_word_prj.weight") else 0.0
+        w = z["grad_s/" + n].astype(np.float64)
+        if float(np.abs(w).max()) < 1e-6 * gmax or n.endswith(BF16_COS_EXEMPT):
+            continue
+        gs = g[GI.sample_index(n, g.size)]
+        norm = float(z["grad_norm/" + n])
+        if dtype == "fp32":
+            assert np.allclose(gs, w, rtol=3e-4, atol=3e-6 * max(float(np.abs(w).max()), 1e-3)), n
+            assert abs(float(np.sqrt((g * g).sum())) - norm) < 1e-4 * norm, n
+            assert abs(float(g @ GI.probe(n, g.size)) - float(z["grad_probe/" + n])) < 1e-3 * norm, n      # every element, not only the samples
+            continue
+        c = float((gs @ w) / (np.linalg.norm(gs) * np.linalg.norm(w) + 1e-300))
+        r = float(np.sqrt((g * g).sum())) / norm
+        relaxed = any(n.startswith(a) and b in n for a, b in BF16_COS_RELAXED)
+        if relaxed:
+            worst_relaxed = min(worst_relaxed, c)
+        elif c < worst:
+            worst, worst_name = c, n
+        if abs(r - 1) > abs(worst_ratio - 1):
+            worst_ratio = r
+        assert c > (BF16_COS_RELAXED_MIN if relaxed else BF16_COS), (n, c)
+        assert 0.97 < r < 1.03, (n, r)
+    gn, gn_want = float(np.sqrt(sq)), float(z["step/grad_norm"])
+    assert abs(gn - gn_want) < (1e-4 if dtype == "fp32" else 1e-2) * gn_want, (gn, gn_want)
+    if dtype == "bf16":
+        _report("default_width_vs_reference_bf16", dict(loss_rel=rel, worst_cos=worst, worst_tensor=worst_name, worst_relaxed_cos=worst_relaxed,
+                                                         worst_norm_ratio=worst_ratio, logits_max_abs=float(np.abs(pred - want).max())))
+    # and through the public entry point: clip + Noam + Adam, then the loss of the second iterate
+    m1, _ = model.iterate(pack, optimizer=opt, is_train=True)
+    m2, _ = model.iterate(pack, optimizer=opt, is_train=True)
+    assert abs(float(m1.loss) - float(z["fwd/loss"])) < (1e-5 if dtype == "fp32" else BF16_LOSS_RTOL) * abs(float(z["fwd/loss"]))
+    assert abs(float(m2.loss) - float(z["step2/loss"])) < (2e-4 if dtype == "fp32" else 5e-3) * abs(float(z["step2/loss"])), (float(m2.loss), float(z["step2/loss"]))
+    if dtype == "fp32":
+        assert abs(float(m1.cer) - float(z["fwd/cer"][0])) < 1e-3
+
+
 @pytest.mark.parametrize("mode", ["ctc_only", "joint"])
 def test_ctc_greedy_cer_matches_oracle(mode):
     """Evaluation of a CTC model reports the CER of best-path decoding: the device decode of the
@@ -294,8 +362,11 @@ def test_beam_search_matches_oracle(dtype, beam):
                 assert h["yseq"] == ids
                 assert abs(h["score"] - score) < 1e-4 * max(1.0, abs(score))
         else:
-            # ~10 steps of bf16 logits through a sharpened softmax: the summed log-probability moves by ~0.1
-            assert abs(got[b][0]["score"] - want[0][1]) < 0.3 * max(1.0, abs(want[0][1]))
+            # ~10 steps of bf16 logits through a sharpened softmax: the summed log-probability moves by a few 1e-2 (measured
+            # values go to gpurun_out/bf16_parity.jsonl); gate: 5 % of the score (round 2: 30 %)
+            err = abs(got[b][0]["score"] - want[0][1]) / max(1.0, abs(want[0][1]))
+            _report("beam_search_bf16_score", dict(utt=b, rel=err, score=want[0][1]))
+            assert err < 0.05, (got[b][0], want[0])
 
 
 def test_label_smoothing_matches_reference_formula():
@@ -332,7 +403,7 @@ def test_baseline_config0_matches_oracle(dtype):
     largest gradient, and no element off by more than 1 % of its tensor's maximum (typical agreement is
     3e-5; with 409 600 ReLU inputs an input within rounding of zero can land on the other side of the
     ReLU on the GPU, which moves a handful of w_1 gradient elements by ~4e-3 and everything upstream of
-    that layer by ~3e-4); bf16 MFMA path: loss 2e-2, gradient cosines > 0.99."""
+    that layer by ~3e-4); bf16 MFMA path: the SURVEY 8(d) gates (loss 1e-3 relative, per-tensor gradient cosine > 0.999)."""
     over = dict(layer_num=2, use_decoder=False, ctc_weight=1.0)
     cfg, sd, batch = oracle_case(4, 100, 80, 50, 12, over, seed=21)
     ref = R.RefTrainer(sd, cfg, warmup=4000).iterate(batch)
@@ -618,11 +689,18 @@ def test_ctc_prefix_beam_search_matches_oracle(frame_topk, on_device):
         assert [tuple(h["yseq"]) for h in got[b]] == [p for p, _ in want], (b, got[b], want)
         for h, (_, sc) in zip(got[b], want):
             assert abs(h["score"] - sc) < 2e-4 * max(1.0, abs(sc))
-    # the best prefix of a wide beam is at least as probable as the greedy (best-path) labelling
+    # a wide beam: identical to the oracle's list again, and its best prefix (a sum over alignments) is at least as probable as
+    # the single best path, whose labelling the greedy search returns
     greedy = model.ctc_greedy_search(pack)
-    wide = model.ctc_prefix_beam_search(pack, beam_size=8, nbest=8, frame_topk=14)
+    wide = model.ctc_prefix_beam_search(pack, beam_size=8, nbest=8, frame_topk=14, on_device=on_device)
     for b in range(len(greedy)):
-        assert any(h["yseq"] == greedy[b] for h in wide[b]) or wide[b][0]["score"] > -1e9
+        Tb = int(batch["wave_len"][b])
+        cand = [list(np.argsort(-logp[b, t], kind="stable")[:14]) for t in range(Tb)] if 14 < logits.shape[-1] else None
+        want = D.ctc_prefix_beam_search(logp[b, :Tb], 8, candidates=cand)[:8]
+        assert [tuple(h["yseq"]) for h in wide[b]] == [p for p, _ in want], (b, wide[b], want)
+        best_path = float(logp[b, :Tb].max(-1).sum())
+        assert wide[b][0]["score"] >= best_path - 1e-6, (wide[b][0], best_path)
+        assert any(h["yseq"] == greedy[b] for h in wide[b]), (greedy[b], wide[b])
 
 
 def test_joint_ctc_attention_rescoring_matches_oracle():
@@ -637,7 +715,6 @@ def test_joint_ctc_attention_rescoring_matches_oracle():
     got = model.beam_search(pack, beam_size=beam, nbest=beam, decode_max_len=9, ctc_weight=lam)
     with torch.no_grad():
         logits = model.forward(pack).ctc_logits.double().cpu().numpy()
-    reordered = 0
     for b in range(logits.shape[0]):
         Tb = int(batch["wave_len"][b])
 
@@ -653,8 +730,9 @@ def test_joint_ctc_attention_rescoring_matches_oracle():
         for h, w in zip(got[b], want):
             for key in ("score", "att_score", "ctc_score"):
                 assert (h[key] == w[key]) or abs(h[key] - w[key]) < 2e-4 * max(1.0, abs(w[key])), (key, h, w)
-        reordered += [h["yseq"] for h in got[b]] != [h["yseq"] for h in att[b]]
-    assert reordered >= 0
+        # the re-ranked list is a permutation of the attention beam's hypotheses, sorted by the joint score
+        assert sorted(map(tuple, (h["yseq"] for h in got[b]))) == sorted(map(tuple, (h["yseq"] for h in att[b])))
+        assert all(got[b][i]["score"] >= got[b][i + 1]["score"] for i in range(len(got[b]) - 1))
     with pytest.raises(RuntimeError):
         build(R.default_cfg(n_mels=16, lfr_m=1, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=1), 14, "TransformerOffical", dtype="fp32").cuda().beam_search(pack, 2, 1, 4, ctc_weight=0.3)
 

@@ -6,7 +6,7 @@ import torch
 
 from oracle import ref_model as R
 from oracle import logmel_ref as LM
-from tests.helpers import golden_model_case, load_npz, rel_err
+from tests.helpers import golden_model_case, load_npz, mfma_golden_case, rel_err
 
 CASES = ["model_small_ragged.npz", "model_small_full.npz"]
 
@@ -212,3 +212,36 @@ def test_spec_augment_oracle_matches_reference_golden():
         assert np.allclose(got, want, rtol=0, atol=2e-6), k
         masked_any |= (m[1] > m[0]) or (m[3] > m[2])
     assert masked_any
+
+
+def test_oracle_matches_reference_at_default_width():
+    """The oracle against the reference at the geometry the MFMA kernels run (d_model 512, 8 x 64 heads, ff 1024, one encoder +
+    one decoder layer, ragged B = 3, T = 140): logits, sampled encoder rows, loss, CER, per parameter the sampled gradient
+    elements, the norm and the full-tensor probe checksum, the clip norm and the loss after one Noam + Adam step."""
+    cfg, sd, batch, z, GI = mfma_golden_case()
+    tr = R.RefTrainer(sd, cfg, warmup=GI.MFMA_CASE["warm_up"])
+    out = R.forward_losses(sd, cfg, batch)
+    assert rel_err(out["enc_out"].detach()[:, ::7], z["fwd/enc_out_rows"]) < 5e-6
+    assert abs(float(out["enc_out"].detach().double().abs().sum()) - float(z["fwd/enc_out_abs_sum"])) < 1e-5 * float(z["fwd/enc_out_abs_sum"])
+    assert np.array_equal(out["gold"].numpy(), z["fwd/gold"])
+    assert rel_err(out["pred"].detach(), z["fwd/pred"]) < 5e-6
+    assert abs(float(out["loss"]) - float(z["fwd/loss"])) < 1e-5 * abs(float(z["fwd/loss"]))
+    id2token = ["$", "%", "^", "&"] + [chr(0x4E00 + i) for i in range(GI.MFMA_CASE["V"] - 4)]
+    assert abs(R.cer_percent(out["pred"].detach(), out["gold"], id2token) - float(z["fwd/cer"][0])) < 1e-3
+    r = tr.iterate(batch)
+    for k in tr.trainable:
+        g = r["grads"][k].double().flatten().numpy()
+        want = z["grad_s/" + k]
+        if k.endswith("w_ks.bias"):      # analytically zero (softmax shift invariance): what is stored is fp32 round-off
+            assert float(np.abs(g).max()) < 1e-6 and float(np.abs(want).max()) < 1e-6
+            continue
+        gmax = float(np.abs(want).max())
+        assert np.allclose(g[GI.sample_index(k, g.size)], want, rtol=3e-4, atol=3e-6 * max(gmax, 1e-3)), k
+        norm = float(z["grad_norm/" + k])
+        assert abs(float(np.sqrt((g * g).sum())) - norm) < 1e-4 * norm, k
+        # <g, probe> has the magnitude of the norm (probe ~ N(0, 1)): a checksum over every element, not only the sampled ones
+        assert abs(float(g @ GI.probe(k, g.size)) - float(z["grad_probe/" + k])) < 1e-3 * norm, k
+    assert abs(float(r["grad_norm"]) - float(z["step/grad_norm"])) < 1e-4 * float(z["step/grad_norm"])
+    assert abs(r["lr"] - float(z["step/lr"])) < 1e-12
+    r2 = tr.iterate(batch)
+    assert abs(float(r2["loss"]) - float(z["step2/loss"])) < 2e-4 * abs(float(z["step2/loss"]))

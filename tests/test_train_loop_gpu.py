@@ -9,7 +9,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-from tests.helpers import ROOT  # noqa: E402
+from tests.helpers import ROOT, free_port  # noqa: E402
 
 
 def small_model(ctc_weight=0.3, cls="TransformerOffical", seed=0):
@@ -382,7 +382,7 @@ def test_data_parallel_wrapper_one_rank_rccl(tmp_path):
     normalisers and fused step give the same trajectory as the plain model."""
     script = tmp_path / "dp_worker.py"
     script.write_text(DP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "dp ok" in p.stdout
@@ -446,8 +446,101 @@ def test_data_parallel_two_ranks_equals_single_process(tmp_path, mode):
     because the test box has one GPU; the RCCL path is the 1-rank test above and the driver's scaling run."""
     script = tmp_path / "dp2_worker.py"
     script.write_text(DP2_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551" if mode == "ctc" else "29552", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} dp2 ok" in o
+
+
+DP2_BF16_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from asr_chinese_e2e_amd import Models, dist as D
+from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+from asr_chinese_e2e_amd.Utils import Pack
+rank, world = D.init("gloo")          # two ranks share the one GPU of the test box: gloo moves the CUDA buckets (bf16 included)
+torch.cuda.set_device(0)
+def build():
+    torch.manual_seed(0)
+    M = Models.TransformerOffical     # the joint CTC/attention model at the reference's default width: the bench's N > 1 workload
+    cfg = M.get_default_config()()
+    cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=1, dropout=0.0, ctc_weight=0.3, dtype="bf16"))
+    m = M(cfg, Vocab.synthetic(60)).cuda()
+    return m, NoamOpt(512, 1, 10, FusedAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+full = synthetic_pack(6, 96, 80, 60, seed=5, ragged=True, Lmin=3, Lmax=9, device="cuda", dtype=torch.bfloat16)
+lo, hi = (0, 3) if rank == 0 else (3, 6)
+mine = Pack()
+mine.add(**{k: full[k][lo:hi].contiguous() for k in ("wave", "wave_len", "tgt_for_input", "tgt_for_metric", "tgt_len")})
+m32, _ = build()                      # bf16 model, fp32 on the wire
+m16, o16 = build()                    # bf16 model, bf16 on the wire (the default for bf16 models)
+dp32 = D.DataParallel(m32, "cuda", bucket_bytes=1 << 20, reduce_loss=True, wire_dtype=torch.float32)
+dp16 = D.DataParallel(m16, "cuda", bucket_bytes=1 << 20, reduce_loss=True)
+assert dp32.bucketer.wire is None and dp16.bucketer.wire is not None and dp16.bucketer.wire.dtype == torch.bfloat16
+assert len(dp16.bucketer.buckets) > 3
+grads = {}
+for name, m, dp in (("fp32", m32, dp32), ("bf16", m16, dp16)):
+    m.zero_flat_grads(); dp.bucketer.begin()
+    m.train_step(mine, count_hook=dp._counts.start); dp.bucketer.finish()
+    torch.cuda.synchronize()
+    grads[name] = m._flat.g.clone()
+# each rank's addend is rounded to bf16 (2^-9 relative) and the two-rank sum once more: per element within 2^-8 * ranks of the
+# larger addend.  The addends are not kept, so the bound is stated on the tensor scale: per parameter tensor the difference is
+# below 2^-8 * world * max|g| everywhere, and the tensors agree in direction to 1e-5 (the two backward passes themselves differ
+# by atomics order only)
+bound = 2.0 ** -8 * world
+for n, (off, shape) in m16._flat.index.items():
+    k = 1
+    for d_ in shape: k *= d_
+    a, b = grads["fp32"][off:off + k], grads["bf16"][off:off + k]
+    sc = float(a.abs().max())
+    if sc == 0.0:
+        assert float(b.abs().max()) == 0.0, n
+        continue
+    assert float((a - b).abs().max()) <= bound * sc, (n, float((a - b).abs().max()), sc)
+    if not n.endswith("w_ks.bias"):
+        c = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm() + 1e-300))
+        assert c > 1.0 - 1e-4, (n, c)
+assert float((grads["fp32"] - grads["bf16"]).abs().max()) > 0.0      # the wire format really differed
+# and the bf16-wire trajectory follows a single process on the whole batch
+m1, o1 = build()
+for _ in range(3):
+    a, _ = m1.iterate(full, optimizer=o1)
+    b, _ = dp16.iterate(mine, optimizer=o16)
+    assert abs(float(a.loss) - float(b.loss)) < 5e-3 * abs(float(a.loss)), (float(a.loss), float(b.loss))
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+print("rank", rank, "dp2 bf16 ok")
+"""
+
+
+@pytest.mark.gpu
+def test_data_parallel_bf16_wire_two_ranks(tmp_path):
+    """The bf16 wire format summed across REAL ranks (round-2 advice): the joint bf16 model at d_model 512 on two ranks (gloo on the
+    one GPU), gradients reduced with bf16 buckets against the same backward reduced with fp32 buckets - element-wise within
+    2^-8 x ranks of the tensor's largest gradient - and the bf16-wire training trajectory against a single process."""
+    script = tmp_path / "dp2_bf16_worker.py"
+    script.write_text(DP2_BF16_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} dp2 bf16 ok" in o
+
+
+@pytest.mark.gpu
+def test_data_parallel_two_ranks_with_deferred_weight_gradients(tmp_path):
+    """Round-2 advice: with ASR_WGRAD_DEFER set to a projection other than the default (here qkv and w1) a weight gradient is
+    still held back when its layer's "gradients final" mark is raised; Engine._ready releases it first, so the two-rank run
+    still equals the single process (before the fix the bucket left without that gradient)."""
+    script = tmp_path / "dp2_worker.py"
+    script.write_text(DP2_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2", ASR_WGRAD_DEFER="qkv,w1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, "ctc"], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
