@@ -46,6 +46,7 @@ SIGNATURES = {
     "asr_last_error": (I, [c_char_p, Z]),
     "asr_stream_fork": (I, [P, P]),
     "asr_stream_create": (I, [I, P]),
+    "asr_set_option": (I, [c_char_p, I, P]),
     "asr_get_deterministic": (I, []),
     "asr_set_deterministic": (I, [I]),
     "asr_add_ln_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, F, U, I, I, P]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "asr_loss_combine": (I, [P, I, P, P, I, F, F, P, P]),
     "asr_gemm_nt_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "asr_gemm_small_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "asr_gemm_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "asr_gemm_nt_add_ln_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "asr_gemm_tn_workspace_bytes": (Z, [I, I, I]),
     "asr_gemm_tn_bf16": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),

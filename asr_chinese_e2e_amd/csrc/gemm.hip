@@ -343,10 +343,13 @@ template <int NW> struct PCfg {                    // NW waves as (NW/2) x 2; wa
     static constexpr int PSTORES = 4 * MI;         // global stores per wave per tile (vmcnt accounting)
 };
 
-template <int ACT, int NW, int DBG = 0>
+// KRAG: K is a multiple of 8 but not of 64 (the CTC head's input gradient reduces over V = 4232 columns): the 16-byte chunks of the
+// LAST k-step that lie past K are fetched from a zero page instead (per-lane select, on that one step only).
+template <int ACT, int NW, int DBG = 0, bool KRAG = false>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                                      bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                                     int tiles_n, int ntiles, const bf16_t* __restrict__ mask) {
+                                                                     int tiles_n, int ntiles, const bf16_t* __restrict__ mask,
+                                                                     const void* __restrict__ zero_page = nullptr, int st_mode = 0) {
     using Cfg = PCfg<NW>;
     constexpr int MI = Cfg::MI, PPW = Cfg::PPW, RM = Cfg::RM, PEPI = Cfg::PEPI, PSTORES = Cfg::PSTORES;
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
     const int first = lo + idx;
     if (first >= hi) return;
     const int my_tiles = (hi - first + nb_x - 1) / nb_x;
-    const int nk = K / PBK;
+    const int nk = KRAG ? (K + PBK - 1) / PBK : K / PBK;
     const int total = my_tiles * nk;
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 31, hh = lane >> 5;
@@ -380,7 +383,13 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
         }
     };
     auto dma = [&](int j) {
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + it_k * PBK), (lds_void_t*)(smem_p + it_slot * PSTAGE + (w * PPW + j) * 1024), 16, 0, 0);
+        const bf16_t* p = src[j] + it_k * PBK;
+        if (KRAG && it_k == nk - 1) {      // wave-uniform: the ragged last k-step
+            const int g = w * PPW + j;
+            const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));
+            p = (it_k * PBK + schunk * 8 < K) ? p : (const bf16_t*)zero_page;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)p, (lds_void_t*)(smem_p + it_slot * PSTAGE + (w * PPW + j) * 1024), 16, 0, 0);
     };
     auto advance = [&]() {
         ++issued;
@@ -553,7 +562,13 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
             for (int q = 0; q < 4 * RM; ++q) {
                 const int row = q * 8 + srow, ch = lane & 7;
                 const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
-                if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
+                if (m < M && n + 8 <= N) {
+                    u32x4* dst = (u32x4*)(C + (size_t)m * ldc + n);
+                    if (st_mode == 0) stream_store(v[q], dst);
+                    else if (st_mode == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v[q]) : "memory");
+                    else if (st_mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v[q]) : "memory");
+                    else *dst = v[q];
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -568,17 +583,199 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_
     }
 }
 
-template <int ACT, int NW, int DBG = 0>
+template <int ACT, int NW, int DBG = 0, bool KRAG = false>
 static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st,
-                              const bf16_t* mask = nullptr) {
+                              const bf16_t* mask = nullptr, const void* zero_page = nullptr) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<ACT, NW, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<ACT, NW, DBG, KRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
         attr = true;
     }
     const int t_n = ceil_div(N, PBN), t_m = ceil_div(M, PBM), ntiles = t_n * t_m;
     const int grid = ntiles < cu_count() ? ntiles : cu_count();
-    gemm_nt_persist_kernel<ACT, NW, DBG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask);
+    // store policy of the output tile: 0 = nt (default), 1 = sc1 (write-through), 2 = plain, 3 = sc0 sc1 - all correct, A/B switch
+    const int st_mode = asr_option(ASR_OPT_NT_STORE);
+    gemm_nt_persist_kernel<ACT, NW, DBG, KRAG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask, zero_page, st_mode);
+}
+
+// ------------------------------------------------------------------------- NT, persistent, 256 x 256 tiles
+// What bounds the 256 x 128 kernel above (in-kernel stamps, round 3): a k-step takes 0.93 us where its 32 MFMAs per SIMD need
+// 0.54 us - the step is paced by the L2 -> LDS stream (48 KiB per k-step and CU at the ~70 GB/s a CU draws from L2 with every CU
+// pulling), not by the matrix pipe.  A 256 x 256 tile moves 64 KiB per 8.4 MFLOP instead of 48 KiB per 4.2: two thirds of the
+// bytes per FLOP, so the k-step becomes matrix-bound (64 MFMAs per SIMD ~ 1.1 us at the ~1.9 GHz held under load).  The price:
+// a stage is 64 KiB, so the ring has TWO slots (128 KiB) and the DMA of step i + 1 has exactly step i to land; and a GEMM needs
+// N >= 1024 with about one tile per CU or many (w_1 forward and w_2 input gradient: 63 x 4 = 252 tiles; CTC head: 63 x 17).
+//   * 8 waves as 4 (rows) x 2 (columns), wave tile 64 x 128 = 2 x 4 MFMA 32x32x16 blocks (128 accumulator registers),
+//     6 fragment reads per 8 MFMAs (the kernel above: 4 per 4);
+//   * the 8 DMA instructions of a wave for step i + 1 go out behind every second MFMA of the FIRST half of step i;
+//   * store tail: per wave two rounds of 32 rows x 128 columns through a wave-private 8-KiB buffer in the slot consumed last
+//     (256-byte rows, 16-byte chunk c of row r at c ^ (r & 15)), 16 lanes per row = whole 256-byte segments per store.
+constexpr int WBM = 256, WBN = 256, WBK = 64;
+constexpr int WSTAGE = (WBM + WBN) * 128;          // 65536 B
+constexpr int WLDS = 2 * WSTAGE;                   // 131072 B
+constexpr int WPPW = (WBM + WBN) / 8 / 8;          // 8 one-KiB DMA pieces per wave per stage
+constexpr int WSTORES = 16;                        // global stores per wave per interior tile
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int tiles_n, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int nb_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int tq = ntiles >> 3, trem = ntiles & 7;
+    const int lo = xcd * tq + min(xcd, trem), hi = lo + tq + (xcd < trem ? 1 : 0);
+    const int first = lo + idx;
+    if (first >= hi) return;
+    const int my_tiles = (hi - first + nb_x - 1) / nb_x;
+    const int nk = K / WBK;
+    const int total = my_tiles * nk;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, hh = lane >> 5, srow = lane >> 3;
+
+    // DMA cursor: ONE k-step ahead of the MFMAs, across tile boundaries
+    int it_tile = first, it_k = 0, it_slot = 0, issued = 0;
+    const bf16_t* src[WPPW];
+    auto set_tile = [&](int tile) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int m0 = tm * WBM, n0 = tn * WBN;
+#pragma unroll
+        for (int j = 0; j < WPPW; ++j) {
+            const int g = w * WPPW + j;                       // 8-row group: 0..31 = A rows, 32..63 = W rows
+            const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));
+            src[j] = g < WBM / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
+                                 : W + (size_t)min(n0 + 8 * (g - WBM / 8) + srow, N - 1) * ldb + schunk * 8;
+        }
+    };
+    auto dma = [&](int j) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + it_k * WBK), (lds_void_t*)(smem_w + it_slot * WSTAGE + (w * WPPW + j) * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        ++issued;
+        it_slot ^= 1;
+        if (++it_k == nk) {
+            it_k = 0;
+            it_tile += nb_x;
+            if (issued < total) set_tile(it_tile);
+        }
+    };
+    const int sw = (r >> 1) & 7;
+    const int a_row = (wm * 64 + r) * 128;                   // + mi * 32 * 128
+    const int w_row = WBM * 128 + (wn * 128 + r) * 128;      // + ni * 32 * 128
+    set_tile(first);
+#pragma unroll
+    for (int j = 0; j < WPPW; ++j) dma(j);
+    advance();
+    int c_slot = 0, i = 0;
+    bool prev_stores = false;
+    for (int c_tile = first; c_tile < hi; c_tile += nb_x) {
+        const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
+        const int m0 = tm * WBM + wm * 64, n0 = tn * WBN + wn * 128;
+        f32x16 acc[4][2];  // [ni][mi]: C^T blocks (n in registers, m on the lane), starting at the bias (scalar loads)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nb = min(n0 + ni * 32 + 8 * g4, N - 8);   // clamped groups are never stored
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
+                    const float bv = hh ? b_hi : b_lo;
+                    acc[ni][0][4 * g4 + e] = bv;
+                    acc[ni][1][4 * g4 + e] = bv;
+                }
+            }
+        for (int c_k = 0; c_k < nk; ++c_k, ++i) {
+            // item i has landed when only the stores of the previous tile's tail (issued after its DMA) are outstanding
+            if (prev_stores && c_k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WSTORES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // every wave's part of item i landed; nobody still reads the other slot (item i - 1)
+            const bool more = issued < total;
+            const char* sb = smem_w + c_slot * WSTAGE;
+            c_slot ^= 1;
+            bf16x8 af[2][2], wf[2][4];
+            auto load_frags = [&](int buf, int ks) {
+                const int coff = ((2 * ks + hh) ^ sw) << 4;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) af[buf][mi] = *(const bf16x8*)(sb + a_row + mi * 32 * 128 + coff);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int ni = q >> 1, mi = q & 1;
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+                    const int g = ks * 8 + q;                    // MFMA number in this step: DMA piece g / 2 behind every odd one of the first 16
+                    if (g < 2 * WPPW && (g & 1)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) dma(g >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (more) advance();
+        }
+        // ---- store tail
+        __builtin_amdgcn_s_barrier();      // the other waves have finished their fragment reads of the slot that becomes the staging area
+        char* epi = smem_w + (c_slot ^ 1) * WSTAGE + w * 8192;
+        const int erow = lane >> 4, ech = lane & 15;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[ni][mi][4 * g4 + e];
+                        if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
+                        o[e] = x;
+                    }
+                    // row r (= m), columns ni*32 + 8*g4 + 4*hh .. +3  ->  16-byte chunk ni*4 + g4 (of 16 per 256-byte row), half hh
+                    store4<bf16_t>((bf16_t*)(epi + r * 256 + (((ni * 4 + g4) ^ (r & 15)) << 4) + hh * 8), o);
+                }
+            __builtin_amdgcn_wave_barrier();
+            u32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = q * 4 + erow;
+                v[q] = *(const u32x4*)(epi + row * 256 + ((ech ^ (row & 15)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = q * 4 + erow;
+                const int m = m0 + mi * 32 + row, n = n0 + ech * 8;
+                if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        prev_stores = (tm * WBM + WBM <= M) && (tn * WBN + WBN <= N);
+    }
+}
+
+template <int ACT>
+static void launch_nt_wide(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
+        attr = true;
+    }
+    const int t_n = ceil_div(N, WBN), t_m = ceil_div(M, WBM), ntiles = t_n * t_m;
+    const int grid = ntiles < cu_count() ? ntiles : cu_count();
+    gemm_nt_wide_kernel<ACT><<<grid, 512, WLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles);
+}
+// Tile choice: the wide tile pays when the GEMM has enough 256 x 256 tiles to fill the chip about once (>= 90 % of the CUs in the
+// last round) - w_1 / w_2-dgrad (252 tiles), the CTC head (1071); N = 1536 (378 tiles = 1.48 rounds) stays on 256 x 128.
+static bool nt_wide_pays(int M, int N, int K) {
+    if (N < 1024 || K % WBK || K < 2 * WBK) return false;
+    const int tiles = ceil_div(N, WBN) * ceil_div(M, WBM), cus = cu_count();
+    const int rounds = ceil_div(tiles, cus);
+    return tiles * 10 >= rounds * cus * 8;      // at least 80 % of the tile slots of the rounds it takes are used
 }
 
 // ------------------------------------------------------------------------- small-M projections (decoder)
@@ -1573,6 +1770,15 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }
+    if (K % DBK != 0 && K >= 2 * PBK && !res && act == ASR_ACT_NONE && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {
+        // ragged reduction length (K % 8 == 0 was checked above): persistent kernel, last k-step padded from the zero page
+        static void* zero_page = nullptr;
+        if (!zero_page && (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page))
+            ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: zero page symbol not found");
+        launch_nt_persist<ASR_ACT_NONE, 8, 0, true>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, nullptr, zero_page);
+        ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
+        return ASR_OK;
+    }
     if (K % DBK == 0 && !res && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {   // LDS-DMA kernel: whole 64-wide k-tiles, 16-B row stores
         static const int dbg = unsafe_debug_env("ASR_GEMM_DBG");      // timing experiments (wrong results): debug builds only
         static const int cfg = getenv("ASR_GEMM_CFG") ? atoi(getenv("ASR_GEMM_CFG")) : 0;   // tuning experiments
@@ -1591,6 +1797,11 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         // they stay selectable through ASR_GEMM_CFG for A/B runs)
         // default: the persistent 8-wave kernel (tools/gemm_bench.py on the config-2 shapes, us:
         // 38.4 / 17.4 / 27.0 / 23.8 / 116.8 vs 46.2 / 19.4 / 32.1 / 27.1 / 130.0 for 128 x 128 ring 2)
+        const int tile_opt = asr_option(ASR_OPT_NT_TILE);      // 0 = by shape, 1 = always 256 x 128, 2 = 256 x 256 whenever the shape allows
+        if (cfg == 0 && dbg == 0 && N % 8 == 0 && tile_opt != 1 && (tile_opt == 2 ? (K % WBK == 0 && K >= 2 * WBK && N >= 256) : nt_wide_pays(M, N, K))) {
+            if (act == ASR_ACT_RELU) launch_nt_wide<ASR_ACT_RELU>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+            else launch_nt_wide<ASR_ACT_NONE>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+        } else
         if ((cfg == 0 || cfg == 8) && K >= 2 * PBK && N % 8 == 0) {
             if (dbg == 5) launch_nt_persist<ASR_ACT_NONE, 8, 5>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
             else if (act == ASR_ACT_RELU) launch_nt_persist<ASR_ACT_RELU, 8>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);

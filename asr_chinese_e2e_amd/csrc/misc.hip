@@ -34,6 +34,41 @@ extern "C" int asr_set_deterministic(int on) {
     return old;
 }
 
+// ---- tuning options: process-wide integer switches that select between CORRECT variants of a kernel (store policy, tile shape ...),
+// settable at run time so that two variants can be timed alternately inside one process (box-to-box noise is ~2 %).
+// Initial value: environment variable ASR_OPT_<NAME upper case>, else the built-in default.
+static const char* const g_opt_names[ASR_OPT_COUNT] = {"nt_store", "nt_tile", "ln_store", "sdpa_store", "tn_cfg", "spare"};
+static int g_opt_val[ASR_OPT_COUNT];
+static bool g_opt_init = false;
+static void opt_init() {
+    if (g_opt_init) return;
+    static const int defaults[ASR_OPT_COUNT] = {ASR_OPT_NT_STORE_DEFAULT, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ASR_OPT_COUNT; ++i) {
+        char env[64] = "ASR_OPT_";
+        size_t k = strlen(env);
+        for (const char* c = g_opt_names[i]; *c && k + 1 < sizeof(env); ++c) env[k++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+        env[k] = 0;
+        const char* e = getenv(env);
+        g_opt_val[i] = e ? atoi(e) : defaults[i];
+    }
+    g_opt_init = true;
+}
+int asr_option(int key) {
+    opt_init();
+    return (key >= 0 && key < ASR_OPT_COUNT) ? g_opt_val[key] : 0;
+}
+extern "C" int asr_set_option(const char* name, int value, int* previous) {
+    opt_init();
+    if (!name) ASR_FAIL(ASR_EINVAL, "asr_set_option: null name");
+    for (int i = 0; i < ASR_OPT_COUNT; ++i)
+        if (strcmp(name, g_opt_names[i]) == 0) {
+            if (previous) *previous = g_opt_val[i];
+            g_opt_val[i] = value;
+            return ASR_OK;
+        }
+    ASR_FAIL(ASR_EINVAL, "asr_set_option: unknown option '%s'", name);
+}
+
 extern "C" int asr_last_error(char* buf, size_t n) {
     if (buf && n) {
         strncpy(buf, g_err, n - 1);

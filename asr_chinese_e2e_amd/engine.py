@@ -96,10 +96,10 @@ class FlatParams:
 
 
 class Linear:
-    """y = x W^T + b with W (N,K) a view of the flat buffers.  bf16: hand-written MFMA kernels
-    (asr_gemm_nt_bf16 forward, asr_gemm_tn_bf16 weight gradient); shapes the kernels do not take
-    (K or leading dims not multiples of 8) and fp32 mode go to the hipBLASLt/rocBLAS library GEMM
-    through torch.matmul - a plain library GEMM, never a CPU fallback."""
+    """y = x W^T + b with W (N,K) a view of the flat buffers.  bf16: hand-written MFMA kernels (asr_gemm_nt_bf16 forward and,
+    with transposed weight copies, input gradient; asr_gemm_small_bf16 for the decoder's few rows; asr_gemm_tn_bf16 weight
+    gradient).  fp32 (parity mode) and the bf16 shapes those kernels do not take (K or leading dimensions not multiples of 8):
+    asr_gemm_f32, fp32 on the matrix cores.  No library GEMM anywhere (round 3), and never a CPU fallback."""
 
     def __init__(self, flat, w_names, b_names, N, Kdim):
         self.flat, self.N, self.K = flat, N, Kdim
@@ -130,11 +130,12 @@ class Linear:
 
     # ---- forward
     SMALL_M = int(os.environ.get("ASR_SMALL_M", "1024"))      # rows up to which the 64 x 64-tile kernel serves a projection (the decoder's B*To)
+    SMALL_REDUCE = 8192      # longest reduction it takes (the tied output projection's input gradient reduces over V = 4232)
 
     def small(self, x, reduce_len):
         """True when the small-M kernel (asr_gemm_small_bf16) takes this operand: few rows, bf16, 8-element alignment."""
         return (x.dtype == torch.bfloat16 and x.shape[0] <= Linear.SMALL_M and self.N % 8 == 0 and self.K % 8 == 0 and x.stride(0) % 8 == 0
-                and x.stride(1) == 1 and x.data_ptr() % 16 == 0 and reduce_len <= 2048)
+                and x.stride(1) == 1 and x.data_ptr() % 16 == 0 and reduce_len <= Linear.SMALL_REDUCE)
 
     def fwd(self, x, act=ACT_NONE, out=None):
         M = x.shape[0]
@@ -144,46 +145,57 @@ class Linear:
         if x.dtype == torch.bfloat16 and K.gemm_nt_supported(M, self.N, self.K, x.stride(0), self.wlp.stride(0), out.stride(0)):
             K.gemm_nt(x, self.wlp, self.b32, out, act)
             return out
-        w = self.wlp if x.dtype == torch.bfloat16 else self.w32
-        if self.b32 is not None:
-            torch.addmm(self.b32.to(x.dtype), x, w.t(), out=out)
-        else:
-            torch.mm(x, w.t(), out=out)
-        if act == ACT_RELU:
-            K.relu_(out)
+        if x.dtype == torch.float32:      # parity mode: fp32 on the matrix cores (asr_gemm_f32), ReLU in the store tail
+            return K.gemm_f32(x, self.w32, out, bias=self.b32, trans_b=True, act=act)
+        # bf16 shapes the bf16 kernels refuse (K or a leading dimension not a multiple of 8): through the fp32 kernel
+        tmp = K.gemm_f32(x.float(), self.w32, torch.empty(M, self.N, dtype=torch.float32, device=x.device), bias=self.b32, trans_b=True, act=act)
+        out.copy_(tmp)
         return out
 
     # ---- backward pieces
     def own_dgrad(self, dy, accumulate=False):
-        """True when dgrad takes the own NT kernel (transposed weight copy) for this dy."""
-        return (self.wlpT is not None and self.flat.lpT_version == self.flat.version      # stale copies (no refresh since the last update): library GEMM
-                and not accumulate and dy.shape[0] >= 4096 and dy.dtype == torch.bfloat16 and self.N % 64 == 0
+        """True when dgrad takes the persistent NT kernel (transposed weight copy) for this dy."""
+        return (self.wlpT is not None and not accumulate and dy.shape[0] >= 4096 and dy.dtype == torch.bfloat16 and self.N % 8 == 0 and self.N >= 128
                 and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0)
 
+    def _fresh_transpose(self):
+        if self.flat.lpT_version != self.flat.version:
+            # the copies are made at the start of every training step (Engine.refresh_transposes); a backward pass without
+            # that call would multiply by last step's weights - refuse instead of silently taking another path
+            raise RuntimeError("transposed weight copies are stale: call Engine.refresh_transposes() before the backward pass")
+
     def dgrad(self, dy, out=None, accumulate=False, relu_mask=None):
-        """dx = dy W, or out += dy W when accumulate.  relu_mask (own-kernel path only, see own_dgrad): the activations
-        of the ReLU in front of this projection - their backward mask is applied in the GEMM's store tail."""
-        w = self.wlp if dy.dtype == torch.bfloat16 else self.w32
-        flops = 2.0 * dy.shape[0] * self.N * self.K
+        """dx = dy W, or out += dy W when accumulate.  relu_mask: the activations of the ReLU in front of this projection -
+        their backward mask is applied in the GEMM's store tail."""
+        if dy.dtype == torch.float32:      # parity mode: fp32 on the matrix cores, W as stored
+            out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
+            return K.gemm_f32(dy, self.w32, out, act=ACT_RELU_MASK if relu_mask is not None else ACT_NONE, mask=relu_mask, accumulate=accumulate)
         if not accumulate and self.small(dy, self.N) and (out is None or out.stride(0) % 4 == 0):
-            # few rows (decoder): dX = dY W straight from the weight as stored, on the 64 x 64-tile kernel (no library call, no transposed copy)
+            # few rows (decoder): dX = dY W straight from the weight as stored, on the 64 x 64-tile kernel (no transposed copy)
             out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
             return K.gemm_small(dy, self.wlp, None, out, trans_b=True, act=ACT_RELU_MASK if relu_mask is not None else ACT_NONE, mask=relu_mask)
         if accumulate and out is not None and relu_mask is None and self.own_dgrad(dy) and out.dtype == torch.bfloat16 and out.stride(0) % 8 == 0 \
                 and out.data_ptr() % 16 == 0:
+            self._fresh_transpose()
             return K.gemm_nt(dy, self.wlpT, None, out, res=out)      # out += dY W: residual add in the store tail, in place
         if self.own_dgrad(dy, accumulate):
-            # dX = dY W as an NT product with the transposed weight copy: own MFMA kernel instead of the library GEMM
+            # dX = dY W as an NT product with the transposed weight copy: own MFMA kernel
+            self._fresh_transpose()
             out = torch.empty(dy.shape[0], self.K, dtype=dy.dtype, device=dy.device) if out is None else out
             if relu_mask is not None:
                 return K.gemm_nt(dy, self.wlpT, None, out, act=ACT_RELU_MASK, res=relu_mask)
             return K.gemm_nt(dy, self.wlpT, None, out)
-        assert relu_mask is None, "relu_mask needs the own-kernel path (check own_dgrad first)"
-        if accumulate:
-            return K.timed("lib_gemm_dgrad", flops, lambda: out.addmm_(dy, w))
+        # what is left: bf16 shapes none of the bf16 kernels takes (odd vocabulary sizes, misaligned views, a many-row operand
+        # without a transposed copy): through the fp32 kernel, W as stored - correct for every shape, never the bench's path
+        res = K.gemm_f32(dy.float(), self.w32, torch.empty(dy.shape[0], self.K, dtype=torch.float32, device=dy.device),
+                         act=ACT_RELU_MASK if relu_mask is not None else ACT_NONE, mask=relu_mask.float() if relu_mask is not None else None)
         if out is None:
-            return K.timed("lib_gemm_dgrad", flops, lambda: torch.mm(dy, w))
-        return K.timed("lib_gemm_dgrad", flops, lambda: torch.mm(dy, w, out=out))
+            return res.to(dy.dtype)
+        if accumulate:
+            out.add_(res.to(out.dtype))
+        else:
+            out.copy_(res)
+        return out
 
     def fused_bias_wgrad(self, dy, x):
         """True when wgrad can also produce the bias gradient (MFMA weight-gradient kernel path)."""
@@ -196,10 +208,10 @@ class Linear:
         M = x.shape[0]
         if dy.dtype == torch.bfloat16 and self.N % 8 == 0 and self.K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
             K.gemm_tn(dy, x, self.gw, accumulate=True, dbias=self.gb if with_bias else None, ws=ws)
-        elif dy.dtype == torch.bfloat16:
-            self.gw.add_(torch.mm(dy.t(), x).float())
-        else:
-            self.gw.addmm_(dy.t(), x)
+        elif dy.dtype == torch.bfloat16:      # odd shapes: through the fp32 kernel
+            K.gemm_f32(dy.float(), x.float(), self.gw, trans_a=True, accumulate=True)
+        else:                                 # parity mode: gw += dy^T x on the fp32 matrix-core kernel (one fixed-order sum per element)
+            K.gemm_f32(dy, x, self.gw, trans_a=True, accumulate=True)
 
     def bgrad(self, dy, ws):
         if self.gb is not None:
@@ -312,16 +324,17 @@ class Engine:
         # Input gradients dX = dY W of the encoder projections run on the own persistent NT kernel, as NT products with
         # transposed bf16 weight copies (one batched transpose launch per step on the side stream, idle during the forward
         # pass), instead of the library GEMM: with the streaming store tail the own kernel is the faster one
-        # (step 3.505 -> 3.428 ms; before that change the two were at parity).  ASR_DGRAD_OWN=0: library GEMM.
+        # (step 3.505 -> 3.428 ms; before that change the two were at parity).
         self._tr_tiles = None
-        if os.environ.get("ASR_DGRAD_OWN", "1") != "0" and flat.lp is not None:
-            # encoder projections only: the decoder's B*To ~ 500 rows are better served by the library's small tiles
-            # (joint config 5.93 ms with its projections on the persistent kernel too, 5.74 with the library)
+        if flat.lp is not None:
+            # encoder projections only: the decoder's B*To ~ 500 rows run on the 64 x 64-tile kernel with W as stored
             lins = [l for mha, ffn in self.enc for l in (mha.qkv, mha.fc, ffn.w1, ffn.w2)]
             # ... and the decoder's cross-attention Q|K|V weights: their K|V half multiplies all B*T encoder frames in the
             # accumulating input gradient d_enc += dK|dV W_kv (the residual-add store tail of the own kernel, no library call)
             cross_qkv = [cross.qkv for _, cross, _ in self.dec] if getattr(self, "dec", None) else []
-            lins = [l for l in lins + cross_qkv if l.N % 64 == 0 and l.K % 8 == 0]
+            # ... and the CTC head (reduction over V = 4232 columns: the kernel's last k-step is ragged)
+            head = [self.ctc_lo] if use_ctc else []
+            lins = [l for l in lins + cross_qkv + head if l.N % 8 == 0 and l.K % 8 == 0]
             flat.lpT = torch.zeros_like(flat.lp)
             tiles = []
             for l in lins:
@@ -637,7 +650,8 @@ class Engine:
         pf, sf = c["drop"]
         dz, dxg = self._ln_bwd(f.ln, f.w2.gb, dy, dy2, c["xhat"], c["rstd"], c["lens"], B, T, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(f.w2, dxg, c["h"])
-        fused_relu = self.fuse_relu_bwd and (f.w2.own_dgrad(dxg) or f.w2.small(dxg, f.w2.N)) and c["h"].is_contiguous() and c["h"].data_ptr() % 16 == 0
+        fused_relu = self.fuse_relu_bwd and (f.w2.own_dgrad(dxg) or f.w2.small(dxg, f.w2.N) or dxg.dtype == torch.float32) and c["h"].is_contiguous() \
+            and c["h"].data_ptr() % 16 == 0
         dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)     # ReLU backward in the GEMM's store tail
         fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
         if not fused_relu:

@@ -523,6 +523,13 @@ def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None, family="gemm_nt"):
     return out
 
 
+def set_option(name, value):
+    """Process-wide tuning switch between correct kernel variants (include/asr_hip.h: asr_set_option); returns the previous value."""
+    prev = ctypes.c_int(0)
+    check(_lib.lib.asr_set_option(name.encode(), int(value), ctypes.byref(prev)), "asr_set_option")
+    return prev.value
+
+
 def deterministic():
     """True when the library's reductions run in a fixed order (asr_set_deterministic / ASR_DETERMINISTIC=1)."""
     return bool(lib.asr_get_deterministic())
@@ -531,6 +538,22 @@ def deterministic():
 def set_deterministic(on):
     """Process-wide switch (see include/asr_hip.h); returns the previous value.  Engines read it when they are built."""
     return bool(lib.asr_set_deterministic(int(bool(on))))
+
+
+def gemm_f32(a, b, out, bias=None, trans_a=False, trans_b=False, act=ACT_NONE, mask=None, accumulate=False):
+    """out (M, N) (+)= act(op(a) @ op(b) + bias) in fp32 on the matrix cores (asr_gemm_f32): a is (M, K), or (K, M) when trans_a;
+    b is (K, N), or (N, K) when trans_b; mask (ACT_RELU_MASK): the activations of the ReLU whose backward this is, laid out like out."""
+    assert a.dtype == b.dtype == out.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    M, N = out.shape
+    K = a.shape[0] if trans_a else a.shape[1]
+    assert a.shape == ((K, M) if trans_a else (M, K)) and b.shape == ((N, K) if trans_b else (K, N)), (a.shape, b.shape, out.shape)
+    _chk_f32(bias)
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.shape == out.shape and mask.stride() == out.stride()
+    timed("gemm_f32", 2.0 * M * N * K, lambda: check(
+        lib.asr_gemm_f32(_p(a), _p(b), _p(bias), _p(mask), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(trans_b), int(act),
+                         int(accumulate), _stream()), "asr_gemm_f32"))
+    return out
 
 
 def gemm_small(a, bm, bias, out, trans_b=False, act=ACT_NONE, mask=None):

@@ -54,9 +54,9 @@ def parse(argv=None):
     ap.add_argument("--window", type=int, default=-1)
     ap.add_argument("--dropout", type=float, default=0.0)
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step instead of eager launches "
-                    "(measured SLOWER on MI355X/ROCm 7: 5.21 vs 4.88 ms CTC-only, 8.81 vs 8.42 ms joint - the step is GPU-bound)")
-    ap.add_argument("--cer", action="store_true", help="joint config: character error rate of the greedy ids in every training step, as the "
-                    "reference's iterate does (on the device: asr_cer)")
+                    "(measured SLOWER than the multi-stream eager step on MI355X/ROCm 7, DESIGN.md section 4 'Streams': the step is GPU-bound)")
+    ap.add_argument("--no-cer", action="store_true", help="joint config: skip the character error rate of the greedy ids that every training step "
+                    "computes by default, as the reference's iterate does (transformer_official.py:83-94; here on the device: asr_cer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (joint model, dropout 0.1)")
@@ -165,24 +165,26 @@ KERNEL_NAMES = {"gemm_nt": "gemm_nt_persist_kernel (asr_gemm_nt_bf16)", "gemm_tn
 class Run:
     """One model + optimizer + batch on this rank, and the timed loop over it."""
 
-    def __init__(self, args, config, dropout, rank, dev, use_dp):
+    def __init__(self, args, config, dropout, rank, dev, use_dp, batch=None, frames=None, window=None):
         import torch
         from asr_chinese_e2e_amd import Models
         from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
         from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
         self.torch, self.args, self.joint, self.use_dp = torch, args, config == "joint", use_dp
+        batch, frames, window = batch or args.batch, frames or args.frames, args.window if window is None else window
         Model = Models.TransformerOffical if self.joint else Models.TransformerCTC
         cfg = Model.get_default_config()()
         cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=dropout, layer_num=args.layers, ctc_weight=0.3 if self.joint else 1.0, dtype="bf16",
-                          attn_window=args.window, cer_in_iterate=args.cer, warm_up=4000))
+                          attn_window=window, cer_in_iterate=self.joint and not args.no_cer, warm_up=4000))
         torch.manual_seed(0)
         self.model = Model(cfg, Vocab.synthetic(args.vocab)).to(dev)
         self.opt = NoamOpt(cfg.d_model, 1, cfg.warm_up, FusedAdam(self.model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
-        self.pack = synthetic_pack(args.batch, args.frames, 80, args.vocab, seed=1234 + rank, device=dev, dtype=torch.bfloat16)
+        self.pack = synthetic_pack(batch, frames, 80, args.vocab, seed=1234 + rank, device=dev, dtype=torch.bfloat16)
         self.runner, self.graphed, self.dp = self.model, False, None
         if use_dp:
             from asr_chinese_e2e_amd import dist as D
             self.runner = self.dp = D.DataParallel(self.model, dev)
+            self.dp.bucketer.measure_exposed = True      # two timing events per step around the final wait for the communication stream
         elif args.graph and dropout == 0.0:
             from asr_chinese_e2e_amd.graph import GraphedModel
             self.runner = GraphedModel(self.model)          # whole step as one hipGraph (single process, no dropout)
@@ -202,6 +204,8 @@ class Run:
     def timed(self, warmup, steps):
         self.steps(warmup)
         self.barrier()
+        if self.dp is not None:
+            self.dp.bucketer.exposed_ms()      # drop the warm-up steps' samples
         t0 = time.perf_counter()
         self.steps(steps)
         self.barrier()
@@ -267,8 +271,22 @@ def main():
     if use_dp:
         from asr_chinese_e2e_amd import dist as D
         os.environ["LOCAL_RANK"] = str(dev_idx)
-        D.init(backend)
-        world = torch.distributed.get_world_size()      # the ranks the process group actually formed
+        # The first N > 1 run on xGMI is also the first execution of the RCCL path anywhere (the build box has one GPU): if the
+        # process group or its first collective fails, say why on stderr and exit non-zero - this process has initialised the
+        # GPU, so it never re-execs or falls back to another backend.
+        try:
+            D.init(backend)
+            world = torch.distributed.get_world_size()      # the ranks the process group actually formed
+            probe = torch.ones(1, device=dev)
+            torch.distributed.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"first all-reduce summed {probe.item()} over a group of {world}")
+        except Exception as e:      # noqa: BLE001 - reported verbatim, then the run ends
+            log(f"rank {rank}: process group / first collective FAILED over backend {backend}: {type(e).__name__}: {e}")
+            log("environment: " + ", ".join(f"{k}={os.environ.get(k)}" for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                                  "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")))
+            raise SystemExit(3)
 
     run = Run(args, config, args.dropout, rank, dev, use_dp)
     log(f"rank {rank}/{world}: {config} model on {dev}, warm-up {args.warmup} steps")
@@ -285,8 +303,13 @@ def main():
     joint, graphed = run.joint, run.graphed
     wire = None
     if run.dp is not None:
+        # comm_exposed_ms: time per step the compute stream waited for the communication stream AFTER backward had finished (HIP
+        # events around GradBucketer.finish()'s wait; mean over the timed steps, MAX over ranks) = all-reduce time backward did not hide
+        ex = torch.tensor([run.dp.bucketer.exposed_ms(reset=False) or 0.0], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(ex, op=torch.distributed.ReduceOp.MAX)
         wire = {"bytes_per_step": run.dp.bucketer.bytes_on_wire, "buckets": len(run.dp.bucketer.buckets),
-                "dtype": "bf16" if run.dp.bucketer.wire is not None else "fp32", "backend": backend}
+                "dtype": "bf16" if run.dp.bucketer.wire is not None else "fp32", "backend": backend, "comm_exposed_ms": float(ex)}
 
     extras = {}
     if world == 1 and not use_dp and not args.no_extras and rank == 0:
@@ -308,6 +331,18 @@ def main():
             extras["dropout_0.1_utterances_per_s"] = args.batch * es / d3
             del r3
             torch.cuda.empty_cache()
+        # BASELINE.json configs[4] per GPU: long-form utterances (T = 2000 frames, +-50-frame attention band, batch 8), joint model
+        r4 = Run(args, "joint", args.dropout, rank, dev, False, batch=8, frames=2000, window=50)
+        d4 = r4.timed(ew, es)
+        extras["long_form_ms_per_step"] = 1e3 * d4 / es
+        extras["long_form_utterances_per_s"] = 8 * es / d4
+        extras["long_form_config"] = "configs[4] per GPU: joint CTC/attention, B=8, T=2000, attention band +-50 frames, bf16"
+        if not args.no_kernel_timer:
+            ks = r4.kernel_pass(min(es, 5))
+            extras["long_form_kernels"] = {k: {"avg_us": v["avg_us"], "launches_per_step": v["launches"] / min(es, 5)}
+                                           for k, v in ks.items() if k in ("sdpa_fwd", "sdpa_bwd", "ctc", "gemm_nt", "gemm_tn")}
+        del r4
+        torch.cuda.empty_cache()
         log(f"extras: {extras}")
 
     if rank == 0:
@@ -317,13 +352,13 @@ def main():
             "metric": "training throughput (utterances/s; frames/s = x T), AISHELL-1-shaped 80-mel T=500",
             "value": utt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic", "ranks_formed": world,
             "frames_per_s": utt * args.frames, "final_loss": loss,
             "config": {"workload": (("configs[3]: data-parallel " if world > 1 else "configs[2]: ") + "joint CTC/attention (lambda=0.3) encoder-decoder" if joint else
                                     "configs[1]: 6-layer Transformer encoder + CTC-only") +
                                    f", bf16, per-GPU batch {args.batch}, T={args.frames}, F=80, V={args.vocab}, "
                                    f"{args.layers} layers, d_model 512, 8x64 heads, ff 1024, dropout {args.dropout}, "
-                                   "fwd+loss+bwd+" + ("bucketed gradient all-reduce+" if use_dp else "") + "clip+Noam/Adam per step" +
+                                   "fwd+loss+" + ("CER+" if joint and not args.no_cer else "") + "bwd+" + ("bucketed gradient all-reduce+" if use_dp else "") + "clip+Noam/Adam per step" +
                                    (", one hipGraph per step" if graphed else ", eager launches"),
                        "global_batch": world * args.batch, "seq_len": args.frames, "parallelism": f"dp{world}"},
         }

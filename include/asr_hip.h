@@ -69,6 +69,11 @@ int asr_stream_fork(void* from_stream, void* to_stream);
  * offers (weight-gradient stream: off the critical path of the step), 0 = default, > 0 = the highest.  Lives as long as the
  * process.  (The reference has one stream, trainer11.py:73-74; torch.cuda.Stream offers no low priority.) */
 int asr_stream_create(int priority, void** out_stream);
+/* Tuning options: process-wide integer switches between CORRECT variants of a kernel (every value gives correct results), settable at
+ * run time so that two variants can be timed alternately inside one process.  Names: "nt_store" (store policy of the NT GEMM's output tile:
+ * 0 nt, 1 sc1 write-through, 2 plain, 3 sc0 sc1), "nt_tile", "ln_store", "sdpa_store", "tn_cfg".  Initial values: ASR_OPT_<NAME>
+ * in the environment, else the defaults.  previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
+int asr_set_option(const char* name, int value, int* previous);
 int asr_get_deterministic(void);
 int asr_set_deterministic(int on);
 
@@ -355,6 +360,16 @@ int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void
  * backward this is).  All bf16, fp32 accumulation; N, K, lda, ldb multiples of 8. */
 int asr_gemm_small_bf16(const void* A, const void* Bm, const float* bias, const void* mask, void* C, int M, int N, int K,
                         int lda, int ldb, int ldc, int trans_b, int act, void* stream);
+/* fp32 projections on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains): every GEMM of the PARITY mode (dtype fp32),
+ * which is what the tests compare with the reference's own CPU outputs - nn.Linear / Conv1d(k=1) forward, input gradient and weight
+ * gradient of attention.py:43-45,59, module.py:70-71, transformer_official.py:176,321 - and the odd shapes the bf16 kernels refuse.
+ *   C (M, N) ldc  (+)=  act( opA (M, K) * opB (K, N) + bias (N) )
+ *   trans_a = 0: A stored (M, K) lda;  1: A stored (K, M) lda      trans_b = 0: B stored (K, N) ldb;  1: B stored (N, K) ldb
+ *   forward y = x W^T + b: (0, 1);  input gradient dx = dy W: (0, 0);  weight gradient dW += dy^T x: (1, 0) with accumulate = 1.
+ * act: ASR_ACT_NONE / ASR_ACT_RELU / ASR_ACT_RELU_MASK (C = 0 where mask <= 0; mask (M, N) ldc f32); accumulate != 0: C += result.
+ * The reduction is never split across workgroups: results are deterministic (same bits every run) in either mode. */
+int asr_gemm_f32(const float* A, const float* B, const float* bias, const float* mask, float* C, int M, int N, int K,
+                 int lda, int ldb, int ldc, int trans_a, int trans_b, int act, int accumulate, void* stream);
 /* Projection + residual + LayerNorm in ONE kernel (N must be 512 = d_model: a workgroup owns whole rows):
  *   y = LN(A W^T + bias + res) * gamma + beta, rows t >= lens[b] zeroed (lens may be NULL); xhat, rstd as asr_add_ln_fwd.
  * Replaces:  fc -> (dropout) -> layer_norm(out + residual) -> *= non_pad_mask      attention.py:59-60, transformer_official.py:208

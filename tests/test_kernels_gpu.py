@@ -471,7 +471,10 @@ def test_optimizer(K, ws):
 @pytest.mark.parametrize("M,N,K_,act,use_bias,use_res", [(256, 128, 64, 0, True, False), (1000, 512, 80, 0, True, False),
                                                           (333, 1536, 512, 0, True, False), (512, 4232, 512, 0, False, False),
                                                           (640, 1024, 512, 1, True, False), (384, 512, 1024, 0, True, True),
-                                                          (130, 40, 24, 1, True, True)])
+                                                          (130, 40, 24, 1, True, True),
+                                                          # reduction length a multiple of 8 but not of 64 (the CTC head's input gradient reduces
+                                                          # over V = 4232): the persistent kernel pads its last k-step from a zero page
+                                                          (1000, 512, 4232, 0, False, False), (300, 256, 136, 0, True, False), (512, 640, 200, 0, True, False)])
 def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     torch.manual_seed(M + N)
     a = torch.randn(M, K_).bfloat16()
@@ -490,9 +493,92 @@ def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     close(out, ref, rtol=1e-2, atol=1e-2, what="gemm_nt")
 
 
+@pytest.mark.parametrize("M,N,K_,act,use_bias", [(256, 256, 128, 0, True), (1000, 1024, 512, 1, True), (300, 4232, 512, 0, True), (777, 520, 192, 0, False),
+                                                 (16000, 1024, 512, 1, True), (16000, 4232, 512, 0, True)])
+def test_gemm_nt_wide_tiles(K, M, N, K_, act, use_bias):
+    """The 256 x 256-tile form of the persistent NT GEMM (gemm_nt_wide_kernel; chosen by shape for w_1, the w_2 input gradient and the
+    CTC head, forced here through the tuning option): edge tiles in M and N, ragged N = 4232, bias, ReLU - against the fp64 product
+    and, element for element, against the 256 x 128 form (same k order, same accumulation: identical bits)."""
+    torch.manual_seed(M + N + K_)
+    a = torch.randn(M, K_, device=DEV).bfloat16()
+    w = (torch.randn(N, K_, device=DEV) * 0.1).bfloat16()
+    bias = torch.randn(N, device=DEV) if use_bias else None
+    outs = {}
+    for tile in (2, 1):
+        prev = K.set_option("nt_tile", tile)
+        try:
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            K.gemm_nt(a, w, bias, out, act)
+            outs[tile] = out
+        finally:
+            K.set_option("nt_tile", prev)
+    rows = slice(None) if M <= 2000 else torch.cat([torch.arange(0, 700), torch.arange(M - 700, M)]).to(DEV)      # fp64 check on the first / last rows of the big cases
+    ref = a[rows].double() @ w.double().t()
+    if use_bias:
+        ref = ref + bias.double()
+    if act:
+        ref = torch.relu(ref)
+    close(outs[2][rows], ref, rtol=1e-2, atol=1e-2, what="gemm_nt wide")
+    assert torch.equal(outs[2], outs[1]), float((outs[2].float() - outs[1].float()).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K_,ta,tb,act,acc,bias", [
+    (420, 512, 80, False, True, 0, False, True),       # forward x W^T + b (linear_in of the d_model 512 golden case)
+    (420, 1024, 512, False, True, 1, False, True),     # forward with ReLU (w_1)
+    (420, 512, 1536, False, False, 0, False, False),   # input gradient dy W (qkv)
+    (420, 1024, 512, False, False, 2, False, False),   # input gradient through the ReLU mask (w_2)
+    (1536, 512, 420, True, False, 0, True, False),     # weight gradient dW += dy^T x
+    (96, 32, 20, False, True, 0, False, True),         # toy widths of the small goldens
+    (28, 30, 32, False, True, 0, False, False),        # tied output projection, V = 30
+    (28, 32, 30, False, False, 0, True, False),        # its input gradient: reduction over V = 30 (not a multiple of 4), accumulate
+    (21, 48, 36, True, False, 0, True, False),         # odd everything
+    (70, 50, 66, True, True, 0, False, True),          # both operands transposed
+    (1, 1, 1, False, True, 0, False, True),
+])
+def test_gemm_f32(K, M, N, K_, ta, tb, act, acc, bias):
+    """asr_gemm_f32 (fp32 on the matrix cores: every projection of the parity mode) against the fp64 product: all four operand
+    layouts, bias, ReLU, ReLU-mask store tail, accumulation into C, shapes with nothing a multiple of 4, strided views; and the
+    same call twice gives the same bits (the reduction is never split)."""
+    torch.manual_seed(M * 7 + N * 3 + K_)
+    a = torch.randn((K_, M) if ta else (M, K_), device=DEV)
+    b = torch.randn((N, K_) if tb else (K_, N), device=DEV) * 0.3
+    bv = torch.randn(N, device=DEV) if bias else None
+    c0 = torch.randn(M, N, device=DEV)
+    mask = torch.relu(torch.randn(M, N, device=DEV)) if act == 2 else None
+    if mask is not None:
+        mask[::3, ::2] = -0.0
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    if bias:
+        ref = ref + bv.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    if act == 2:
+        ref = ref * (mask.double() > 0)
+    if acc:
+        ref = ref + c0.double()
+    scale = float(ref.abs().max()) + 1e-30
+    outs = []
+    for _ in range(2):
+        out = c0.clone() if acc else torch.full((M, N), float("nan"), device=DEV)
+        K.gemm_f32(a, b, out, bias=bv, trans_a=ta, trans_b=tb, act=act, mask=mask, accumulate=acc)
+        outs.append(out)
+    close(outs[0], ref, rtol=1e-5, atol=2e-6 * scale, what="gemm_f32")
+    assert torch.equal(outs[0], outs[1])
+    if act == 2:
+        assert bool((outs[0][mask <= 0] == (c0[mask <= 0] if acc else 0)).all())
+    # column-slice views of wider buffers (the fused Q|K|V buffer): leading dimensions larger than the rows
+    if not ta and not tb and N >= 8 and K_ >= 8:
+        wide_a = torch.randn(M, K_ + 24, device=DEV)
+        wide_c = torch.full((M, N + 8), float("nan"), device=DEV)
+        K.gemm_f32(wide_a[:, 8:8 + K_], b, wide_c[:, 4:4 + N])
+        close(wide_c[:, 4:4 + N], wide_a[:, 8:8 + K_].double() @ b.double(), rtol=1e-5, atol=2e-6 * scale, what="gemm_f32 views")
+        assert bool(torch.isnan(wide_c[:, :4]).all()) and bool(torch.isnan(wide_c[:, 4 + N:]).all())
+
+
 @pytest.mark.parametrize("M,N,K_,trans_b,act", [(544, 512, 512, False, 0), (544, 1536, 512, False, 0), (544, 1024, 512, False, 1), (544, 512, 1024, False, 0),
                                                  (544, 512, 1536, True, 0), (544, 1024, 512, True, 0), (544, 512, 1024, True, 2), (37, 40, 24, False, 0),
-                                                 (70, 264, 136, True, 2), (1000, 4232, 512, False, 0)])
+                                                 (70, 264, 136, True, 2), (1000, 4232, 512, False, 0),
+                                                 (544, 512, 4232, True, 0)])      # input gradient of the tied output projection: reduction over V
 def test_gemm_small(K, M, N, K_, trans_b, act):
     """Small-M projections of the decoder: forward (x W^T + bias, ReLU) and input gradient (dy W from the weight as stored, ReLU mask in
     the store tail) against the fp64 product of the bf16-rounded operands."""

@@ -546,3 +546,40 @@ def test_data_parallel_two_ranks_with_deferred_weight_gradients(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} dp2 ok" in o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["ctc", "joint"])
+def test_graphed_step_matches_eager(mode):
+    """graph.GraphedModel (the whole step - forward, losses, backward on the compute + weight-gradient streams, clip, Noam/Adam -
+    captured once per batch shape and replayed; `bench.py --graph`) follows the eager model: same losses over three steps, and
+    parameters within a few learning rates (Adam, eps 1e-9, turns the atomics-order round-off of near-zero gradients into +-lr).
+    Round-2 advice: the path had no test, and the joint model's stream joins must not touch non-capturing streams while capturing."""
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+    from asr_chinese_e2e_amd.graph import GraphedModel
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+
+    def build():
+        torch.manual_seed(3)
+        M = Models.TransformerOffical if mode == "joint" else Models.TransformerCTC
+        cfg = M.get_default_config()()
+        cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=2, dropout=0.0, ctc_weight=0.3 if mode == "joint" else 1.0, dtype="bf16"))
+        m = M(cfg, Vocab.synthetic(60)).cuda()
+        return m, NoamOpt(512, 1, 10, FusedAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+
+    pack = synthetic_pack(4, 96, 80, 60, seed=6, ragged=True, Lmin=3, Lmax=9, device="cuda", dtype=torch.bfloat16)
+    m1, o1 = build()
+    m2, o2 = build()
+    g = GraphedModel(m2)
+    for step in range(3):
+        a, _ = m1.iterate(pack, optimizer=o1)
+        b, _ = g.iterate(pack, optimizer=o2)
+        torch.cuda.synchronize()
+        assert abs(float(a.loss) - float(b.loss)) < 2e-3 * abs(float(a.loss)), (step, float(a.loss), float(b.loss))
+        assert o1._step == o2._step and abs(o1._rate - o2._rate) < 1e-12
+    assert len(g.graphs) == 1
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        d = (p.detach() - q.detach()).abs()
+        assert float(d.max()) <= 3 * 3 * o1._rate, (n, float(d.max()), o1._rate)
+        assert float((d > 1e-6 + 1e-3 * q.detach().abs()).float().mean()) < 0.05, n

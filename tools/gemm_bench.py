@@ -8,6 +8,8 @@ from asr_chinese_e2e_amd import kernels as K
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 M = int(os.environ.get("BENCH_M", "16000"))
 SHAPES = [(1536, 512, "qkv"), (512, 512, "fc"), (1024, 512, "w1"), (512, 1024, "w2"), (4232, 512, "ctc_lo")]
+if which == "nt":
+    SHAPES = SHAPES + [(512, 4232, "ctc_dx"), (512, 1536, "qkv_dx")]      # input gradients as NT products with transposed weight copies
 
 
 def timeit(fn, reps=30):

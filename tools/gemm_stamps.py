@@ -3,11 +3,12 @@ per workgroup: start, barrier passage of the first 12 k-steps, end of first tile
 s_memrealtime ticks are 10 ns."""
 import os, sys
 os.environ.setdefault("ASR_GEMM_DBG", "5")
+os.environ.setdefault("ASR_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "asr_chinese_e2e_amd", "libasr_hip_dbg.so"))      # `make -C asr_chinese_e2e_amd/csrc debug`
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from asr_chinese_e2e_amd import kernels as K
 M = 16000
-for N, Kd, name in [(512, 512, "fc"), (1536, 512, "qkv"), (512, 1024, "w2")]:
+for N, Kd, name in [(512, 512, "fc"), (1536, 512, "qkv"), (1024, 512, "w1"), (512, 1024, "w2"), (4232, 512, "ctc_lo")]:
     x = torch.randn(M, Kd, device="cuda").bfloat16(); w = (torch.randn(N, Kd, device="cuda") * 0.05).bfloat16()
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     st = torch.zeros(256 * 16 * 2, device="cuda", dtype=torch.float32)   # 256 x 16 uint64
