@@ -40,6 +40,26 @@ class LnReduceItem(ctypes.Structure):
 
 LN_REDUCE_MAX = 16
 
+
+class DecLayerPlan(ctypes.Structure):
+    """asr_dec_layer_plan of include/asr_hip.h (same field order)."""
+    _fields_ = ([(n, I) for n in ("B", "To", "T", "d", "H", "dk", "ff")] + [("drop_p", F), ("seed", U * 5), ("ld_kv_c_T", I)] +
+                [(n, P) for n in ("dec_len", "cross_len",
+                                  "w_qkv_s", "w_fc_s", "w_q_c", "w_fc_c", "w_1", "w_2",
+                                  "b_qkv_s", "b_fc_s", "b_q_c", "b_fc_c", "b_1", "b_2",
+                                  "g_s", "be_s", "g_c", "be_c", "g_f", "be_f",
+                                  "w_kv_c_T", "x_in",
+                                  "qkv_s", "ctx_s", "a_s", "y_s", "lse_s", "rstd_s",
+                                  "q_c", "kv_c", "kv_ready_event",
+                                  "ctx_c", "a_c", "y_c", "lse_c", "rstd_c",
+                                  "h", "o", "y_f", "rstd_f",
+                                  "dz_f", "g_o", "g_h", "dx_f",
+                                  "dz_c", "g_ac", "g_qc", "g_kvc", "dx_c",
+                                  "dz_s", "g_as", "g_qkv", "dx_s",
+                                  "dctx", "gb_2", "gb_fc_c", "gb_fc_s",
+                                  "part_f", "part_c", "part_s", "delta")] +
+                [("delta_bytes", Z), ("d_enc", P)])
+
 # name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
 SIGNATURES = {
     "asr_abi_version": (I, []),
@@ -54,7 +74,8 @@ SIGNATURES = {
     "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, F, U, I, I, P]),
     "asr_add_ln_bwd_reduce_batched": (I, [P, I, I, P]),
     "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
-    "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
+    "asr_sdpa_bwd_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),
+    "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, Z, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
     "asr_dropout_mask": (I, [P, I, I, F, U, P]),
     "asr_sdpa_dropout_mask": (I, [P, I, I, I, I, F, U, P]),
     "asr_ctc_workspace_bytes": (Z, [I, I, I]),
@@ -85,6 +106,8 @@ SIGNATURES = {
     "asr_gemm_small_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "asr_gemm_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "asr_gemm_nt_add_ln_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "asr_decoder_layer_fwd": (I, [P, P]),
+    "asr_decoder_layer_bwd": (I, [P, P, P, P, P]),
     "asr_gemm_tn_workspace_bytes": (Z, [I, I, I]),
     "asr_gemm_tn_bf16": (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P]),
     "asr_gemm_tn_bias_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, P, Z, P]),

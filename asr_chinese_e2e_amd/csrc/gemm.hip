@@ -1797,8 +1797,12 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         // they stay selectable through ASR_GEMM_CFG for A/B runs)
         // default: the persistent 8-wave kernel (tools/gemm_bench.py on the config-2 shapes, us:
         // 38.4 / 17.4 / 27.0 / 23.8 / 116.8 vs 46.2 / 19.4 / 32.1 / 27.1 / 130.0 for 128 x 128 ring 2)
-        const int tile_opt = asr_option(ASR_OPT_NT_TILE);      // 0 = by shape, 1 = always 256 x 128, 2 = 256 x 256 whenever the shape allows
-        if (cfg == 0 && dbg == 0 && N % 8 == 0 && tile_opt != 1 && (tile_opt == 2 ? (K % WBK == 0 && K >= 2 * WBK && N >= 256) : nt_wide_pays(M, N, K))) {
+        // tuning option "nt_tile": 0 = always 256 x 128 (default), 2 = 256 x 256 whenever the shape allows, 3 = 256 x 256 where nt_wide_pays().
+        // Measured (round 3): the wide tile is no faster alone (w_1: 26.3 vs 27.0 us; CTC head 111 vs 117) - its ring of two leaves the
+        // L2 -> LDS stream idle between a step's last landing and the next step's first issue - and SLOWER beside other streams (the joint
+        // model's K|V projections: 41 vs 26 us), step 3.416 vs 3.423 ms: kept as an option, not the default.
+        const int tile_opt = asr_option(ASR_OPT_NT_TILE);
+        if (cfg == 0 && dbg == 0 && N % 8 == 0 && tile_opt >= 2 && (tile_opt == 2 ? (K % WBK == 0 && K >= 2 * WBK && N >= 256) : nt_wide_pays(M, N, K))) {
             if (act == ASR_ACT_RELU) launch_nt_wide<ASR_ACT_RELU>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
             else launch_nt_wide<ASR_ACT_NONE>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
         } else

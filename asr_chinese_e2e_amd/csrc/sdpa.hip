@@ -789,13 +789,22 @@ __device__ __forceinline__ uint32_t scale_bf16_pair(uint32_t x, float f) {
     return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
 }
 
-template <bool DROP, bool MASKED>
+template <bool DROP, bool MASKED, bool BAND = false>
 __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                          const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const float* __restrict__ lse,
                                                                          bf16_t* __restrict__ dq, bf16_t* __restrict__ dk_, bf16_t* __restrict__ dv,
                                                                          const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
-                                                                         int causal, int window, float scale, uint32_t dseed, uint32_t dthr, float dscale) {
+                                                                         int causal, int window, float scale, uint32_t dseed, uint32_t dthr, float dscale,
+                                                                         float* __restrict__ halo = nullptr, int halo_slots = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_fb[];
+    // BAND (self-attention inside a +-window band over MORE keys than one workgroup holds: the long-form configuration, T = 2000):
+    // blockIdx.y = key block of FB_KEYS keys.  The workgroup owns the dK / dV of its keys and walks only the query tiles whose band
+    // touches them; per tile only the waves whose 64 keys lie in the band work, and the dQ product runs over those waves' keys.
+    // A query tile near a block boundary gets dQ contributions from TWO workgroups: each writes its fp32 partial to a slab of
+    // `halo` and sdpa_band_halo_kernel adds the two (fixed order, no atomics); tiles of one block store bf16 dQ directly.
+    const int kblk0 = BAND ? (int)blockIdx.y * FB_KEYS : 0;      // first key of this workgroup's block
+    const int Tkg = Tk;                                          // keys of the head; Tk below = keys of this block
+    if (BAND) Tk = min(FB_KEYS, Tkg - kblk0);
     bf16_t* Kimg = (bf16_t*)smem_fb;
     bf16_t* dSimg = (bf16_t*)(smem_fb + FB_K_BYTES);                               // two buffers of FB_KEYS x 32
     bf16_t* tiles = (bf16_t*)(smem_fb + FB_K_BYTES + 2 * FB_DS_BYTES);
@@ -806,10 +815,11 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
     const bf16_t* dob = d_o + (size_t)b * Tq * ldo + h * DK;
     const bf16_t* ob = o + (size_t)b * Tq * ldo + h * DK;
-    const bf16_t* kb = k + (size_t)b * Tk * ldk + h * DK;
-    const bf16_t* vb = v + (size_t)b * Tk * ldv + h * DK;
+    const bf16_t* kb = k + ((size_t)b * Tkg + kblk0) * ldk + h * DK;
+    const bf16_t* vb = v + ((size_t)b * Tkg + kblk0) * ldv + h * DK;
     const float* lseb = lse + ((size_t)b * H + h) * Tq;
-    const int klen = min(k_len ? k_len[b] : Tk, Tk);
+    const int klen_g = min(k_len ? k_len[b] : Tkg, Tkg);       // valid keys of the head
+    const int klen = BAND ? max(0, min(klen_g - kblk0, Tk)) : klen_g;      // ... of this block (block-local index)
     const int kk0 = 64 * w;
     const bool active = kk0 < Tk;                 // wave-uniform: this wave owns keys of the head
     const int nks = (Tk + 31) >> 5;               // 32-key steps of the dQ product
@@ -912,6 +922,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     // ---- the two halves of a tile's work
     auto phase_keys = [&](int t) {      // S, dP, P, dS, dV^T, dK^T of this wave's keys against query tile t; dS -> image t & 1
         const int buf = t & 1, qt0 = t * FB_QT;
+        if (BAND && (kblk0 + kk0 > qt0 + FB_QT - 1 + window || kblk0 + kk0 + 63 < qt0 - window)) return;      // none of this wave's keys is in the tile's band
         const bf16_t* Qt = tiles + buf * 2 * FB_TILE_ELEMS;
         const bf16_t* Dt = Qt + FB_TILE_ELEMS;
         const float* s_l = stats + buf * 64;
@@ -938,11 +949,12 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Dt, 0, ks, lane), vf[kbk][ks], dp, 0, 0, 0);
             }
             if (MASKED) {
-                const bool need = (causal && key0 + 31 > qt0) || (window >= 0 && (key0 + 31 - qt0 > window || qt0 + 31 - key0 > window));
+                const int gk0 = kblk0 + key0;
+                const bool need = (causal && gk0 + 31 > qt0) || (window >= 0 && (gk0 + 31 - qt0 > window || qt0 + 31 - gk0 > window));
                 if (need) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        if (!visible(qt0 + acc_row(i, lane), kj, klen, causal, window)) st[i] = -1.0e30f;
+                        if (!visible(qt0 + acc_row(i, lane), kblk0 + kj, klen_g, causal, window)) st[i] = -1.0e30f;
                 }
             }
 #pragma unroll
@@ -954,7 +966,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                 // neighbour (8 hashes + 8 lane swaps per 16 elements instead of 16 hashes: 3 integer multiplies each)
                 uint32_t hsh[4] = {0u, 0u, 0u, 0u};
                 if (DROP) {
-                    const uint32_t kcl = (uint32_t)min(kj, Tk - 1), tkp = (uint32_t)((Tk + 1) & ~1), bhq = ((uint32_t)(b * H + h)) * Tq;
+                    const uint32_t kcl = (uint32_t)min(kblk0 + kj, Tkg - 1), tkp = (uint32_t)((Tkg + 1) & ~1), bhq = ((uint32_t)(b * H + h)) * Tq;
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
                         const int em = e + (lane & 1);
@@ -970,7 +982,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                     const int i = 4 * g4 + e;
                     const float p = __builtin_amdgcn_exp2f(st[i]);
                     if (DROP) {
-                        const float keepf = drop_keep(hsh[e], min(kj, Tk - 1) & 1, dthr) ? dscale : 0.f;
+                        const float keepf = drop_keep(hsh[e], min(kblk0 + kj, Tkg - 1) & 1, dthr) ? dscale : 0.f;
                         dp[i] = p * (dp[i] * keepf + d4[e]);     // dS / scale (d4 = -delta)
                         st[i] = p * keepf;                       // dropped probabilities feed dV
                     } else {
@@ -1000,6 +1012,22 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         const int buf = t & 1, qt0 = t * FB_QT;
         f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const bf16_t* dSr = dSimg + buf * (FB_DS_BYTES / 2);
+        if (BAND) {      // only the waves that ran the key phase of this tile wrote dS rows: the product runs over their keys
+            const int wv_lo = max(0, qt0 - window - kblk0) >> 6, wv_hi = min(min(qt0 + FB_QT - 1 + window, kblk0 + Tk - 1) - kblk0, FB_KEYS - 1) >> 6;
+            for (int wv = wv_lo; wv <= wv_hi; ++wv) {
+                bf16x8 ka[2], da[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ka[u] = frag_tr16<TS>(Kimg, 32 * (2 * wv + u), d0, lane);
+                    const bf16_t* pr = dSr + 32 * (2 * wv + u) * FB_QT;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[0]));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[1]));
+                    da[u] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[0], da[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[1], da[1], acc1, 0, 0, 0);
+            }
+        } else
         for (int s4 = 0; s4 < nks; s4 += 4) {     // rows past the last key: K rows and dS rows are zeros
             bf16x8 ka[4], da[4];
 #pragma unroll
@@ -1016,6 +1044,20 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[3], da[3], acc1, 0, 0, 0);
         }
         const int qi = qt0 + q0l + (lane & 15);     // accumulator: column = query, rows = d0 + 4 (l >> 4) + r
+        if (BAND) {
+            // key blocks whose keys the tile's band touches: one -> this workgroup has the whole sum; two -> fp32 partial to the slab
+            const int jl = max(qt0 - window, 0) / FB_KEYS, jh = min(qt0 + FB_QT - 1 + window, Tkg - 1) / FB_KEYS;
+            if (jl != jh) {
+                const int nbnd = (int)gridDim.y - 1, side = (int)blockIdx.y == jh ? 1 : 0;
+                const int t_first = max(0, (FB_KEYS * (jl + 1) - (FB_QT - 1) - window + FB_QT - 1) / FB_QT);
+                float* dst = halo + ((((size_t)bh * nbnd + jl) * 2 + side) * halo_slots + (t - t_first)) * (FB_QT * DK);
+                f32x4_t pv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pv[e] = (acc0[e] + acc1[e]) * LN2;
+                *(f32x4_t*)(dst + (q0l + (lane & 15)) * DK + d0 + 4 * (lane >> 4)) = pv;
+                return;
+            }
+        }
         if (qi < Tq) {
             bf16x4 ov;       // K was staged times scale * log2(e): dQ = scale dS K = dS K' / log2(e)
 #pragma unroll
@@ -1024,19 +1066,22 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         }
     };
 
-    FB_PREFETCH(0);
-    FB_COMMIT(0);
-    if (ntiles > 1) FB_PREFETCH(FB_QT);
-    __syncthreads();         // K image, zeroed dS images, tile 0
+    // BAND: the query tiles whose band [qt0 - window, qt0 + 31 + window] touches this block's keys
+    const int t_lo = BAND ? max(0, (kblk0 - (FB_QT - 1) - window + FB_QT - 1) / FB_QT) : 0;
+    const int t_hi = BAND ? min(ntiles, (kblk0 + Tk + window + FB_QT - 1) / FB_QT) : ntiles;
+    FB_PREFETCH(t_lo * FB_QT);
+    FB_COMMIT(t_lo & 1);
+    if (t_lo + 1 < t_hi) FB_PREFETCH((t_lo + 1) * FB_QT);
+    __syncthreads();         // K image, zeroed dS images, first tile
     // One barrier per tile.  Before barrier t: key phase of tile t (writes dS image t & 1, last read by the dQ block of
     // tile t - 2, i.e. before barrier t - 1) and the store of tile t + 1 into tile buffer (t + 1) & 1 (last read by the key
     // phase of tile t - 1).  After it: the dQ block of tile t, while other waves already run the key phase of tile t + 1.
     // (Giving the two waves of a SIMD opposite phase orders through a wave-uniform switch was 10 us SLOWER: 92 vs 82.)
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         if (active) phase_keys(t);
-        if (t + 1 < ntiles) FB_COMMIT((t + 1) & 1);
+        if (t + 1 < t_hi) FB_COMMIT((t + 1) & 1);
         __syncthreads();
-        if (t + 2 < ntiles) FB_PREFETCH((t + 2) * FB_QT);
+        if (t + 2 < t_hi) FB_PREFETCH((t + 2) * FB_QT);
         phase_dq(t);
     }
 #undef FB_PREFETCH
@@ -1044,10 +1089,34 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     if (active) {
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
-            store_rows_T(dka[kbk], scale, dk_ + (size_t)b * Tk * ldk + h * DK, ldk, kk0 + 32 * kbk, Tk, lane);
-            store_rows_T(dva[kbk], 1.f, dv + (size_t)b * Tk * ldv + h * DK, ldv, kk0 + 32 * kbk, Tk, lane);
+            store_rows_T(dka[kbk], scale, dk_ + ((size_t)b * Tkg + kblk0) * ldk + h * DK, ldk, kk0 + 32 * kbk, Tk, lane);
+            store_rows_T(dva[kbk], 1.f, dv + ((size_t)b * Tkg + kblk0) * ldv + h * DK, ldv, kk0 + 32 * kbk, Tk, lane);
         }
     }
+}
+
+// Sum of the two fp32 dQ partials of the query tiles that straddle a key-block boundary of sdpa_bwd_fused_bf16_kernel<.., BAND>
+// (side 0 = the lower block's keys, then side 1: a fixed order) -> bf16 dQ rows.  grid (slots, boundaries, B * H), 256 threads.
+__global__ __launch_bounds__(256) void sdpa_band_halo_kernel(const float* __restrict__ halo, bf16_t* __restrict__ dq, int H, int Tq, int Tk, int ldq, int window,
+                                                             int halo_slots) {
+    const int slot = blockIdx.x, bnd = blockIdx.y, bh = blockIdx.z, nbnd = gridDim.y;
+    const int t_first = max(0, (FB_KEYS * (bnd + 1) - (FB_QT - 1) - window + FB_QT - 1) / FB_QT);
+    const int t = t_first + slot, qt0 = t * FB_QT;
+    if (qt0 >= Tq) return;
+    const int jl = max(qt0 - window, 0) / FB_KEYS, jh = min(qt0 + FB_QT - 1 + window, Tk - 1) / FB_KEYS;
+    if (jl != bnd || jh != bnd + 1) return;      // not a tile shared across this boundary
+    const float* s0 = halo + ((((size_t)bh * nbnd + bnd) * 2 + 0) * halo_slots + slot) * (FB_QT * DK);
+    const float* s1 = s0 + (size_t)halo_slots * (FB_QT * DK);
+    const int b = bh / H, h = bh - b * H;
+    const int row = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+    const int qi = qt0 + row;
+    if (qi >= Tq) return;
+    float x[8], y[8];
+    load8<float>(s0 + row * DK + c8, x);
+    load8<float>(s1 + row * DK + c8, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+    store8<bf16_t>(dq + ((size_t)b * Tq + qi) * ldq + h * DK + c8, x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1259,12 +1328,30 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
     return ASR_OK;
 }
 
-extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, void* dq, void* dk_,
-                            void* dv, const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk, int ldv, int ldo, int causal, int window,
-                            float scale, float drop_p, uint32_t dseed, int dtype, void* stream) {
+// single-pass band kernel: bf16 MFMA shapes, self-attention (Tq == Tk) inside a +-window band, more keys than one workgroup holds,
+// and the band of a 32-query tile touches at most two 512-key blocks
+static bool sdpa_band_shape(int Tq, int Tk, int dk, int causal, int window, int dtype) {
+    return dtype == ASR_BF16 && dk == DK && Tq == Tk && Tk > FB_KEYS && !causal && window >= 0 && 2 * window + FB_QT <= FB_KEYS;
+}
+static int sdpa_band_slots(int window) { return (2 * window + FB_QT - 1) / FB_QT + 2; }
+
+extern "C" size_t asr_sdpa_bwd_workspace_bytes(int B, int H, int Tq, int Tk, int dk, int causal, int window, int dtype) {
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
+    size_t need = (size_t)B * H * Tq * sizeof(float);
+    if (sdpa_band_shape(Tq, Tk, dk, causal, window, dtype)) {
+        const size_t halo = (size_t)B * H * (ceil_div(Tk, FB_KEYS) - 1) * 2 * sdpa_band_slots(window) * FB_QT * DK * sizeof(float);
+        if (halo > need) need = halo;
+    }
+    return need;
+}
+
+extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, size_t delta_bytes,
+                            void* dq, void* dk_, void* dv, const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk, int ldv, int ldo,
+                            int causal, int window, float scale, float drop_p, uint32_t dseed, int dtype, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk_ || !dv) ASR_FAIL(ASR_EINVAL, "asr_sdpa_bwd: null pointer");
     if (int rc = check_common("asr_sdpa_bwd", B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo)) return rc;
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_sdpa_bwd: dtype %d", dtype);
+    if (delta_bytes < (size_t)B * H * Tq * sizeof(float)) ASR_FAIL(ASR_EWORKSPACE, "asr_sdpa_bwd: scratch of %zu bytes, need at least B*H*Tq floats = %zu", delta_bytes, (size_t)B * H * Tq * sizeof(float));
     if (drop_p < 0.f || drop_p >= 1.f) ASR_FAIL(ASR_EINVAL, "asr_sdpa_bwd: bad dropout p=%f", drop_p);
     const uint32_t dthr = drop_thr16(drop_p);
     const float dscale = 1.f / (1.f - drop_p);
@@ -1292,6 +1379,22 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         else if (masked) sdpa_bwd_fused_bf16_kernel<false, true><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
         else sdpa_bwd_fused_bf16_kernel<false, false><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
 #undef FB_ARGS
+    } else if (mfma && !bwd_split && sdpa_band_shape(Tq, Tk, dk, causal, window, dtype) && delta_bytes >= asr_sdpa_bwd_workspace_bytes(B, H, Tq, Tk, dk, causal, window, dtype)
+               && ((uintptr_t)delta % 16) == 0) {
+        // long-form band: one workgroup per (b, h, 512-key block), single pass; dQ of the tiles on a block boundary through fp32 slabs
+        static bool attr_b = false;
+        if (!attr_b) {
+            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+            attr_b = true;
+        }
+        const int nblk = ceil_div(Tk, FB_KEYS), slots = sdpa_band_slots(window);
+        const dim3 grid(B * H, nblk);
+#define FBB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale, delta, slots
+        if (dthr) sdpa_bwd_fused_bf16_kernel<true, true, true><<<grid, FB_THREADS, FB_LDS, st>>>(FBB_ARGS);
+        else sdpa_bwd_fused_bf16_kernel<false, true, true><<<grid, FB_THREADS, FB_LDS, st>>>(FBB_ARGS);
+#undef FBB_ARGS
+        sdpa_band_halo_kernel<<<dim3(slots, nblk - 1, B * H), 256, 0, st>>>(delta, (bf16_t*)dq, H, Tq, Tk, ldq, window, slots);
     } else if (mfma) {
         const int gq = ceil_div(Tq, 128) * H * B, gk = ceil_div(Tk, 128) * H * B;
 #define SDPA_BWD(D)                                                                                                                                        \

@@ -18,6 +18,9 @@ import os
 
 import torch
 
+import ctypes
+
+from . import _lib
 from . import kernels as K
 from ._lib import ACT_NONE, ACT_RELU, ACT_RELU_MASK
 
@@ -384,6 +387,8 @@ class Engine:
         self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
         self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
         self._ln_part, self._ln_pending = {}, []
+        self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
+        self._dec_cache = {}
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
         # dropout (reference default 0.1; sites: transformer_official.py:175, 306; attention.py:59, 83;
@@ -508,10 +513,12 @@ class Engine:
             K.gemm_tn_grouped(probs, accumulate=True)
         finally:
             K.STREAM_OVERRIDE = None
-        if not torch.cuda.is_current_stream_capturing():   # graph pools never recycle during capture
-            for dy, x, _, _ in probs:
-                dy.record_stream(self.side)
-                x.record_stream(self.side)
+        # also while capturing: a graph's private pool DOES reuse a block freed earlier in the same capture, and without the mark a
+        # replay overwrote dY / X tensors that the side stream's weight-gradient kernel had not read yet (round 3: gradients of the
+        # replayed step differed from the eager step; tests/test_train_loop_gpu.py::test_graphed_step_matches_eager)
+        for dy, x, _, _ in probs:
+            dy.record_stream(self.side)
+            x.record_stream(self.side)
 
     def _release_deferred(self):
         """Launch the weight gradients held back by ASR_WGRAD_DEFER (see _wgrad)."""
@@ -558,9 +565,8 @@ class Engine:
                 if bias_from is not None and not fused:
                     lin.bgrad(bias_from, self.ws_side)
                 lin.wgrad(dy, x, with_bias=fused)
-        if not torch.cuda.is_current_stream_capturing():   # graph pools never recycle during capture
-            for t in (dy, x):
-                t.record_stream(self.side)
+        for t in (dy, x):      # also while capturing (see flush_wgrads)
+            t.record_stream(self.side)
 
     def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross, site, kv_pre=None):
         """x: (B*Tq, d) queries + residual; kv_src: (B*Tk, d).  Returns output and cache."""
@@ -743,6 +749,119 @@ class Engine:
             self._ready("ctc_lo.weight")
         return nll, d_enc
 
+    # ------------------------------------------------------------------ decoder layers through the native launch sequencer
+    def _dec_exec_ok(self, B, To, T):
+        """The C++ sequencer (csrc/decoder_exec.hip: asr_decoder_layer_fwd / _bwd) takes the decoder layers when every projection
+        of the layer runs on the small-M kernel: bf16, B*To rows within its limit, widths multiples of 8.  ASR_DEC_EXEC=0 keeps
+        the per-kernel Python path (also used while bench.py times individual kernels)."""
+        hd = self.H * self.dk
+        return (self.dec_exec and self.dtype == torch.bfloat16 and K.TIMER is None and B * To <= Linear.SMALL_M and self.d % 8 == 0 and hd % 8 == 0
+                and self.ff % 8 == 0 and max(3 * hd, self.ff, self.d) <= Linear.SMALL_REDUCE)
+
+    def _dec_bufs(self, B, To, T, drop):
+        """Persistent activation / gradient buffers and launch plans of the decoder layers for one batch shape (the layer sequence
+        is fixed, so nothing is allocated per step; steps are sequential and the optimizer joins every side stream before the
+        next forward pass touches these buffers)."""
+        key = (B, To, T, bool(drop))
+        hit = self._dec_cache.get(key)
+        if hit is not None:
+            return hit
+        dev, M, d, hd, ff, H = self.flat.device, B * To, self.d, self.H * self.dk, self.ff, self.H
+        bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        part_bytes = K.add_ln_bwd_workspace_bytes(M, d)
+        need = max(_lib.lib.asr_sdpa_bwd_workspace_bytes(B, H, To, T, self.dk, 0, -1, _lib.ASR_BF16), _lib.lib.asr_sdpa_bwd_workspace_bytes(B, H, To, To, self.dk, 1, -1, _lib.ASR_BF16))
+        delta = f32((need + 3) // 4)
+        layers = []
+        for i, (slf, cross, ffn) in enumerate(self.dec):
+            t = dict(qkv_s=bf(M, 3 * hd), ctx_s=bf(M, hd), a_s=bf(M, d), y_s=bf(M, d), lse_s=f32(B, H, To), rstd_s=f32(M),
+                     q_c=bf(M, hd), kv_c=bf(B * T, 2 * hd), ctx_c=bf(M, hd), a_c=bf(M, d), y_c=bf(M, d), lse_c=f32(B, H, To), rstd_c=f32(M),
+                     h=bf(M, ff), o=bf(M, d), y_f=bf(M, d), rstd_f=f32(M),
+                     dz_f=bf(M, d), g_h=bf(M, ff), dx_f=bf(M, d), dz_c=bf(M, d), g_qc=bf(M, hd), g_kvc=bf(B * T, 2 * hd), dx_c=bf(M, d),
+                     dz_s=bf(M, d), g_qkv=bf(M, 3 * hd), dx_s=bf(M, d), dctx=bf(M, hd),
+                     part_f=torch.empty(part_bytes, dtype=torch.uint8, device=dev), part_c=torch.empty(part_bytes, dtype=torch.uint8, device=dev),
+                     part_s=torch.empty(part_bytes, dtype=torch.uint8, device=dev))
+            if drop:      # pre-residual dropout: the gradient wrt a projection's output is its own tensor
+                t.update(g_o=bf(M, d), g_ac=bf(M, d), g_as=bf(M, d))
+            pl = _lib.DecLayerPlan()
+            pl.B, pl.To, pl.T, pl.d, pl.H, pl.dk, pl.ff = B, To, T, d, H, self.dk, ff
+            for name, ten in t.items():
+                setattr(pl, name, ten.data_ptr())
+            for name, lin in (("qkv_s", slf.qkv), ("fc_s", slf.fc), ("q_c", cross.q), ("fc_c", cross.fc), ("1", ffn.w1), ("2", ffn.w2)):
+                setattr(pl, "w_" + name, lin.wlp.data_ptr())
+                setattr(pl, "b_" + name, lin.b32.data_ptr())
+            for name, ln in (("s", slf.ln), ("c", cross.ln), ("f", ffn.ln)):
+                setattr(pl, "g_" + name, ln.g.data_ptr())
+                setattr(pl, "be_" + name, ln.b.data_ptr())
+            pl.gb_2, pl.gb_fc_c, pl.gb_fc_s = ffn.w2.gb.data_ptr(), cross.fc.gb.data_ptr(), slf.fc.gb.data_ptr()
+            if cross.kv.wlpT is not None:
+                pl.w_kv_c_T, pl.ld_kv_c_T = cross.kv.wlpT.data_ptr(), cross.kv.wlpT.stride(0)
+            pl.delta, pl.delta_bytes = delta.data_ptr(), delta.numel() * 4
+            t["kv_event"] = torch.cuda.Event()
+            layers.append((pl, t))
+        hit = self._dec_cache[key] = dict(layers=layers, delta=delta)
+        return hit
+
+    def _dec_exec_fwd(self, x, enc, dec_len, cross_len, B, To, T):
+        drop = self.training and self.drop_p > 0.0
+        bufs = self._dec_bufs(B, To, T, drop)
+        main = K._stream()
+        overlap = self.aux_overlap and not torch.cuda.is_current_stream_capturing()
+        if overlap:      # the six K|V projections of the encoder output on the auxiliary stream, one event each (see decoder_fwd)
+            self._fork(self.ctc_stream)
+            with torch.cuda.stream(self.ctc_stream):
+                for (pl, t), (_, cross, _) in zip(bufs["layers"], self.dec):
+                    cross.kv.fwd(enc, out=t["kv_c"])
+                    t["kv_event"].record(self.ctc_stream)
+                    pl.kv_ready_event = t["kv_event"].cuda_event
+            enc.record_stream(self.ctc_stream)
+        for i, ((pl, t), (_, cross, _)) in enumerate(zip(bufs["layers"], self.dec)):
+            if not overlap:
+                cross.kv.fwd(enc, out=t["kv_c"])
+                pl.kv_ready_event = None
+            pl.x_in = x.data_ptr()
+            pl.dec_len, pl.cross_len = dec_len.data_ptr(), cross_len.data_ptr()
+            pl.drop_p = self.drop_p if drop else 0.0
+            for j, site in enumerate((100 + 8 * i, 101 + 8 * i, 102 + 8 * i, 103 + 8 * i, 104 + 8 * i)):
+                pl.seed[j] = self._drop(site)[1]
+            _lib.check(_lib.fast.asr_decoder_layer_fwd(ctypes.addressof(pl), main), "asr_decoder_layer_fwd")
+            t["x_in"] = x
+            x = t["y_f"]
+        return x, bufs
+
+    def _dec_exec_bwd(self, bufs, dy, enc, d_enc, d_enc_ready):
+        drop = self.training and self.drop_p > 0.0
+        main = K._stream()
+        aux = self.ctc_stream.cuda_stream if (self.aux_overlap and not torch.cuda.is_current_stream_capturing()) else None
+        dy2 = None
+        M = dy.shape[0]
+        for i in reversed(range(self.L)):
+            pl, t = bufs["layers"][i]
+            slf, cross, ffn = self.dec[i]
+            if cross.kv.wlpT is not None:
+                cross.kv._fresh_transpose()
+            if d_enc_ready is not None:      # d_enc must hold the CTC branch's contribution before the first cross-attention add
+                torch.cuda.current_stream().wait_event(d_enc_ready)
+                d_enc_ready = None
+            pl.d_enc = d_enc.data_ptr() if cross.kv.wlpT is not None else None
+            _lib.check(_lib.fast.asr_decoder_layer_bwd(ctypes.addressof(pl), dy.data_ptr(), None if dy2 is None else dy2.data_ptr(), main, aux),
+                       "asr_decoder_layer_bwd")
+            if cross.kv.wlpT is None:      # no transposed copy (odd widths): the accumulating input gradient through the generic path
+                cross.kv.dgrad(t["g_kvc"], out=d_enc, accumulate=True)
+            # weight gradients of the layer (one grouped launch on the side stream) and the LayerNorm parameter-gradient partial sums
+            self._wgrad(ffn.w2, t["g_o"] if drop else t["dz_f"], t["h"])
+            self._wgrad(ffn.w1, t["g_h"], t["y_c"], bias_from=t["g_h"])
+            self._wgrad(cross.fc, t["g_ac"] if drop else t["dz_c"], t["ctx_c"])
+            self._wgrad(cross.q, t["g_qc"], t["y_s"], bias_from=t["g_qc"])
+            self._wgrad(cross.kv, t["g_kvc"], enc, bias_from=t["g_kvc"])
+            self._wgrad(slf.fc, t["g_as"] if drop else t["dz_s"], t["ctx_s"])
+            self._wgrad(slf.qkv, t["g_qkv"], t["x_in"], bias_from=t["g_qkv"])
+            self._ln_pending += [(t["part_f"], ffn.ln.gg, ffn.ln.gb, ffn.w2.gb, M), (t["part_c"], cross.ln.gg, cross.ln.gb, cross.fc.gb, M),
+                                 (t["part_s"], slf.ln.gg, slf.ln.gb, slf.fc.gb, M)]
+            dy, dy2 = t["dx_s"], t["dz_s"]
+            self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
+        return dy, dy2
+
     # ------------------------------------------------------------------ decoder
     def decoder_fwd(self, prep, enc, cross_len, B, T):
         """prep = kernels.dec_preprocess(tgt).  transformer_official.py:277-328."""
@@ -751,6 +870,12 @@ class Engine:
         pe_, se_ = self._drop(2)           # dropout(emb * scale + PE)  (transformer_official.py:306-307)
         x = K.embed_pe_fwd(ys_in.reshape(-1), self.emb32, self.pe, self.d ** -0.5, B, To, self.dtype, drop_p=pe_, drop_seed=se_)
         cache = dict(B=B, T=T, To=To, ys_in=ys_in, layers=[], drop=(pe_, se_))
+        if self._dec_exec_ok(B, To, T):
+            x, bufs = self._dec_exec_fwd(x, enc, dec_len, cross_len, B, To, T)
+            cache.update(exec_bufs=bufs, enc=enc, keep=(dec_len, cross_len))      # the plans hold raw pointers to the length vectors
+            pred = self.prj.fwd(x)
+            cache["x_last"] = x
+            return pred, cache
         kv_pre = [None] * self.L
         if self.aux_overlap and not torch.cuda.is_current_stream_capturing():
             # the six cross-attention K|V projections of the encoder output (16000-row GEMMs, 26 us each) do not depend on the
@@ -783,7 +908,9 @@ class Engine:
         self.wait_transposes()
         self._wgrad(self.prj, dpred, cache["x_last"])
         dy, dy2 = self.prj.dgrad(dpred), None
-        for i in reversed(range(self.L)):
+        if "exec_bufs" in cache:
+            dy, dy2 = self._dec_exec_bwd(cache["exec_bufs"], dy, cache["enc"], d_enc, d_enc_ready)
+        for i in (reversed(range(self.L)) if "exec_bufs" not in cache else ()):
             slf, cross, ffn = self.dec[i]
             c1, c2, c3 = cache["layers"][i]
             dx, dz = self._ffn_block_bwd(ffn, c3, dy, dy2)

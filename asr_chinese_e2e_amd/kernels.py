@@ -244,11 +244,13 @@ def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=F
     assert q.dtype == k.dtype == v.dtype == o.dtype == do.dtype == dq.dtype == dk_.dtype == dv.dtype
     _chk_i32(k_len)
     _chk_f32(lse)
-    delta = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if delta is None else delta
+    if delta is None:      # scratch: row sums of dO o O, or the band kernel's dQ partials of the tiles on a key-block boundary
+        need = lib.asr_sdpa_bwd_workspace_bytes(B, H, Tq, Tk, dk, int(causal), int(window), _dt(q))
+        delta = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
     scale = float(dk) ** -0.5 if scale is None else float(scale)
     e = q.element_size()
     timed("sdpa_bwd", 10.0 * B * H * Tq * Tk * dk, lambda: check(
-        lib.asr_sdpa_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk_), _p(dv), _p(k_len),
+        lib.asr_sdpa_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), delta.numel() * 4, _p(dq), _p(dk_), _p(dv), _p(k_len),
                          B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, int(causal), int(window), scale, float(drop_p),
                          int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_bwd"),
           B * H * (4.0 * Tq + 4.0 * Tk) * dk * e)    # Q, O, dO, dQ + K, V, dK, dV (8 x 16.4 MB at config 2); 5 products

@@ -71,7 +71,7 @@ int asr_stream_fork(void* from_stream, void* to_stream);
 int asr_stream_create(int priority, void** out_stream);
 /* Tuning options: process-wide integer switches between CORRECT variants of a kernel (every value gives correct results), settable at
  * run time so that two variants can be timed alternately inside one process.  Names: "nt_store" (store policy of the NT GEMM's output tile:
- * 0 nt, 1 sc1 write-through, 2 plain, 3 sc0 sc1), "nt_tile", "ln_store", "sdpa_store", "tn_cfg".  Initial values: ASR_OPT_<NAME>
+ * 0 nt, 1 sc1 write-through, 2 plain, 3 sc0 sc1), "nt_tile" (0: 256 x 128 tiles, 2: 256 x 256 wherever the shape allows, 3: by shape), "ln_store", "sdpa_store", "tn_cfg".  Initial values: ASR_OPT_<NAME>
  * in the environment, else the defaults.  previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
 int asr_set_option(const char* name, int value, int* previous);
 int asr_get_deterministic(void);
@@ -150,9 +150,14 @@ int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* ls
                  uint32_t drop_seed, int dtype, void* stream);
 
 /* Backward: given do (same layout as o) computes dq, dk, dv (layouts/strides of q, k, v).
- * delta: (B, H, Tq) f32 scratch (rowsum(do*o)), written by the call. */
+ * delta: f32 scratch of delta_bytes >= asr_sdpa_bwd_workspace_bytes(...) bytes, written by the call: (B, H, Tq) row sums
+ * rowsum(do*o) for the two-kernel paths, or - bf16 self-attention inside a +-window band over more than 512 keys (the long-form
+ * configuration, T = 2000: the band precedent is Predictor/Models/transformer_new.py:53) - the fp32 dQ partials of the query tiles
+ * that straddle a 512-key block boundary of the single-pass band kernel.  With a smaller scratch (>= B*H*Tq floats) the band shapes
+ * run on the two-kernel path. */
+size_t asr_sdpa_bwd_workspace_bytes(int B, int H, int Tq, int Tk, int dk, int causal, int window, int dtype);
 int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                 const float* lse, float* delta, void* dq, void* dk_, void* dv,
+                 const float* lse, float* delta, size_t delta_bytes, void* dq, void* dk_, void* dv,
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
                  int ldv, int ldo, int causal, int window, float scale, float drop_p,
                  uint32_t drop_seed, int dtype, void* stream);
@@ -405,6 +410,55 @@ typedef struct asr_tn_problem {
     int M, N, K, ldy, ldx, ldw;
 } asr_tn_problem;
 int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One decoder layer as ONE host call: the fixed launch sequence of DecoderLayer.forward (transformer_official.py:446-458: self-attention,
+ * encoder-decoder attention, position-wise FFN; each with post-LayerNorm and pad zeroing, attention.py:33-62, module.py:68-75) and of
+ * autograd through it, issued from C++ on caller-owned buffers.  The decoder's ~23 kernels per layer and direction take 4 - 13 us each on
+ * its B*To ~ 550 rows: with one foreign call per kernel from Python the host paced that part of the joint step.  Same kernels, same order,
+ * same results as calling asr_gemm_small_bf16 / asr_sdpa_* / asr_add_ln_* / asr_gemm_nt_bf16 one by one.  bf16 activations only
+ * (M = B*To rows; d, H*dk, ff multiples of 8).  All pointers are device pointers unless stated; the struct itself is HOST memory, read
+ * during the call.  Not included (they stay with the caller): weight-gradient GEMMs (the dY / X operands are the buffers below), the
+ * reduction of the LayerNorm parameter-gradient partial sums left in part_* (asr_add_ln_bwd_reduce_batched), data-parallel marks. */
+typedef struct asr_dec_layer_plan {
+    int B, To, T, d, H, dk, ff;           /* utterances, target positions, encoder frames per utterance, model width, heads, head dim, FFN width */
+    float drop_p;                          /* dropout of every site of the layer (0 = off) */
+    uint32_t seed[5];                      /* per-step mask seeds: self-attn probabilities, after self fc, cross-attn probabilities, after cross fc, after w_2 */
+    int ld_kv_c_T;                         /* row stride (elements) of w_kv_c_T */
+    const int32_t* dec_len;                /* (B) valid target positions (self-attention keys, pad zeroing) */
+    const int32_t* cross_len;              /* (B) visible encoder frames of the encoder-decoder attention */
+    /* parameters: bf16 weights as stored (out, in), f32 biases and LayerNorm gains / biases */
+    const void *w_qkv_s, *w_fc_s, *w_q_c, *w_fc_c, *w_1, *w_2;
+    const float *b_qkv_s, *b_fc_s, *b_q_c, *b_fc_c, *b_1, *b_2;
+    const float *g_s, *be_s, *g_c, *be_c, *g_f, *be_f;
+    const void* w_kv_c_T;                  /* (d, 2 H dk) bf16: transposed K|V projection weight of the cross attention (backward; may be NULL) */
+    /* forward: input, then every activation the backward pass needs */
+    const void* x_in;                      /* (M, d) layer input */
+    void *qkv_s, *ctx_s, *a_s, *y_s;       /* (M, 3 H dk), (M, H dk), (M, d) = fc output then xhat, (M, d) block output */
+    float *lse_s, *rstd_s;                 /* (B, H, To), (M) */
+    void* q_c;                             /* (M, H dk) */
+    const void* kv_c;                      /* (B*T, 2 H dk) K|V of the encoder frames, projected by the caller */
+    void* kv_ready_event;                  /* hipEvent_t after which kv_c is complete, or NULL (HOST handle) */
+    void *ctx_c, *a_c, *y_c;
+    float *lse_c, *rstd_c;
+    void *h, *o, *y_f;                     /* (M, ff) ReLU output, (M, d) w_2 output then xhat, (M, d) layer output */
+    float* rstd_f;
+    /* backward: gradients wrt activations (bf16), bias gradients (f32, accumulated), scratch */
+    void *dz_f, *g_o, *g_h, *dx_f;         /* residual gradient of the FFN block, dY of w_2 (only with dropout, else dz_f is it), dY of w_1, dX of w_1 */
+    void *dz_c, *g_ac, *g_qc, *g_kvc, *dx_c;   /* cross block: residual gradient, dY of fc (dropout only), dY of the Q projection (M, H dk), dY of K|V (B*T, 2 H dk), dX of Q */
+    void *dz_s, *g_as, *g_qkv, *dx_s;      /* self block: residual gradient, dY of fc (dropout only), dY of Q|K|V (M, 3 H dk), dX of Q|K|V */
+    void* dctx;                            /* (M, H dk) scratch: gradient wrt an attention output */
+    float *gb_2, *gb_fc_c, *gb_fc_s;       /* bias gradients of w_2 and the two out-projections: come out of the LayerNorm backward (partial sums) */
+    void *part_f, *part_c, *part_s;        /* asr_add_ln_bwd_workspace_bytes(M, d) bytes each: partial sums of the LayerNorm parameter gradients */
+    float* delta;                          /* scratch of asr_sdpa_bwd */
+    size_t delta_bytes;
+    void* d_enc;                           /* (B*T, d) bf16 gradient wrt the encoder output, accumulated in place (or NULL) */
+} asr_dec_layer_plan;
+int asr_decoder_layer_fwd(const asr_dec_layer_plan* plan, void* stream);
+/* (dy, dy2): gradient wrt y_f (dy2 may be NULL; the two are added).  Results: plan->dx_s and plan->dz_s = gradient wrt x_in through the
+ * projections and along the residual path (to be added by the consumer).  aux_stream: stream for d_enc += g_kvc W_kv (forked behind
+ * `stream`), or NULL = on `stream`. */
+int asr_decoder_layer_bwd(const asr_dec_layer_plan* plan, const void* dy, const void* dy2, void* stream, void* aux_stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Log-mel front end on device.

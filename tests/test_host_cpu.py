@@ -456,3 +456,22 @@ def test_host_code_under_address_sanitizer():
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0 and "3 passed" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
     assert "AddressSanitizer" not in p.stderr
+
+
+def test_decoder_plan_struct_layout_matches_header(tmp_path):
+    """_lib.DecLayerPlan (ctypes) against asr_dec_layer_plan as the C compiler lays it out: same size, same offset of every field
+    (the plan is filled in Python and read by csrc/decoder_exec.hip)."""
+    import ctypes
+    from asr_chinese_e2e_amd._lib import DecLayerPlan
+    names = [f[0] for f in DecLayerPlan._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "asr_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(asr_dec_layer_plan));\n' +
+                   "".join(f'  printf("{n} %zu\\n", offsetof(asr_dec_layer_plan, {n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert int(out[0]) == ctypes.sizeof(DecLayerPlan)
+    for line in out[1:]:
+        if line:
+            n, off = line.split()
+            assert getattr(DecLayerPlan, n).offset == int(off), n

