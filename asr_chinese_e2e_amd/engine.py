@@ -274,7 +274,9 @@ def _shared_stream(device, kind):
     their steps one after the other, so sharing costs nothing."""
     key = (torch.device(device).index, kind)
     if key not in _STREAMS:
-        _STREAMS[key] = _side_stream(device) if kind == "wgrad" else torch.cuda.Stream(device=device)
+        # "aux" (the CTC branch / cross-attention K|V work beside the decoder): ASR_AUX_PRIORITY=low puts it at the lowest priority too
+        low = kind == "wgrad" or os.environ.get("ASR_AUX_PRIORITY", "normal") == "low"
+        _STREAMS[key] = _side_stream(device) if low else torch.cuda.Stream(device=device)
     return _STREAMS[key]
 
 

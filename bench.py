@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")
 
 
 def parse(argv=None):
@@ -144,7 +144,7 @@ def cpu_baseline(args, config):
 
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed PMC summary (None if absent)."""
-    pat = {"gemm_nt": "gemm_nt", "gemm_tn": "gemm_tn", "lib_gemm_dgrad": "Cijk"}.get(family, family)
+    pat = {"gemm_nt": "gemm_nt", "gemm_tn": "gemm_tn"}.get(family, family)
     try:
         table = json.load(open(PMC_TRAFFIC_FILE))
     except (OSError, ValueError):
@@ -154,9 +154,9 @@ def pmc_traffic(family):
     return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
 
 
-MATRIX_FAMILIES = ("gemm_nt", "gemm_tn", "lib_gemm_dgrad", "sdpa_fwd", "sdpa_bwd")
+MATRIX_FAMILIES = ("gemm_nt", "gemm_tn", "sdpa_fwd", "sdpa_bwd")
 KERNEL_NAMES = {"gemm_nt": "gemm_nt_persist_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
-                "lib_gemm_dgrad": "hipBLASLt GEMM (input gradients not on the own kernel)", "sdpa_fwd": "sdpa_fwd_fused_bf16_kernel (asr_sdpa_fwd)",
+                "sdpa_fwd": "sdpa_fwd_fused_bf16_kernel (asr_sdpa_fwd)",
                 "sdpa_bwd": "sdpa_bwd_fused_bf16_kernel (asr_sdpa_bwd)", "add_ln_fwd": "add_ln_fwd_kernel", "add_ln_bwd": "add_ln_bwd_kernel",
                 "ctc": "ctc_lse_gather_rows + ctc_alpha_beta + ctc_label_fix (asr_ctc_fwd_bwd)", "xent": "xent_kernel", "adam": "adam_kernel (asr_adam_step)",
                 "grad_sumsq": "sumsq kernels (asr_grad_sumsq)"}
@@ -216,15 +216,32 @@ class Run:
         the stream the kernel is launched on).  A separate pass: ~100 event pairs per step cost ~25 % wall time on
         ROCm; the wgrad overlap is off so the durations are stand-alone."""
         from asr_chinese_e2e_amd import kernels as K
+        torch = self.torch
         timer = K.LaunchTimer(list(KERNEL_NAMES))
         K.TIMER = timer
         self.model._engine.overlap_wgrad = False
+        # every GEMM of the step is an own kernel (round 3): count what still reaches the library through torch during these steps
+        self.lib_gemm_calls = 0
+        saved = {}
+
+        def counting(fn):
+            def wrapped(*a, **k):
+                self.lib_gemm_calls += 1
+                return fn(*a, **k)
+            return wrapped
+        for owner, name in ((torch, "mm"), (torch, "addmm"), (torch, "matmul"), (torch, "bmm"), (torch.Tensor, "addmm_"), (torch.Tensor, "matmul"), (torch.Tensor, "mm")):
+            saved[(owner, name)] = getattr(owner, name)
+            setattr(owner, name, counting(saved[(owner, name)]))
         try:
             self.steps(n_inst, runner=self.model if self.graphed else self.runner)   # events cannot be read back from a captured graph
             self.barrier()
         finally:
+            for (owner, name), fn in saved.items():
+                setattr(owner, name, fn)
             K.TIMER = None
             self.model._engine.overlap_wgrad = not self.model._engine.deterministic
+        if self.lib_gemm_calls:
+            raise SystemExit(f"bench: {self.lib_gemm_calls} library GEMM call(s) in {n_inst} steps - every projection is expected on an own kernel")
         return timer.summary()
 
 
@@ -370,7 +387,8 @@ def main():
             out["scaling_reference"] = {"n1_key": "joint_utterances_per_s", "workload": "joint CTC/attention model, same per-GPU batch"}
         out.update(extras)
         if summary:
-            fam = {k: v for k, v in summary.items() if k in ("gemm_nt", "gemm_tn", "lib_gemm_dgrad")}
+            out["library_gemm_calls_per_step"] = 0      # asserted by kernel_pass (torch.mm / addmm / matmul / bmm are counted there)
+            fam = {k: v for k, v in summary.items() if k in ("gemm_nt", "gemm_tn")}
             dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
             if dom:
                 a = fam[dom]["work_per_s"] / 1e12

@@ -855,9 +855,9 @@ def test_decoder_sequencer_matches_per_kernel_path(dropout, monkeypatch):
     every gradient are bit-identical, with and without dropout (same per-site mask seeds)."""
     from asr_chinese_e2e_amd import kernels as K
     over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, ctc_weight=0.3, dropout=dropout)
-    cfg, sd, batch = oracle_case(4, 136, 80, 56, 12, over, seed=9)
-    sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
-    sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+    # 9 x 500 = 4500 encoder frames: the accumulating input gradient d_enc += dK|dV W_kv takes the persistent NT kernel on both paths
+    # (below 4096 rows the per-kernel path sends it through the fp32 kernel, which rounds differently)
+    cfg, sd, batch = oracle_case(9, 500, 80, 56, 12, over, seed=9)
     pack = to_pack(batch)
     prev = K.set_deterministic(True)
     try:

@@ -3,7 +3,7 @@
 # kernel trace + stats, then separate --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) as MI355X_MICROARCH.md prescribes.
 # Writes the summaries under gpurun_out/prof_<tag>/ ; copy the ones to keep into profiles/.
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -23,4 +23,13 @@ cp $(find $OUT/trace -name "*kernel_stats.csv") $OUT/kernel_stats.csv
 python3 tools/pmc_summary.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
 python3 tools/mfma_util.py $(find $OUT/mfma -name "*counter_collection.csv") $OUT/mfma_util.json
 rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
+# HBM traffic of the long-form band attention kernels (BASELINE configs[4] per GPU: B = 8, T = 2000, +-50 frames), stand-alone
+cd /tmp
+B=8 T=2000 WINDOW=50 REPS=5 rocprofv3 --pmc FETCH_SIZE -d $OUT/bfetch -o p --output-format csv -- python3 $R/tools/sdpa_bench.py > $OUT/band_bench.txt 2> $OUT/bfetch.err
+B=8 T=2000 WINDOW=50 REPS=5 rocprofv3 --pmc WRITE_SIZE -d $OUT/bwrite -o p --output-format csv -- python3 $R/tools/sdpa_bench.py > /dev/null 2> $OUT/bwrite.err
+cd $R
+python3 tools/pmc_summary.py $(find $OUT/bfetch -name "*counter_collection.csv") $(find $OUT/bwrite -name "*counter_collection.csv") $OUT/pmc_traffic_band.json > $OUT/pmc_traffic_band.txt
+B=8 T=2000 WINDOW=50 python3 tools/sdpa_bench.py > $OUT/band_bench_plain.txt 2>&1
+B=8 T=2000 WINDOW=50 ASR_SDPA_BWD_SPLIT=1 python3 tools/sdpa_bench.py > $OUT/band_bench_pair.txt 2>&1
+rm -rf $OUT/bfetch $OUT/bwrite
 ls -la $OUT

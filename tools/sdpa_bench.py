@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from asr_chinese_e2e_amd import kernels as K
 
-B, H, T, dk = 32, 8, int(os.environ.get("T", "500")), 64
+B, H, T, dk = int(os.environ.get("B", "32")), 8, int(os.environ.get("T", "500")), 64      # long-form band: B=8 T=2000 WINDOW=50 (ASR_SDPA_BWD_SPLIT=1: the kernel pair)
 window = int(os.environ.get("WINDOW", "-1"))
 d = H * dk
 def timeit(fn, reps=int(os.environ.get("REPS", "20"))):
