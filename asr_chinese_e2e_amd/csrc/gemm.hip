@@ -1770,7 +1770,7 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }
-    if (K % DBK != 0 && K >= 2 * PBK && !res && act == ASR_ACT_NONE && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {
+    if (K % DBK != 0 && K > PBK && !res && act == ASR_ACT_NONE && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {      // >= 2 k-steps, the last one ragged (also linear_in: K = 80)
         // ragged reduction length (K % 8 == 0 was checked above): persistent kernel, last k-step padded from the zero page
         static void* zero_page = nullptr;
         if (!zero_page && (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page))

@@ -480,7 +480,8 @@ def test_optimizer(K, ws):
                                                           (130, 40, 24, 1, True, True),
                                                           # reduction length a multiple of 8 but not of 64 (the CTC head's input gradient reduces
                                                           # over V = 4232): the persistent kernel pads its last k-step from a zero page
-                                                          (1000, 512, 4232, 0, False, False), (300, 256, 136, 0, True, False), (512, 640, 200, 0, True, False)])
+                                                          (1000, 512, 4232, 0, False, False), (300, 256, 136, 0, True, False), (512, 640, 200, 0, True, False),
+                                                          (16000, 512, 80, 0, True, False)])      # linear_in (F = 80): two k-steps, the second with 16 columns
 def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     torch.manual_seed(M + N)
     a = torch.randn(M, K_).bfloat16()
