@@ -18,6 +18,7 @@ import os
 
 import torch
 
+import collections
 import ctypes
 
 from . import _lib
@@ -390,7 +391,7 @@ class Engine:
         self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
-        self._dec_cache = {}
+        self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
         # dropout (reference default 0.1; sites: transformer_official.py:175, 306; attention.py:59, 83;
@@ -752,6 +753,8 @@ class Engine:
         return nll, d_enc
 
     # ------------------------------------------------------------------ decoder layers through the native launch sequencer
+    DEC_CACHE_SHAPES = 6
+
     def _dec_exec_ok(self, B, To, T):
         """The C++ sequencer (csrc/decoder_exec.hip: asr_decoder_layer_fwd / _bwd) takes the decoder layers when every projection
         of the layer runs on the small-M kernel: bf16, B*To rows within its limit, widths multiples of 8.  ASR_DEC_EXEC=0 keeps
@@ -767,7 +770,10 @@ class Engine:
         key = (B, To, T, bool(drop))
         hit = self._dec_cache.get(key)
         if hit is not None:
+            self._dec_cache.move_to_end(key)
             return hit
+        while len(self._dec_cache) >= self.DEC_CACHE_SHAPES:      # real batches come in many shapes: keep the most recent few, free the rest
+            self._dec_cache.popitem(last=False)
         dev, M, d, hd, ff, H = self.flat.device, B * To, self.d, self.H * self.dk, self.ff, self.H
         bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)

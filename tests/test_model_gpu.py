@@ -878,3 +878,20 @@ def test_decoder_sequencer_matches_per_kernel_path(dropout, monkeypatch):
         K.set_deterministic(prev)
     assert torch.equal(res["1"][0], res["0"][0]), (res["1"][0], res["0"][0])
     assert torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
+
+
+def test_decoder_sequencer_buffer_cache_is_bounded():
+    """Real batches come in many shapes: the sequencer's persistent per-shape buffers are an LRU of a few shapes (Engine.DEC_CACHE_SHAPES),
+    re-used when a shape returns, and the training steps stay finite across the changes."""
+    from asr_chinese_e2e_amd.data_handler import synthetic_pack
+    cfg = R.default_cfg(n_mels=80, lfr_m=1, ctc_weight=0.3)
+    cfg.layer_num = 1
+    model = build(cfg, 60, "TransformerOffical", dtype="bf16").cuda()
+    opt = make_opt(model, cfg, 20)
+    shapes = [(4, 96, 9), (3, 120, 7), (4, 64, 11), (2, 200, 5), (4, 96, 9), (5, 88, 8), (4, 72, 6), (3, 130, 10), (4, 96, 9)]
+    for i, (B, T, L) in enumerate(shapes):
+        pack = synthetic_pack(B, T, 80, 60, seed=i, ragged=True, Lmin=2, Lmax=L, device=DEV, dtype=torch.bfloat16)
+        m, _ = model.iterate(pack, optimizer=opt, is_train=True)
+        assert torch.isfinite(m.loss).all()
+    eng = model._engine
+    assert 0 < len(eng._dec_cache) <= eng.DEC_CACHE_SHAPES
