@@ -598,6 +598,224 @@ static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bia
     gemm_nt_persist_kernel<ACT, NW, DBG, KRAG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask, zero_page, st_mode);
 }
 
+// ------------------------------------------------------------------------- NT, persistent, loader / consumer waves
+// In the kernel above every wave issues its share of the LDS-DMA between its own MFMAs, and a 1-KiB DMA instruction holds the issuing wave
+// for ~165 cycles (in-kernel stamps: 0.52 us of DMA issue + 0.82 us of MFMA per k-step overlap to 0.93 us, not to 0.82).  Here the two
+// jobs belong to different waves of the same workgroup: waves 4..7 only LOAD (12 DMA instructions per k-step each, two k-steps ahead,
+// counted vmcnt), waves 0..3 only COMPUTE (wave tile 128 x 64 = 4 x 2 MFMA blocks, 32 back-to-back MFMAs per k-step, fragments read
+// one k-sub-step ahead) and store.  Same tile (256 x 128 x 64), same ring (3 x 48 KiB), same one s_barrier per k-step, same tile
+// order; a loader and a consumer share each SIMD, so DMA issue and matrix issue come from different instruction streams.  Every output
+// element sees the same k order as in the kernel above: identical bits.
+template <int ACT, bool KRAG = false>
+__global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int tiles_n, int ntiles,
+                                                              const bf16_t* __restrict__ mask, const void* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int nb_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int tq = ntiles >> 3, trem = ntiles & 7;
+    const int lo = xcd * tq + min(xcd, trem), hi = lo + tq + (xcd < trem ? 1 : 0);
+    const int first = lo + idx;
+    if (first >= hi) return;
+    const int my_tiles = (hi - first + nb_x - 1) / nb_x;
+    const int nk = KRAG ? (K + PBK - 1) / PBK : K / PBK;
+    const int total = my_tiles * nk;
+    const int srow = lane >> 3;
+    if (w >= 4) {
+        // ================================================================ loader waves
+        constexpr int LP = (PBM + PBN) / 8 / 4;      // 12 one-KiB pieces per loader wave and stage
+        const int lw = w - 4;
+        const bf16_t* src[LP];
+        auto set_tile = [&](int tile) {
+            const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+            const int m0 = tm * PBM, n0 = tn * PBN;
+#pragma unroll
+            for (int j = 0; j < LP; ++j) {
+                const int g = lw * LP + j;                       // 8-row group: 0..31 = A rows, 32..47 = W rows
+                const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));
+                src[j] = g < PBM / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
+                                     : W + (size_t)min(n0 + 8 * (g - PBM / 8) + srow, N - 1) * ldb + schunk * 8;
+            }
+        };
+        int it_tile = first, it_k = 0, it_slot = 0, issued = 0;
+        auto issue_stage = [&]() {
+#pragma unroll
+            for (int j = 0; j < LP; ++j) {
+                const bf16_t* p = src[j] + it_k * PBK;
+                if (KRAG && it_k == nk - 1) {
+                    const int g = lw * LP + j;
+                    const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));
+                    p = (it_k * PBK + schunk * 8 < K) ? p : (const bf16_t*)zero_page;
+                }
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)p, (lds_void_t*)(smem_s + it_slot * PSTAGE + (lw * LP + j) * 1024), 16, 0, 0);
+            }
+            ++issued;
+            it_slot = it_slot == PRING - 1 ? 0 : it_slot + 1;
+            if (++it_k == nk) {
+                it_k = 0;
+                it_tile += nb_x;
+                if (issued < total) set_tile(it_tile);
+            }
+        };
+        set_tile(first);
+        issue_stage();
+        if (total > 1) issue_stage();
+        int i = 0;
+        for (int c_tile = first; c_tile < hi; c_tile += nb_x) {
+            for (int c_k = 0; c_k < nk; ++c_k, ++i) {
+                // item i has landed when only item i + 1 (LP instructions) is outstanding
+                if (i + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();      // item i is complete for the consumers; they have finished item i - 1, whose slot is refilled now
+                if (issued < total) issue_stage();
+            }
+            __builtin_amdgcn_s_barrier();          // the consumers' barrier in front of their store tail
+        }
+        return;
+    }
+    // ==================================================================== consumer waves
+    constexpr int MI = 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int sw = (r >> 1) & 7;
+    const int a_row = (wm * 128 + r) * 128;                  // + mi * 32 * 128
+    const int w_row = PBM * 128 + (wn * 64 + r) * 128;       // + ni * 32 * 128
+    int c_slot = 0;
+    for (int c_tile = first; c_tile < hi; c_tile += nb_x) {
+        const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
+        const int m0 = tm * PBM + wm * 128, n0 = tn * PBN + wn * 64;
+        f32x16 acc[2][MI];  // [ni][mi]: C^T blocks (n in registers, m on the lane), starting at the bias (scalar loads)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int nb = min(n0 + ni * 32 + 8 * g4, N - 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
+                    const float bv = hh ? b_hi : b_lo;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[ni][mi][4 * g4 + e] = bv;
+                }
+            }
+        u32x4 hm0[4];
+        auto load_masks = [&](u32x4 (&dst)[4], int mi) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = q * 8 + srow, ch = lane & 7;
+                const int m = m0 + mi * 32 + row, n = n0 + ch * 8;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                dst[q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
+            }
+        };
+        for (int c_k = 0; c_k < nk; ++c_k) {
+            __builtin_amdgcn_s_barrier();
+            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && c_k == nk - 1) load_masks(hm0, 0);
+            const char* sb = smem_s + c_slot * PSTAGE;
+            c_slot = c_slot == PRING - 1 ? 0 : c_slot + 1;
+            bf16x8 af[2][MI], wf[2][2];
+            auto load_frags = [&](int buf, int ks) {
+                const int coff = ((2 * ks + hh) ^ sw) << 4;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[buf][mi] = *(const bf16x8*)(sb + a_row + mi * 32 * 128 + coff);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+                for (int q = 0; q < 2 * MI; ++q) {
+                    const int ni = q / MI, mi = q % MI;
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
+                }
+            }
+        }
+        // ---- store tail: four rounds of 32 rows x 64 columns through a wave-private 4-KiB buffer in the slot consumed last
+        __builtin_amdgcn_s_barrier();
+        char* epi = smem_s + (c_slot == 0 ? PRING - 1 : c_slot - 1) * PSTAGE + w * 4096;
+        // ReLU mask / residual pieces: round 0 was fetched under the tile's last k-step, round mi + 1 is fetched while round mi is
+        // transposed and stored (loaded right where they are used they cost the old kernel 8.8 us per launch)
+        u32x4 hm[4], hm_next[4];
+        if (ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hm[q] = hm0[q];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && mi + 1 < MI) load_masks(hm_next, mi + 1);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[ni][mi][4 * g4 + e];
+                        if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
+                        o[e] = x;
+                    }
+                    store4<bf16_t>((bf16_t*)(epi + r * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
+                }
+            __builtin_amdgcn_wave_barrier();
+            u32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = q * 8 + srow, ch = lane & 7;
+                v[q] = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+            if (ACT == NT_ACT_ADD_RES) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t a = v[q][e], r2 = hm[q][e];
+                        const bf16_t lo_ = (bf16_t)(__uint_as_float(a << 16) + __uint_as_float(r2 << 16));
+                        const bf16_t hi_ = (bf16_t)(__uint_as_float(a & 0xffff0000u) + __uint_as_float(r2 & 0xffff0000u));
+                        v[q][e] = (uint32_t)__builtin_bit_cast(unsigned short, lo_) | ((uint32_t)__builtin_bit_cast(unsigned short, hi_) << 16);
+                    }
+            }
+            if (ACT == ASR_ACT_RELU_MASK) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t h = hm[q][e];
+                        const uint32_t lo_ = ((h & 0x7fffu) != 0u && !(h & 0x8000u)) ? 0x0000ffffu : 0u;
+                        const uint32_t hi_ = ((h & 0x7fff0000u) != 0u && !(h & 0x80000000u)) ? 0xffff0000u : 0u;
+                        v[q][e] &= lo_ | hi_;
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = q * 8 + srow, ch = lane & 7;
+                const int m = m0 + mi * 32 + row, n = n0 + ch * 8;
+                if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && mi + 1 < MI) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hm[q] = hm_next[q];
+            }
+        }
+    }
+}
+
+template <int ACT, bool KRAG = false>
+static void launch_nt_spec(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st,
+                           const bf16_t* mask = nullptr, const void* zero_page = nullptr) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_spec_kernel<ACT, KRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        attr = true;
+    }
+    const int t_n = ceil_div(N, PBN), t_m = ceil_div(M, PBM), ntiles = t_n * t_m;
+    const int grid = ntiles < cu_count() ? ntiles : cu_count();
+    gemm_nt_spec_kernel<ACT, KRAG><<<grid, 512, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask, zero_page);
+}
+
 // ------------------------------------------------------------------------- NT, persistent, 256 x 256 tiles
 // What bounds the 256 x 128 kernel above (in-kernel stamps, round 3): a k-step takes 0.93 us where its 32 MFMAs per SIMD need
 // 0.54 us - the step is paced by the L2 -> LDS stream (48 KiB per k-step and CU at the ~70 GB/s a CU draws from L2 with every CU
@@ -1757,15 +1975,20 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     if ((((uintptr_t)A | (uintptr_t)W) % 16) || ((uintptr_t)C % 8) || (res && (uintptr_t)res % 8) || (bias && (uintptr_t)bias % 16)) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     if (act != ASR_ACT_RELU && act != ASR_ACT_NONE && act != ASR_ACT_RELU_MASK) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
+    const bool spec = asr_option(ASR_OPT_NT_TILE) != 1;      // loader / consumer form of the persistent kernel (gemm_nt_spec_kernel): the default since round 3
     if (act == ASR_ACT_RELU_MASK) {   // C = (A W^T + bias) where res > 0, else 0: persistent kernel only
         if (!res || (uintptr_t)res % 16 || K % DBK || K < 2 * PBK || N % 8 || ldc % 8 || ((uintptr_t)C % 16))
             ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: ASR_ACT_RELU_MASK needs the mask in `res`, K %% 64 == 0, K >= 128, N, ldc %% 8 == 0 and 16-byte aligned pointers");
+        if (spec) launch_nt_spec<ASR_ACT_RELU_MASK>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+        else
         launch_nt_persist<ASR_ACT_RELU_MASK, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }
     if (res && act == ASR_ACT_NONE && K % DBK == 0 && K >= 2 * PBK && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)res % 16) == 0) {
         // residual add in the persistent kernel's store tail (res = C accumulates in place: every element is read and written by one lane)
+        if (spec) launch_nt_spec<NT_ACT_ADD_RES>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+        else
         launch_nt_persist<NT_ACT_ADD_RES, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
@@ -1775,6 +1998,8 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         static void* zero_page = nullptr;
         if (!zero_page && (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page))
             ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: zero page symbol not found");
+        if (spec) launch_nt_spec<ASR_ACT_NONE, true>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, nullptr, zero_page);
+        else
         launch_nt_persist<ASR_ACT_NONE, 8, 0, true>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, nullptr, zero_page);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
@@ -1797,14 +2022,19 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
         // they stay selectable through ASR_GEMM_CFG for A/B runs)
         // default: the persistent 8-wave kernel (tools/gemm_bench.py on the config-2 shapes, us:
         // 38.4 / 17.4 / 27.0 / 23.8 / 116.8 vs 46.2 / 19.4 / 32.1 / 27.1 / 130.0 for 128 x 128 ring 2)
-        // tuning option "nt_tile": 0 = always 256 x 128 (default), 2 = 256 x 256 whenever the shape allows, 3 = 256 x 256 where nt_wide_pays().
+        // tuning option "nt_tile": 0 = 256 x 128 tiles, loader / consumer waves (default); 1 = 256 x 128, every wave loads and computes (the
+        // round-2 kernel); 2 = 256 x 256 whenever the shape allows; 3 = 256 x 256 where nt_wide_pays().
         // Measured (round 3): the wide tile is no faster alone (w_1: 26.3 vs 27.0 us; CTC head 111 vs 117) - its ring of two leaves the
         // L2 -> LDS stream idle between a step's last landing and the next step's first issue - and SLOWER beside other streams (the joint
         // model's K|V projections: 41 vs 26 us), step 3.416 vs 3.423 ms: kept as an option, not the default.
         const int tile_opt = asr_option(ASR_OPT_NT_TILE);
-        if (cfg == 0 && dbg == 0 && N % 8 == 0 && tile_opt >= 2 && (tile_opt == 2 ? (K % WBK == 0 && K >= 2 * WBK && N >= 256) : nt_wide_pays(M, N, K))) {
+        if (cfg == 0 && dbg == 0 && N % 8 == 0 && (tile_opt == 2 || tile_opt == 3) && (tile_opt == 2 ? (K % WBK == 0 && K >= 2 * WBK && N >= 256) : nt_wide_pays(M, N, K))) {
             if (act == ASR_ACT_RELU) launch_nt_wide<ASR_ACT_RELU>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
             else launch_nt_wide<ASR_ACT_NONE>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+        } else
+        if (spec && cfg == 0 && dbg == 0 && K >= 2 * PBK && N % 8 == 0) {
+            if (act == ASR_ACT_RELU) launch_nt_spec<ASR_ACT_RELU>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
+            else launch_nt_spec<ASR_ACT_NONE>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
         } else
         if ((cfg == 0 || cfg == 8) && K >= 2 * PBK && N % 8 == 0) {
             if (dbg == 5) launch_nt_persist<ASR_ACT_NONE, 8, 5>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);

@@ -152,7 +152,8 @@ class Linear:
         if x.dtype == torch.float32:      # parity mode: fp32 on the matrix cores (asr_gemm_f32), ReLU in the store tail
             return K.gemm_f32(x, self.w32, out, bias=self.b32, trans_b=True, act=act)
         # bf16 shapes the bf16 kernels refuse (K or a leading dimension not a multiple of 8): through the fp32 kernel
-        tmp = K.gemm_f32(x.float(), self.w32, torch.empty(M, self.N, dtype=torch.float32, device=x.device), bias=self.b32, trans_b=True, act=act)
+        # (the bf16 shadow of the weight, as every bf16 kernel reads it - not the fp32 master)
+        tmp = K.gemm_f32(x.float(), self.wlp.float(), torch.empty(M, self.N, dtype=torch.float32, device=x.device), bias=self.b32, trans_b=True, act=act)
         out.copy_(tmp)
         return out
 
@@ -191,7 +192,7 @@ class Linear:
             return K.gemm_nt(dy, self.wlpT, None, out)
         # what is left: bf16 shapes none of the bf16 kernels takes (odd vocabulary sizes, misaligned views, a many-row operand
         # without a transposed copy): through the fp32 kernel, W as stored - correct for every shape, never the bench's path
-        res = K.gemm_f32(dy.float(), self.w32, torch.empty(dy.shape[0], self.K, dtype=torch.float32, device=dy.device),
+        res = K.gemm_f32(dy.float(), self.wlp.float(), torch.empty(dy.shape[0], self.K, dtype=torch.float32, device=dy.device),
                          act=ACT_RELU_MASK if relu_mask is not None else ACT_NONE, mask=relu_mask.float() if relu_mask is not None else None)
         if out is None:
             return res.to(dy.dtype)

@@ -155,7 +155,7 @@ def pmc_traffic(family):
 
 
 MATRIX_FAMILIES = ("gemm_nt", "gemm_tn", "sdpa_fwd", "sdpa_bwd")
-KERNEL_NAMES = {"gemm_nt": "gemm_nt_persist_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
+KERNEL_NAMES = {"gemm_nt": "gemm_nt_spec_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
                 "sdpa_fwd": "sdpa_fwd_fused_bf16_kernel (asr_sdpa_fwd)",
                 "sdpa_bwd": "sdpa_bwd_fused_bf16_kernel (asr_sdpa_bwd)", "add_ln_fwd": "add_ln_fwd_kernel", "add_ln_bwd": "add_ln_bwd_kernel",
                 "ctc": "ctc_lse_gather_rows + ctc_alpha_beta + ctc_label_fix (asr_ctc_fwd_bwd)", "xent": "xent_kernel", "adam": "adam_kernel (asr_adam_step)",

@@ -529,6 +529,33 @@ def test_gemm_nt_wide_tiles(K, M, N, K_, act, use_bias):
     assert torch.equal(outs[2], outs[0]), float((outs[2].float() - outs[0].float()).abs().max())
 
 
+@pytest.mark.parametrize("M,N,K_,mode", [(16000, 512, 512, "none"), (16000, 1536, 512, "none"), (16000, 1024, 512, "relu"), (16000, 1024, 512, "mask"),
+                                            (16000, 512, 1024, "res"), (1000, 512, 4232, "none"), (777, 520, 192, "none"), (300, 4232, 512, "relu"),
+                                            (16000, 512, 80, "none")])
+def test_gemm_nt_loader_consumer_form(K, M, N, K_, mode):
+    """The loader / consumer form of the persistent NT GEMM (gemm_nt_spec_kernel: four waves only issue the LDS-DMA, four only compute;
+    the default form; tuning option nt_tile = 1 selects the all-in-one round-2 kernel) against that kernel: every store-tail variant (bias, ReLU, ReLU mask, residual add), the ragged
+    last k-step, edge tiles - identical bits (same tile, same k order)."""
+    from asr_chinese_e2e_amd._lib import ACT_RELU_MASK
+    torch.manual_seed(M + N + K_)
+    a = torch.randn(M, K_, device=DEV).bfloat16()
+    w = (torch.randn(N, K_, device=DEV) * 0.1).bfloat16()
+    bias = torch.randn(N, device=DEV) if mode in ("none", "relu") and K_ % 64 == 0 else None
+    res = torch.relu(torch.randn(M, N, device=DEV)).bfloat16() if mode in ("mask", "res") else None
+    act = {"none": 0, "relu": 1, "mask": ACT_RELU_MASK, "res": 0}[mode]
+    outs = {}
+    for tile in (0, 1):      # 0 = loader / consumer form (the default), 1 = every wave loads and computes (the round-2 kernel)
+        prev = K.set_option("nt_tile", tile)
+        try:
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            K.gemm_nt(a, w, bias, out, act, res)
+            outs[tile] = out
+        finally:
+            K.set_option("nt_tile", prev)
+    assert not bool(torch.isnan(outs[0].float()).any())
+    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+
+
 @pytest.mark.parametrize("M,N,K_,ta,tb,act,acc,bias", [
     (420, 512, 80, False, True, 0, False, True),       # forward x W^T + b (linear_in of the d_model 512 golden case)
     (420, 1024, 512, False, True, 1, False, True),     # forward with ReLU (w_1)
