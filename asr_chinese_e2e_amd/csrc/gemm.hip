@@ -1648,6 +1648,177 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
     }
 }
 
+// ------------------------------------------------------------------------- TN, loader / consumer waves
+// The weight-gradient kernel above is balanced on paper - a 64-row stage of a 128 x 128 tile is 32 one-KiB DMA instructions (512
+// cycles of the CU's vector-memory issue) against 16 MFMAs per SIMD (512 cycles) - but each wave issues its 8 DMA instructions
+// between its own MFMAs and runs ~730 cycles per stage.  Same split as gemm_nt_spec_kernel: waves 4..7 only load (8 pieces per
+// stage each, TRING - 1 stages ahead, counted vmcnt, zero-page redirection of a ragged last stage), waves 0..3 only compute
+// (unchanged 64 x 64 wave tiles, transposed fragment reads with hand-counted lgkmcnt) and add the tile to memory.  Same stages,
+// same ring, same split of the M range, same accumulation order per element.
+template <int TRING>
+__global__ __launch_bounds__(512) void gemm_tn_spec_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N, int K,
+                                                           int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split, int use_atomic,
+                                                           const void* __restrict__ zero_page, float* __restrict__ dbias, size_t split_stride,
+                                                           int bias_split_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ts[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = tiles_k * tiles_n;
+    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    const int split = vid / ntiles, tile = vid - split * ntiles;
+    const int tk = tile % tiles_k, tn = tile / tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    constexpr int SR = TM;                     // rows per ring slot
+    constexpr int SBYTES = TSTAGE;             // bytes per ring slot: [dY 64 x 256 B | X 64 x 256 B]
+    const int nsteps = (mend - mbeg + SR - 1) / SR;
+    if (nsteps <= 0) return;
+    if (w >= 4) {
+        // ================================================================ loader waves: lw 0, 1 stage dY, lw 2, 3 stage X
+        const int lw = w - 4;
+        const int lrow = lane >> 4, slot = lane & 15;
+        const bool is_y = lw < 2;
+        const bf16_t* cur[8];
+        int prow[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gg = (lw & 1) * 8 + j;
+            const int row = 4 * gg + lrow;
+            const int col = (slot ^ (4 * (row & 3))) * 8;
+            prow[j] = row;
+            cur[j] = is_y ? dY + (size_t)(mbeg + row) * ldy + min(n0 + col, N - 8) : X + (size_t)(mbeg + row) * ldx + min(k0 + col, K - 8);
+        }
+        const size_t stage_step = (size_t)SR * (is_y ? ldy : ldx);
+        const bool ragged = ((mend - mbeg) % SR) != 0;
+        int it = 0, it_slot = 0;
+        auto fix_last = [&]() {
+            if (ragged && it == nsteps - 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cur[j] = (mbeg + it * SR + prow[j] < mend) ? cur[j] : (const bf16_t*)zero_page;
+            }
+        };
+        auto issue_stage = [&]() {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)cur[j], (lds_void_t*)(smem_ts + it_slot * SBYTES + (lw * 8 + j) * 1024), 16, 0, 0);
+            ++it;
+            it_slot = it_slot == TRING - 1 ? 0 : it_slot + 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[j] += stage_step;
+            fix_last();
+        };
+        fix_last();
+        for (int p = 0; p < TRING - 1 && p < nsteps; ++p) issue_stage();
+        for (int i = 0; i < nsteps; ++i) {
+            const int younger = min(TRING - 2, nsteps - 1 - i);      // stages issued after stage i that may still be in flight
+            if (TRING >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (TRING >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // stage i is complete for the consumers; they have finished stage i - 1, whose slot is refilled now
+            if (it < nsteps) issue_stage();
+        }
+        __builtin_amdgcn_s_barrier();          // the consumers' barrier(s) of the bias reduction / end
+        if (dbias != nullptr && tk == 0) __builtin_amdgcn_s_barrier();
+        return;
+    }
+    // ==================================================================== consumer waves
+    dW += (size_t)split * split_stride;
+    const int wn = w >> 1, wk = w & 1;
+    f32x16 acc[2][2];  // [ni][ki]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_ts;
+    const unsigned y_off[2] = {tn_frag_off(wn * 64, lane), tn_frag_off(wn * 64 + 32, lane)};
+    const unsigned x_off[2] = {SR * 256 + tn_frag_off(wk * 64, lane), SR * 256 + tn_frag_off(wk * 64 + 32, lane)};
+    const bool do_bias = dbias != nullptr && tk == 0;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    const unsigned b_off = (unsigned)((tid >> 4) * 256 + (((tid & 15) ^ (4 * ((tid >> 4) & 3))) << 4));
+    int c_slot = 0;
+    for (int i = 0; i < nsteps; ++i) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned sbase = lds_base + c_slot * SBYTES;
+        c_slot = c_slot == TRING - 1 ? 0 : c_slot + 1;
+        bf16x8 yf[2][2], xf[2][2];
+#define TNS_LOAD(BUF, S)                                             \
+    do {                                                             \
+        yf[BUF][0] = tn_frag_swz<S>(sbase + y_off[0]);               \
+        yf[BUF][1] = tn_frag_swz<S>(sbase + y_off[1]);               \
+        xf[BUF][0] = tn_frag_swz<S>(sbase + x_off[0]);               \
+        xf[BUF][1] = tn_frag_swz<S>(sbase + x_off[1]);               \
+    } while (0)
+#define TNS_MMA(BUF)                                                                                                          \
+    do {                                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                       \
+            const int ni = q >> 1, ki = q & 1;                                                                                \
+            acc[ni][ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[BUF][ni], xf[BUF][ki], acc[ni][ki], 0, 0, 0);            \
+        }                                                                                                                     \
+    } while (0)
+        if (do_bias) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const u32x4 c8 = *(const u32x4*)(smem_ts + (sbase - lds_base) + b_off + qq * 16 * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(c8[e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(c8[e] & 0xffff0000u);
+                }
+            }
+        }
+        TNS_LOAD(0, 0);
+        TNS_LOAD(1, 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TNS_MMA(0);
+        TNS_LOAD(0, 2);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TNS_MMA(1);
+        TNS_LOAD(1, 3);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TNS_MMA(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TNS_MMA(1);
+#undef TNS_LOAD
+#undef TNS_MMA
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+            const int kc = k0 + wk * 64 + ki * 32 + (lane & 31);
+            if (kc >= K) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + ni * 32 + acc_row(e, lane);
+                if (n >= N) continue;
+                float* dst = dW + (size_t)n * ldw + kc;
+                if (use_atomic) atomicAdd(dst, acc[ni][ki][e]);
+                else *dst = acc[ni][ki][e];
+            }
+        }
+    __builtin_amdgcn_s_barrier();      // every consumer has finished its LDS reads of the ring (pairs with the loaders' barrier)
+    if (do_bias) {   // 16 row phases -> one sum per column, through the (now idle) ring memory
+        float* red = (float*)smem_ts;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
+        __builtin_amdgcn_s_barrier();
+        if (tid < 128 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < 16; ++ph) t += red[ph * 128 + tid];
+            if (bias_split_stride) dbias[(size_t)split * bias_split_stride + n0 + tid] = t;
+            else atomicAdd(dbias + n0 + tid, t);
+        }
+    }
+}
+
 template <int S>
 __device__ __forceinline__ bf16x8 tg_frag(unsigned addr) {   // tn_frag_swz through the builtin (compiler-counted lgkmcnt)
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(size_t)(addr + S * 4096));
@@ -2305,6 +2476,10 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
             gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE + lds_pad, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
         } else if (tn_cfg == 2 && ring == 4) {   // 2-stage ring, 64 KiB, still one workgroup per CU
             gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
+        } else if (tn_cfg != 4 && ring == 4 && !eight && asr_option(ASR_OPT_TN_CFG) == 1) {   // tuning option "tn_cfg" = 1: loader / consumer waves, 3-stage ring
+            static bool once_s = false;
+            if (!once_s) { (void)hipFuncSetAttribute((const void*)gemm_tn_spec_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); once_s = true; }
+            gemm_tn_spec_kernel<3><<<grid, 512, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
         } else if (tn_cfg != 4 && ring == 4 && !eight) {   // default: 3-stage ring, 96 KiB (step 3.74 vs 3.79 ms with 4 stages = 128 KiB, although the kernel alone is 1-5 % slower)
             static bool once3 = false;
             if (!once3) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); once3 = true; }

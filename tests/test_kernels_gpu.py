@@ -771,6 +771,28 @@ def test_gemm_tn(K, M, N, K_):
     close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn bias gradient")
 
 
+@pytest.mark.parametrize("M,N,K_", [(16000, 1536, 512), (16000, 512, 512), (16000, 512, 1024), (8197, 512, 512), (4000, 1536, 512), (300, 128, 128)])
+def test_gemm_tn_loader_consumer_form(K, M, N, K_):
+    """The loader / consumer form of the weight-gradient kernel (gemm_tn_spec_kernel, tuning option tn_cfg = 1): same values as the
+    fp64 product, weight gradient and fused bias gradient, accumulate and overwrite, ragged M (zero-page redirection of the last stage)."""
+    torch.manual_seed(M + K_)
+    dy = (torch.randn(M, N) * 0.5 + 0.05).bfloat16().to(DEV)
+    x = torch.randn(M, K_).bfloat16().to(DEV)
+    ref = dy.double().cpu().t() @ x.double().cpu()
+    prev = K.set_option("tn_cfg", 1)
+    try:
+        dw = torch.ones(N, K_, device=DEV)
+        db = torch.full((N,), 2.0, device=DEV)
+        K.gemm_tn(dy, x, dw, accumulate=True, dbias=db)
+        dw2 = torch.full((N, K_), float("nan"), device=DEV)
+        K.gemm_tn(dy, x, dw2, accumulate=False)
+    finally:
+        K.set_option("tn_cfg", prev)
+    close(dw - 1, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="gemm_tn loader/consumer accumulate")
+    close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn loader/consumer bias gradient")
+    close(dw2, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="gemm_tn loader/consumer overwrite")
+
+
 @pytest.mark.parametrize("M,N,K_", [(16000, 512, 512), (16000, 4232, 512), (1000, 1536, 512), (8197, 264, 72)])
 def test_gemm_tn_deterministic_mode(K, ws, deterministic_mode, M, N, K_):
     """ASR_DETERMINISTIC / asr_set_deterministic: partial tiles of the M-splits go to slabs that a second pass adds in split
