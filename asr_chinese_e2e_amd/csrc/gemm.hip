@@ -1446,7 +1446,7 @@ template <int TRING, int G>
 __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
                                                              int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
                                                              int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias, size_t split_stride,
-                                                             int bias_split_stride) {
+                                                             int bias_split_stride, int skew = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = tiles_k * tiles_n;
@@ -1454,7 +1454,9 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
     const int split = vid / ntiles, tile = vid - split * ntiles;
     const int tk = tile % tiles_k, tn = tile / tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
-    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    // skew > 0 (the default; tuning option "tn_cfg" = 3 switches it off): split s reduces rows_per_split + skew * s rows, so the splits - which all add their tile
+    // to memory with fp32 atomics when they finish - finish one after the other instead of together
+    const int mbeg = split * rows_per_split + skew * (split * (split - 1) / 2), mend = min(M, mbeg + rows_per_split + skew * split);
     constexpr int SR = TM * G;                 // rows per ring slot
     constexpr int SBYTES = TSTAGE * G;         // bytes per ring slot: [dY SR x 256 B | X SR x 256 B]
     const int nsteps = (mend - mbeg + SR - 1) / SR;
@@ -2384,8 +2386,9 @@ static TnPlan tn_plan(int M, int N, int K) {
         const int s_floor = cus / tiles > 0 ? cus / tiles : 1;
         if (tiles * s_floor * 5 >= cus * 4) { splits = s_floor; ring = 4; }   // "4" = the one-per-CU form <2, 2>
         else { splits = ceil_div(2 * cus, tiles) > 1 ? (2 * cus) / tiles : 1; ring = 2; }
-        static const int split_pct = getenv("ASR_GEMM_TN_SPLIT_PCT") ? atoi(getenv("ASR_GEMM_TN_SPLIT_PCT")) : 100;   // tuning: fewer, longer workgroups
-        splits = splits * split_pct / 100;
+        static const int split_env = getenv("ASR_GEMM_TN_SPLIT_PCT") ? atoi(getenv("ASR_GEMM_TN_SPLIT_PCT")) : 100;   // tuning: fewer, longer workgroups
+        const int split_opt = asr_option(ASR_OPT_TN_SPLIT);      // run-time form (tuning option "tn_split", percent; 0 = unset)
+        splits = splits * (split_opt > 0 ? split_opt : split_env) / 100;
         if (splits > max_s) splits = max_s;
         if (splits < 1) splits = 1;
     }
@@ -2456,6 +2459,18 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
         zero_f32_kernel<<<g < 1024 ? g : 1024, 256, 0, st>>>(dW, N, K, ldw);
     }
     const int grid = tiles * nsplit;
+    // Staggered M-splits (default since round 3; tuning option "tn_cfg" = 3: equal splits): lengths r0 + skew * s, s = 0 .. nsplit - 1, from
+    // ~0.75 to ~1.25 of the mean (the spread, in percent of the mean, is the tuning option "spare", default 50), all multiples of the 64-row
+    // stage, covering M.  Every split ends by adding its 128 x 128 tile to memory with fp32 atomics (256 workgroups x 64 KiB = 16 MB per
+    // launch at the chip's 1.3 TB/s atomic rate): splits that finish one after the other put that traffic under the others' compute.
+    int sk_r0 = rows_per_split, sk_skew = 0;
+    if (asr_option(ASR_OPT_TN_CFG) != 3 && nsplit >= 3 && !eight) {
+        const int spread = asr_option(ASR_OPT_SPARE) > 0 ? asr_option(ASR_OPT_SPARE) : 50;
+        sk_skew = (int)((long long)rows_per_split * spread / 100 / (nsplit - 1)) / TM * TM;
+        const int tri = nsplit * (nsplit - 1) / 2;
+        sk_r0 = ceil_div(ceil_div(M - sk_skew * tri > 0 ? M - sk_skew * tri : M, nsplit), TM) * TM;
+        if (sk_skew <= 0 || sk_r0 < 4 * TM || sk_r0 * (nsplit - 1) + sk_skew * ((nsplit - 1) * (nsplit - 2) / 2) >= M) { sk_r0 = rows_per_split; sk_skew = 0; }      // the last split must start inside the range
+    }
     if (tn_cfg == 1) {
         if (dbias) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bias_bf16: the register-staged kernel (ASR_GEMM_TN_CFG=1) has no bias path");
         gemm_tn_kernel<<<grid, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, split_stride);
@@ -2483,11 +2498,13 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
         } else if (tn_cfg != 4 && ring == 4 && !eight) {   // default: 3-stage ring, 96 KiB (step 3.74 vs 3.79 ms with 4 stages = 128 KiB, although the kernel alone is 1-5 % slower)
             static bool once3 = false;
             if (!once3) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); once3 = true; }
-            gemm_tn_dma_kernel<3, 1><<<grid, 256, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
+            int r0 = rows_per_split, skew = 0;
+            r0 = sk_r0; skew = sk_skew;
+            gemm_tn_dma_kernel<3, 1><<<grid, 256, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, r0, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride, skew);
         } else
         if (ring == 4 && !eight) gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
         else if (ring == 4) gemm_tn_dma_kernel<2, 2><<<grid, 512, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
-        else gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
+        else gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, sk_r0, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride, sk_skew);
     }
     if (det) {
         const size_t total4 = (size_t)N * K / 4;

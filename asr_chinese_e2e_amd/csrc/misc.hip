@@ -37,7 +37,7 @@ extern "C" int asr_set_deterministic(int on) {
 // ---- tuning options: process-wide integer switches that select between CORRECT variants of a kernel (store policy, tile shape ...),
 // settable at run time so that two variants can be timed alternately inside one process (box-to-box noise is ~2 %).
 // Initial value: environment variable ASR_OPT_<NAME upper case>, else the built-in default.
-static const char* const g_opt_names[ASR_OPT_COUNT] = {"nt_store", "nt_tile", "ln_store", "sdpa_store", "tn_cfg", "spare"};
+static const char* const g_opt_names[ASR_OPT_COUNT] = {"nt_store", "nt_tile", "tn_split", "sdpa_store", "tn_cfg", "spare"};
 static int g_opt_val[ASR_OPT_COUNT];
 static bool g_opt_init = false;
 static void opt_init() {

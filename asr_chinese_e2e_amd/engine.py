@@ -392,6 +392,8 @@ class Engine:
         self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
+        # ASR_WGRAD_SPLIT="fc:25,w2:50": percent of the planned M-splits for the named projections' weight gradients (tuning experiments)
+        self._wgrad_split = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in os.environ.get("ASR_WGRAD_SPLIT", "").split(",") if ":" in kv}
         self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
@@ -545,6 +547,15 @@ class Engine:
             self._deferred.append((lin, dy, x, bias_from))
             return
         fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
+        split_pct = self._wgrad_split.get(lin.tag) if not self._in_decoder else None      # experiment: fewer M-splits (less atomic traffic) for one projection
+        if split_pct:
+            K.set_option("tn_split", split_pct)
+            try:
+                self._wgrad_split, hold = {}, self._wgrad_split
+                return self._wgrad(lin, dy, x, bias_from)
+            finally:
+                self._wgrad_split = hold
+                K.set_option("tn_split", 0)
         if self.group_wgrad and (self.group_wgrad != "decoder" or self._in_decoder) and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
                 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
             self._pending.append((dy, x, lin.gw, lin.gb if fused else None))     # launched by flush_wgrads (end of the layer)

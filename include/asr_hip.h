@@ -71,7 +71,8 @@ int asr_stream_fork(void* from_stream, void* to_stream);
 int asr_stream_create(int priority, void** out_stream);
 /* Tuning options: process-wide integer switches between CORRECT variants of a kernel (every value gives correct results), settable at
  * run time so that two variants can be timed alternately inside one process.  Names: "nt_store" (store policy of the NT GEMM's output tile:
- * 0 nt, 1 sc1 write-through, 2 plain, 3 sc0 sc1), "nt_tile" (0: 256 x 128 tiles with loader / consumer waves, 1: 256 x 128 with every wave loading and computing, 2: 256 x 256 wherever the shape allows, 3: by shape), "ln_store", "sdpa_store", "tn_cfg".  Initial values: ASR_OPT_<NAME>
+ * 0 nt, 1 sc1 write-through, 2 plain, 3 sc0 sc1), "nt_tile" (0: 256 x 128 tiles with loader / consumer waves, 1: 256 x 128 with every wave loading and computing, 2: 256 x 256 wherever the shape allows, 3: by shape), "tn_cfg" (weight-gradient kernel: 0 four waves with staggered M-splits, 1 loader / consumer waves, 3 equal M-splits), "spare" (spread of the
+ * staggered splits in percent of their mean length), "tn_split" (M-splits of the weight-gradient kernel in percent of the plan's), "sdpa_store" (reserved).  Initial values: ASR_OPT_<NAME>
  * in the environment, else the defaults.  previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
 int asr_set_option(const char* name, int value, int* previous);
 int asr_get_deterministic(void);

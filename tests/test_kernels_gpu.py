@@ -771,15 +771,17 @@ def test_gemm_tn(K, M, N, K_):
     close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn bias gradient")
 
 
-@pytest.mark.parametrize("M,N,K_", [(16000, 1536, 512), (16000, 512, 512), (16000, 512, 1024), (8197, 512, 512), (4000, 1536, 512), (300, 128, 128)])
-def test_gemm_tn_loader_consumer_form(K, M, N, K_):
-    """The loader / consumer form of the weight-gradient kernel (gemm_tn_spec_kernel, tuning option tn_cfg = 1): same values as the
-    fp64 product, weight gradient and fused bias gradient, accumulate and overwrite, ragged M (zero-page redirection of the last stage)."""
+@pytest.mark.parametrize("cfg", [1, 3])
+@pytest.mark.parametrize("M,N,K_", [(16000, 1536, 512), (16000, 512, 512), (16000, 512, 1024), (8197, 512, 512), (4000, 1536, 512), (300, 128, 128), (16000, 1024, 512)])
+def test_gemm_tn_loader_consumer_form(K, M, N, K_, cfg):
+    """The optional forms of the weight-gradient kernel (tuning option tn_cfg): 1 = loader / consumer waves (gemm_tn_spec_kernel), 3 = M-splits
+    of equal length (the default staggers them: they finish - and add their tiles with atomics - one after the other).  Same values as the fp64 product, weight
+    gradient and fused bias gradient, accumulate and overwrite, ragged M (zero-page redirection of the last stage)."""
     torch.manual_seed(M + K_)
     dy = (torch.randn(M, N) * 0.5 + 0.05).bfloat16().to(DEV)
     x = torch.randn(M, K_).bfloat16().to(DEV)
     ref = dy.double().cpu().t() @ x.double().cpu()
-    prev = K.set_option("tn_cfg", 1)
+    prev = K.set_option("tn_cfg", cfg)
     try:
         dw = torch.ones(N, K_, device=DEV)
         db = torch.full((N,), 2.0, device=DEV)
