@@ -147,14 +147,14 @@ __device__ __forceinline__ float wave_row_lse_regs(const u32x4 (&xv)[NV], int nv
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict__ logits, const int32_t* __restrict__ in_len,
                                                              const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                             double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int Lmax,
+                                                             double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int ld, int Lmax,
                                                              int W, int blank) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
         const int b = row / T_, t = row - b * T_;
         if (t >= in_len[b]) continue;
-        const T* x = logits + (size_t)row * V;
+        const T* x = logits + (size_t)row * ld;
         const float lse = wave_row_lse<T>(x, V, lane, nullptr);
         if (lane == 0) lse_out[row] = lse;
         const int L = lab_len[b];
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict
 template <int NV, bool WRITE>
 __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* logits, const int32_t* __restrict__ in_len,
                                                                   const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                                  double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int Lmax,
+                                                                  double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int ld, int Lmax,
                                                                   int W, int blank, bf16_t* dlogits, float scale_in, const float* __restrict__ scale_div) {
     const float scale = scale_div ? scale_in / *scale_div : scale_in;     // scale_div: a device scalar (global batch under data parallelism)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -186,11 +186,11 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* 
         if (t >= in_len[b]) {
             if (WRITE) {
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                for (int i = lane; i < nvec; i += 64) *(u32x4*)(dlogits + (size_t)row * V + (size_t)i * 8) = z;
+                for (int i = lane; i < nvec; i += 64) *(u32x4*)(dlogits + (size_t)row * ld + (size_t)i * 8) = z;
             }
             continue;
         }
-        const bf16_t* x = logits + (size_t)row * V;
+        const bf16_t* x = logits + (size_t)row * ld;
         u32x4 xv[NV];
         wave_row_load<NV>(x, nvec, lane, xv);
         const int L = lab_len[b];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* 
         const float lse = wave_row_lse_regs<NV>(xv, nvec, lane);
         if (lane == 0) lse_out[row] = lse;
         if (WRITE) {
-            bf16_t* dl = dlogits + (size_t)row * V;
+            bf16_t* dl = dlogits + (size_t)row * ld;
             const float lb = lse * LOG2E;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const double* __restrict__ alpha, const double* __restrict__ beta,
                                                        const float* __restrict__ lse_in, const int32_t* __restrict__ in_len,
                                                        const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                       const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank,
+                                                       const float* __restrict__ nll_raw, int B, int T_, int V, int ld, int Lmax, int W, int blank,
                                                        float scale_in, int det, const float* __restrict__ scale_div) {
     const float scale = scale_div ? scale_in / *scale_div : scale_in;
     extern __shared__ __attribute__((aligned(16))) float occ[];  // V floats: posterior mass per label
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     __syncthreads();
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         const int b = row / T_, t = row - b * T_;
-        T* dl = dlogits + (size_t)row * V;
+        T* dl = dlogits + (size_t)row * ld;
         // padded frame, or infeasible utterance (nll = +inf): zero gradient
         if (t >= in_len[b] || nll_raw[b] == INFINITY) {
             if (V % N == 0) {
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
             }
             continue;
         }
-        const T* x = logits + (size_t)row * V;
+        const T* x = logits + (size_t)row * ld;
         const int L = lab_len[b];
         const float lse = lse_in[row];
         if (threadIdx.x < 64) {
@@ -550,21 +550,21 @@ __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const bf16_t* __rest
                                                             const double* __restrict__ alpha, const double* __restrict__ beta,
                                                             const float* __restrict__ lse_in, const int32_t* __restrict__ in_len,
                                                             const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank,
+                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int ld, int Lmax, int W, int blank,
                                                             float scale_in, const float* __restrict__ scale_div) {
     const float scale = scale_div ? scale_in / *scale_div : scale_in;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_, nvec = V >> 3;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
         const int b = row / T_, t = row - b * T_;
-        bf16_t* dl = dlogits + (size_t)row * V;
+        bf16_t* dl = dlogits + (size_t)row * ld;
         // padded frame, or infeasible utterance (nll = +inf): zero gradient
         if (t >= in_len[b] || nll_raw[b] == INFINITY) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (int i = lane; i < nvec; i += 64) *(u32x4*)(dl + (size_t)i * 8) = z;
             continue;
         }
-        const bf16_t* x = logits + (size_t)row * V;
+        const bf16_t* x = logits + (size_t)row * ld;
         u32x4 xv[NV];
         wave_row_load<NV>(x, nvec, lane, xv);
         const int L = lab_len[b];
@@ -640,14 +640,14 @@ __global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256) void ctc_label_fix_kernel(bf16_t* __restrict__ dlogits, const double* __restrict__ lp, const double* __restrict__ alpha,
                                                             const double* __restrict__ beta, const int32_t* __restrict__ in_len,
                                                             const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int Lmax, int W, int blank, float scale_in, const float* __restrict__ scale_div) {
+                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int ld, int Lmax, int W, int blank, float scale_in, const float* __restrict__ scale_div) {
     const float scale = scale_div ? scale_in / *scale_div : scale_in;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_, nvec = V >> 3;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
         const int b = row / T_, t = row - b * T_;
         if (t >= in_len[b]) continue;           // already zero
-        bf16_t* dl = dlogits + (size_t)row * V;
+        bf16_t* dl = dlogits + (size_t)row * ld;
         if (nll_raw[b] == INFINITY) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (int i = lane; i < nvec; i += 64) *(u32x4*)(dl + (size_t)i * 8) = z;
@@ -792,10 +792,11 @@ extern "C" size_t asr_ctc_workspace_bytes(int B, int T, int Lmax) {
 }
 
 extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len, const int32_t* labels, const int32_t* lab_len,
-                               float* nll, int B, int T, int V, int Lmax, int blank, float grad_scale, const float* grad_scale_div,
+                               float* nll, int B, int T, int V, int ld, int Lmax, int blank, float grad_scale, const float* grad_scale_div,
                                int zero_infinity, void* ws, size_t ws_bytes, int dtype, void* stream) {
     if (!logits || !in_len || !labels || !lab_len || !nll || !ws) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: null pointer");
     if (B <= 0 || T <= 0 || V <= 1 || Lmax <= 0 || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: bad shape B=%d T=%d V=%d Lmax=%d blank=%d", B, T, V, Lmax, blank);
+    if (ld < V || (ld != V && ld % 8)) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: row stride ld=%d (V=%d): V, or a multiple of 8 above it", ld, V);
     if (Lmax > 255) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: Lmax = %d: label sequences longer than 255 are not supported", Lmax);
     if (ws_bytes < asr_ctc_workspace_bytes(B, T, Lmax)) ASR_FAIL(ASR_EWORKSPACE, "asr_ctc_fwd_bwd: workspace %zu < %zu", ws_bytes, asr_ctc_workspace_bytes(B, T, Lmax));
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_ctc_fwd_bwd: dtype %d", dtype);
@@ -814,7 +815,7 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     // bf16 rows of whole 16-byte vectors that fit a wave's registers take the row-in-registers kernels
     const int need = ceil_div(V / 8, 64);
     static const int ctc_split = getenv("ASR_CTC_SPLIT") ? atoi(getenv("ASR_CTC_SPLIT")) : 1;
-    const bool rows_path = dtype == ASR_BF16 && V % 8 == 0 && need <= 16 && ((uintptr_t)logits % 16) == 0 && (!dlogits || ((uintptr_t)dlogits % 16) == 0);
+    const bool rows_path = dtype == ASR_BF16 && V % 8 == 0 && ld % 8 == 0 && need <= 16 && ((uintptr_t)logits % 16) == 0 && (!dlogits || ((uintptr_t)dlogits % 16) == 0);
 #define ROWS_DISPATCH(CALL)           \
     do {                              \
         if (need <= 2) { CALL(2); }   \
@@ -828,16 +829,16 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
         // with a gradient: the softmax part of it is written by the same wave that reduces the row (one pass over
         // the logits less); ASR_CTC_SPLIT=0 keeps the separate gradient kernel (A/B runs)
         if (dlogits && ctc_split) {
-#define K1(NV) ctc_lse_gather_rows_kernel<NV, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, (bf16_t*)dlogits, grad_scale, grad_scale_div)
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, (bf16_t*)dlogits, grad_scale, grad_scale_div)
             ROWS_DISPATCH(K1);
 #undef K1
         } else {
-#define K1(NV) ctc_lse_gather_rows_kernel<NV, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank, nullptr, 0.f, nullptr)
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, nullptr, 0.f, nullptr)
             ROWS_DISPATCH(K1);
 #undef K1
         }
-    } else if (dtype == ASR_F32) ctc_lse_gather_kernel<float><<<g1, 256, 0, st>>>((const float*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
-    else ctc_lse_gather_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, Lmax, W, blank);
+    } else if (dtype == ASR_F32) ctc_lse_gather_kernel<float><<<g1, 256, 0, st>>>((const float*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank);
+    else ctc_lse_gather_kernel<bf16_t><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank);
 #define AB(N) ctc_alpha_beta_kernel<N><<<B, 128, 0, st>>>(lp, alpha, beta, in_len, labels, lab_len, nll, nll_raw, T, Lmax, blank, zero_infinity)
     if (W == 32) AB(32);
     else if (W == 64) AB(64);
@@ -847,13 +848,13 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     if (dlogits) {
         int g3 = rows < 2048 ? rows : 2048;
         if (rows_path && ctc_split) {
-            ctc_label_fix_kernel<<<g1, 256, 0, st>>>((bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, grad_scale_div);
+            ctc_label_fix_kernel<<<g1, 256, 0, st>>>((bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, grad_scale_div);
         } else if (rows_path) {
-#define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, grad_scale_div)
+#define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, grad_scale_div)
             ROWS_DISPATCH(K3);
 #undef K3
-        } else if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
-        else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
+        } else if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
+        else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
     }
     ASR_CHECK_LAUNCH("asr_ctc_fwd_bwd");
     return ASR_OK;

@@ -24,7 +24,7 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 // one wave per frame; frames at or past in_len[b] get `blank`
 template <typename T>
 __global__ __launch_bounds__(256) void frame_argmax_kernel(const T* __restrict__ logits, const int32_t* __restrict__ in_len, int32_t* __restrict__ path,
-                                                           int B, int T_, int V, int blank) {
+                                                           int B, int T_, int V, int ld, int blank) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void frame_argmax_kernel(const T* __restrict__
             if (lane == 0) path[row] = blank;
             continue;
         }
-        const T* x = logits + (size_t)row * V;
+        const T* x = logits + (size_t)row * ld;
         float best = -INFINITY;
         int bi = 0x7fffffff;
         if constexpr (sizeof(T) == 2) {
@@ -89,17 +89,18 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(int32_t* __restrict__ 
 
 }  // namespace
 
-extern "C" int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* out_ids, int32_t* out_len, int B, int T, int V, int blank,
+extern "C" int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* out_ids, int32_t* out_len, int B, int T, int V, int ld, int blank,
                                      int dtype, void* stream) {
     if (!logits || !in_len || !out_ids || !out_len) ASR_FAIL(ASR_EINVAL, "asr_ctc_greedy_decode: null pointer");
     if (B <= 0 || T <= 0 || V <= 1 || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_greedy_decode: bad shape B=%d T=%d V=%d blank=%d", B, T, V, blank);
+    if (ld < V) ASR_FAIL(ASR_EINVAL, "asr_ctc_greedy_decode: row stride ld=%d < V=%d", ld, V);
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_ctc_greedy_decode: dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
     const int rows = B * T;
     int g = ceil_div(rows, 4);
     if (g > 4096) g = 4096;
-    if (dtype == ASR_F32) frame_argmax_kernel<float><<<g, 256, 0, st>>>((const float*)logits, in_len, out_ids, B, T, V, blank);
-    else frame_argmax_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)logits, in_len, out_ids, B, T, V, blank);
+    if (dtype == ASR_F32) frame_argmax_kernel<float><<<g, 256, 0, st>>>((const float*)logits, in_len, out_ids, B, T, V, ld, blank);
+    else frame_argmax_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)logits, in_len, out_ids, B, T, V, ld, blank);
     ctc_collapse_kernel<<<B, 64, 0, st>>>(out_ids, in_len, out_len, T, blank);
     ASR_CHECK_LAUNCH("asr_ctc_greedy_decode");
     return ASR_OK;

@@ -429,13 +429,14 @@ extern "C" int asr_relu_fwd(void* x, size_t n, int dtype, void* stream) {
     return ASR_OK;
 }
 
-// Batched 2-D transposes inside one flat bf16 buffer: tile t of `tiles` = {element offset of the matrix,
-// rows N, cols K, (tile row << 16) | tile col}; dst[off + k * N + n] = src[off + n * K + k].
+// Batched 2-D transposes out of one flat bf16 buffer: tile t of `tiles` = {element offset of the matrix in src, rows N, cols K,
+// (tile row << 16) | tile col, element offset of the copy in dst, row stride of the copy};
+// dst[dst_off + k * ldd + n] = src[src_off + n * K + k].
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int32_t* __restrict__ tiles) {
     __shared__ bf16_t tile[64][66];
-    const int32_t* e = tiles + 4 * (size_t)blockIdx.x;
-    const size_t off = (size_t)(uint32_t)e[0];
-    const int N = e[1], K = e[2], r0 = (e[3] >> 16) * 64, c0 = (e[3] & 0xffff) * 64;
+    const int32_t* e = tiles + 6 * (size_t)blockIdx.x;
+    const size_t off = (size_t)(uint32_t)e[0], doff = (size_t)(uint32_t)e[4];
+    const int N = e[1], K = e[2], r0 = (e[3] >> 16) * 64, c0 = (e[3] & 0xffff) * 64, ldd = e[5];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = c0 + ty + 4 * i, r = r0 + tx;
-        if (r < N && c < K) dst[off + (size_t)c * N + r] = tile[tx][ty + 4 * i];
+        if (r < N && c < K) dst[doff + (size_t)c * ldd + r] = tile[tx][ty + 4 * i];
     }
 }
 

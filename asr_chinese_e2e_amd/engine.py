@@ -327,6 +327,13 @@ class Engine:
                          FFN(flat, f"decoder.layer_stack.{i}.pos_ffn.", d, ff)) for i in range(self.L)]
         if use_ctc:
             self.ctc_lo = Linear(flat, ["ctc_lo.weight"], ["ctc_lo.bias"], vocab_size, d)
+        # row stride of the CTC head's logits / gradient rows in the training step: whole 128-byte lines (bf16: multiples of 64
+        # elements; V = 4232 -> 4288).  With dense rows of 8464 B every row of a GEMM tile straddles one line more and shares
+        # its first and last line with the neighbouring tiles: head GEMM 110 -> 94 us, its input gradient 87 -> 76 us
+        # (tools/gemm_bench.py pad).  ASR_PAD_LOGITS=0: dense rows.
+        self.ld_v = vocab_size
+        if self.dtype == torch.bfloat16 and vocab_size % 8 == 0 and os.environ.get("ASR_PAD_LOGITS", "1") != "0":
+            self.ld_v = (vocab_size + 63) // 64 * 64
         self.grad_ready = None  # callback(offset): gradients at flat offsets >= offset are final
         # Input gradients dX = dY W of the encoder projections run on the own persistent NT kernel, as NT products with
         # transposed bf16 weight copies (one batched transpose launch per step on the side stream, idle during the forward
@@ -342,11 +349,20 @@ class Engine:
             # ... and the CTC head (reduction over V = 4232 columns: the kernel's last k-step is ragged)
             head = [self.ctc_lo] if use_ctc else []
             lins = [l for l in lins + cross_qkv + head if l.N % 8 == 0 and l.K % 8 == 0]
-            flat.lpT = torch.zeros_like(flat.lp)
+            # copies sit at the offsets of their matrices, rows N elements apart; the CTC head's (rows of V = 4232 elements = 8464 B:
+            # every row starts 16 B further into a 128-byte line) goes behind them with rows padded to whole lines (self.ld_v)
+            n_flat = (flat.lp.numel() + 63) // 64 * 64
+            pad_head = use_ctc and self.ld_v != self.V and self.ctc_lo in lins
+            flat.lpT = torch.zeros(n_flat + (self.ctc_lo.K * self.ld_v if pad_head else 0), dtype=flat.lp.dtype, device=flat.device)
             tiles = []
             for l in lins:
-                l.wlpT = flat.lpT[l.w_off:l.w_off + l.N * l.K].view(l.K, l.N)
-                tiles += [[l.w_off, l.N, l.K, (r << 16) | c] for r in range((l.N + 63) // 64) for c in range((l.K + 63) // 64)]
+                if pad_head and l is self.ctc_lo:
+                    dst_off, ldd = n_flat, self.ld_v
+                    l.wlpT = flat.lpT[n_flat:].view(l.K, ldd)[:, :l.N]
+                else:
+                    dst_off, ldd = l.w_off, l.N
+                    l.wlpT = flat.lpT[l.w_off:l.w_off + l.N * l.K].view(l.K, l.N)
+                tiles += [[l.w_off, l.N, l.K, (r << 16) | c, dst_off, ldd] for r in range((l.N + 63) // 64) for c in range((l.K + 63) // 64)]
             for _, cross, _ in (self.dec if getattr(self, "dec", None) else []):
                 if cross.qkv.wlpT is not None:
                     cross.kv.wlpT = cross.qkv.wlpT[:, cross.H * cross.dk:]      # (d, 2 H dk) view, row stride 3 H dk
@@ -392,8 +408,6 @@ class Engine:
         self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
-        # ASR_WGRAD_SPLIT="fc:25,w2:50": percent of the planned M-splits for the named projections' weight gradients (tuning experiments)
-        self._wgrad_split = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in os.environ.get("ASR_WGRAD_SPLIT", "").split(",") if ":" in kv}
         self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
@@ -547,15 +561,6 @@ class Engine:
             self._deferred.append((lin, dy, x, bias_from))
             return
         fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
-        split_pct = self._wgrad_split.get(lin.tag) if not self._in_decoder else None      # experiment: fewer M-splits (less atomic traffic) for one projection
-        if split_pct:
-            K.set_option("tn_split", split_pct)
-            try:
-                self._wgrad_split, hold = {}, self._wgrad_split
-                return self._wgrad(lin, dy, x, bias_from)
-            finally:
-                self._wgrad_split = hold
-                K.set_option("tn_split", 0)
         if self.group_wgrad and (self.group_wgrad != "decoder" or self._in_decoder) and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
                 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
             self._pending.append((dy, x, lin.gw, lin.gb if fused else None))     # launched by flush_wgrads (end of the layer)
@@ -748,12 +753,14 @@ class Engine:
 
     def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None, ws=None):
         """Returns (nll (B,), d_enc contribution or None)."""
-        logits = self.ctc_lo.fwd(enc)
-        nll, dl = K.ctc_fwd_bwd(logits.view(B, T, self.V), wave_len, labels32, lab_len, ws if ws is not None else self.ws, blank=0, grad_scale=grad_scale,
-                                dlogits=logits.view(B, T, self.V) if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div)
+        buf = torch.empty(B * T, self.ld_v, dtype=enc.dtype, device=enc.device)      # rows padded to whole lines (see self.ld_v)
+        logits = self.ctc_lo.fwd(enc, out=buf[:, :self.V])
+        frames = buf.view(B, T, self.ld_v)[:, :, :self.V]
+        nll, dl = K.ctc_fwd_bwd(frames, wave_len, labels32, lab_len, ws if ws is not None else self.ws, blank=0, grad_scale=grad_scale,
+                                dlogits=frames if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div)
         if not want_grad:
             return nll, None
-        dl = dl.view(B * T, self.V)
+        dl = logits      # the gradient was written in place
         self._wgrad(self.ctc_lo, dl, enc, bias_from=dl)
         d_enc = self.ctc_lo.dgrad(dl)
         # "ready(o)" means every gradient at flat offsets >= o is final.  ctc_lo sits BELOW the decoder

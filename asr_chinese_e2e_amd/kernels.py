@@ -258,24 +258,32 @@ def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=F
 
 
 # --------------------------------------------------------------------------------- losses
+def _frame_rows(logits):
+    """Row stride (elements) of a (B, T, V) tensor of frames: dense, or a view of rows padded to `ld` >= V elements."""
+    B, T, V = logits.shape
+    ld = logits.stride(1) if B * T > 1 else V
+    assert logits.stride(2) == 1 and ld >= V and (B == 1 or logits.stride(0) == T * ld), f"frames must be rows of one (B*T, ld) buffer: {logits.stride()}"
+    return ld
+
+
 def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, zero_infinity=False, dlogits=None,
                 want_grad=True, nll=None, grad_scale_div=None):
     """logits (B,T,V); returns (nll (B,), dlogits or None).  dlogits may alias logits.
     grad_scale_div: optional 1-element f32 device tensor; the gradient scale is then grad_scale / grad_scale_div[0]."""
     B, T, V = logits.shape
-    assert logits.is_contiguous()
+    ld = _frame_rows(logits)
     _chk_i32(in_len, labels, lab_len)
     Lmax = labels.shape[1]
     assert labels.shape[0] == B and in_len.numel() == B and lab_len.numel() == B
     nll = torch.empty(B, dtype=torch.float32, device=logits.device) if nll is None else nll
     if want_grad and dlogits is None:
-        dlogits = torch.empty_like(logits)
+        dlogits = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
     if dlogits is not None:
-        assert dlogits.is_contiguous() and dlogits.shape == logits.shape and dlogits.dtype == logits.dtype
+        assert dlogits.shape == logits.shape and dlogits.stride() == logits.stride() and dlogits.dtype == logits.dtype
     w = ws.get(lib.asr_ctc_workspace_bytes(B, T, Lmax))
     _chk_f32(grad_scale_div)
     timed("ctc", 0.0, lambda: check(
-        lib.asr_ctc_fwd_bwd(_p(logits), _p(dlogits), _p(in_len), _p(labels), _p(lab_len), _p(nll), B, T, V, Lmax,
+        lib.asr_ctc_fwd_bwd(_p(logits), _p(dlogits), _p(in_len), _p(labels), _p(lab_len), _p(nll), B, T, V, ld, Lmax,
                             int(blank), float(grad_scale), _p(grad_scale_div), int(zero_infinity), _p(w), w.numel(), _dt(logits), _stream()),
         "asr_ctc_fwd_bwd"), (3.0 if dlogits is not None else 1.0) * logits.numel() * logits.element_size())   # SURVEY 8(d): 3 B T V e
 
@@ -285,11 +293,11 @@ def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, ze
 def ctc_greedy_decode(logits, in_len, blank=0):
     """logits (B,T,V) -> (ids (B,T) int32, collapsed and 0-padded; lens (B,) int32)."""
     B, T, V = logits.shape
-    assert logits.is_contiguous()
+    ld = _frame_rows(logits)
     _chk_i32(in_len)
     ids = torch.empty(B, T, dtype=torch.int32, device=logits.device)
     lens = torch.empty(B, dtype=torch.int32, device=logits.device)
-    check(lib.asr_ctc_greedy_decode(_p(logits), _p(in_len), _p(ids), _p(lens), B, T, V, int(blank), _dt(logits), _stream()),
+    check(lib.asr_ctc_greedy_decode(_p(logits), _p(in_len), _p(ids), _p(lens), B, T, V, ld, int(blank), _dt(logits), _stream()),
           "asr_ctc_greedy_decode")
     return ids, lens
 
@@ -502,9 +510,9 @@ def gemm_nt_supported(M, N, K, lda, ldb, ldc):
 
 
 def transpose_batched(src, dst, tiles):
-    """Transposed copies of the matrices listed in `tiles` (int32 (ntiles, 4), see include/asr_hip.h) from the flat
-    bf16 buffer src into dst (same offsets)."""
-    assert src.dtype == dst.dtype == torch.bfloat16 and src.numel() == dst.numel() and tiles.dtype == torch.int32 and tiles.is_contiguous()
+    """Transposed copies of the matrices listed in `tiles` (int32 (ntiles, 6), see include/asr_hip.h) from the flat
+    bf16 buffer src into dst (each copy at its own offset and row stride)."""
+    assert src.dtype == dst.dtype == torch.bfloat16 and tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.shape[1] == 6
     check(lib.asr_transpose_batched_bf16(_p(src), _p(dst), _p(tiles), tiles.shape[0], _stream()), "asr_transpose_batched_bf16")
 
 

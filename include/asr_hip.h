@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 5
+#define ASR_ABI_VERSION 6
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -174,10 +174,12 @@ int asr_sdpa_dropout_mask(uint8_t* mask, int B, int H, int Tq, int Tk, float dro
  * NOT in the reference (it has only cross-entropy, Predictor/Utils/loss.py:26-51); required by
  * BASELINE.json north_star.  Semantics = torch.nn.functional.ctc_loss(log_softmax(logits), ...,
  * blank, reduction='none') and its gradient wrt logits (ATen native/LossCTC.cpp).
- * logits: (B, T, V) `dtype`;  in_len: (B) int32 frames per utterance (<= T);
+ * logits: (B, T, V) `dtype`, rows `ld` elements apart (ABI 6: ld = V for a dense tensor; the training engine pads rows to a
+ * multiple of 64 elements so that every row starts on a 128-byte line - with V = 4232 the head GEMM that writes them is 14 %
+ * faster; columns V .. ld are never read or written);  in_len: (B) int32 frames per utterance (<= T);
  * labels: (B, Lmax) int32 padded; lab_len: (B) int32 (<= Lmax <= 255).
  * nll: (B) f32 = -log p(labels | x) (+inf when infeasible; 0 if zero_infinity).
- * dlogits: (B, T, V) `dtype` (may alias logits) = scale * d(sum_b nll_b)/dlogits,
+ * dlogits: (B, T, V) `dtype`, same row stride (may alias logits) = scale * d(sum_b nll_b)/dlogits,
  * rows t >= in_len[b] are 0.  If dlogits is NULL only nll is computed.
  * scale = grad_scale, or grad_scale / *grad_scale_div when grad_scale_div (a DEVICE f32 scalar) is not NULL: under data
  * parallelism the CTC term is normalised by the GLOBAL batch, which arrives from an all-reduce on the device - the
@@ -185,7 +187,7 @@ int asr_sdpa_dropout_mask(uint8_t* mask, int B, int H, int Tq, int Tk, float dro
  */
 size_t asr_ctc_workspace_bytes(int B, int T, int Lmax);
 int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len,
-                    const int32_t* labels, const int32_t* lab_len, float* nll, int B, int T, int V,
+                    const int32_t* labels, const int32_t* lab_len, float* nll, int B, int T, int V, int ld,
                     int Lmax, int blank, float grad_scale, const float* grad_scale_div, int zero_infinity,
                     void* ws, size_t ws_bytes, int dtype, void* stream);
 
@@ -194,10 +196,11 @@ int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len,
  * torch.argmax), frames t >= in_len[b] count as blank, then the CTC collapse (merge repeats, drop
  * blanks).  NOT in the reference (no CTC there; its decoder-side search is the Python beam loop
  * transformer_official.py:331-434) - SURVEY.md 8(f) rank 1.
- * logits: (B, T, V) `dtype`; out_ids: (B, T) int32 = collapsed label ids, 0-padded; out_len: (B).
+ * logits: (B, T, V) `dtype`, rows `ld` elements apart (ABI 6; V for a dense tensor); out_ids: (B, T) int32 = collapsed label ids,
+ * 0-padded; out_len: (B).
  */
 int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* out_ids,
-                          int32_t* out_len, int B, int T, int V, int blank, int dtype, void* stream);
+                          int32_t* out_len, int B, int T, int V, int ld, int blank, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Beam search of the attention decoder, batched over utterances x beams
@@ -319,8 +322,10 @@ int asr_colsum(const void* x, float* out, void* ws, size_t ws_bytes, int rows, i
 /* dst (n) `dst_dtype` = src (n) `src_dtype`  (f32 <-> bf16 conversion / copy) */
 int asr_cast(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, void* stream);
 /* Transposed copies of many matrices that live in one flat bf16 buffer, one launch: for tile t,
- * tiles[4t..4t+3] = {element offset of its matrix, rows N, cols K, (tile row << 16) | tile col} (64 x 64
- * tiles); dst[off + k * N + n] = src[off + n * K + k].  Used for the W^T copies the input-gradient GEMMs
+ * tiles[6t..6t+5] = {element offset of its matrix in src, rows N, cols K, (tile row << 16) | tile col (64 x 64 tiles),
+ * element offset of the copy in dst, row stride ldd >= N of the copy} (ABI 6: the copy has its own offset and stride, so that
+ * the CTC head's W^T - rows of V = 4232 elements - can be padded to whole 128-byte lines);
+ * dst[dst_off + k * ldd + n] = src[src_off + n * K + k].  Used for the W^T copies the input-gradient GEMMs
  * (dX = dY W as an NT product, replacing autograd's mm backward of nn.Linear, attention.py:43-59, module.py:70-71) read. */
 int asr_transpose_batched_bf16(const void* src, void* dst, const int32_t* tiles, int ntiles, void* stream);
 

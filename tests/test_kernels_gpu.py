@@ -324,6 +324,42 @@ def test_ctc_greedy_decode(K, dtype, B, T, V):
         assert int(ids[b, int(n[b]):].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("dtype,B,T,V,ld", [(torch.bfloat16, 3, 40, 4232, 4288), (torch.bfloat16, 2, 24, 256, 320), (torch.float32, 2, 20, 12, 16),
+                                            (torch.bfloat16, 2, 20, 50, 56)])
+def test_ctc_padded_rows(K, ws, dtype, B, T, V, ld):
+    """Rows `ld` > V elements apart (the training engine pads the CTC head's rows to whole 128-byte lines): loss, gradient and greedy
+    path are bit-identical to the dense layout's, in place too, and the padding columns are never written."""
+    lt, in_len, labels, lab_len = ctc_case(21, B, T, V, 6, True, dtype)
+    dev = lambda a: torch.from_numpy(a).int().to(DEV)
+    nll0, dl0 = K.ctc_fwd_bwd(lt.to(DEV), dev(in_len), dev(labels), dev(lab_len), ws, grad_scale=0.25)
+    buf = torch.full((B * T, ld), 7.0, dtype=dtype, device=DEV)
+    frames = buf.view(B, T, ld)[:, :, :V]
+    frames.copy_(lt.to(DEV))
+    ids0, n0 = K.ctc_greedy_decode(lt.to(DEV), dev(in_len))
+    ids1, n1 = K.ctc_greedy_decode(frames, dev(in_len))
+    assert torch.equal(ids0, ids1) and torch.equal(n0, n1)
+    nll1, dl1 = K.ctc_fwd_bwd(frames, dev(in_len), dev(labels), dev(lab_len), ws, grad_scale=0.25, dlogits=frames)
+    assert dl1.data_ptr() == buf.data_ptr() and dl1.stride() == frames.stride()
+    assert torch.equal(nll0, nll1) and torch.equal(dl0, dl1.contiguous())
+    assert float((buf[:, V:] - 7.0).abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="row stride"):
+        K.ctc_fwd_bwd(torch.zeros(B * T, V + 3, dtype=dtype, device=DEV).view(B, T, V + 3)[:, :, :V], dev(in_len), dev(labels), dev(lab_len), ws)
+
+
+def test_transposed_copies_with_own_offset_and_stride(K):
+    """asr_transpose_batched_bf16 (ABI 6): every copy at its own offset and row stride."""
+    torch.manual_seed(3)
+    src = torch.randn(100 * 70 + 200 * 64, device=DEV).bfloat16()
+    a, b = src[:7000].view(100, 70), src[7000:].view(200, 64)
+    dst = torch.zeros(70 * 128 + 64 * 200 + 64, dtype=torch.bfloat16, device=DEV)
+    tiles = [[0, 100, 70, (r << 16) | c, 64, 128] for r in range(2) for c in range(2)]
+    tiles += [[7000, 200, 64, (r << 16) | 0, 64 + 70 * 128, 200] for r in range(4)]
+    K.transpose_batched(src, dst, torch.tensor(tiles, dtype=torch.int32, device=DEV))
+    assert torch.equal(dst[64:64 + 70 * 128].view(70, 128)[:, :100], a.t())
+    assert float(dst[64:64 + 70 * 128].view(70, 128)[:, 100:].abs().max()) == 0.0 and float(dst[:64].abs().max()) == 0.0
+    assert torch.equal(dst[64 + 70 * 128:].view(64, 200), b.t())
+
+
 def test_ctc_full_size_properties(K, ws):
     """BASELINE size (B=32, T=500, V=4232): size-independent properties - every gradient row of a
     valid frame sums to 0 (softmax minus a distribution), padded frames are exactly 0, and the

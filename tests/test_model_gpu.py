@@ -880,6 +880,38 @@ def test_decoder_sequencer_matches_per_kernel_path(dropout, monkeypatch):
     assert torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
 
 
+@pytest.mark.parametrize("name", ["TransformerCTC", "TransformerOffical"])
+def test_padded_head_rows_match_dense_rows(name, monkeypatch):
+    """The training step keeps the CTC head's logits / gradient rows 64-element aligned (V = 56 -> 64, like 4232 -> 4288 at full size;
+    the W^T copy of the head is padded the same way).  Same kernels, same tiles: in deterministic mode the loss and every gradient are
+    bit-identical to the dense layout's (ASR_PAD_LOGITS=0)."""
+    from asr_chinese_e2e_amd import kernels as K
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=1, ctc_weight=0.3)
+    if name == "TransformerCTC":
+        over.update(use_decoder=False, ctc_weight=1.0)
+    cfg, sd, batch = oracle_case(9, 500, 80, 56, 12, over, seed=13)      # 4500 frames: the head's input gradient runs on the persistent NT kernel
+    pack = to_pack(batch)
+    prev = K.set_deterministic(True)
+    try:
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ASR_PAD_LOGITS", mode)
+            model = build(cfg, 56, name, dtype="bf16").cuda()
+            model.load_state_dict(sd)
+            model.train()
+            eng = model._ensure_engine(DEV)
+            assert eng.ld_v == (64 if mode == "1" else 56) and eng.ctc_lo.wlpT.stride(0) == eng.ld_v
+            model.zero_flat_grads()
+            loss, _ = model.train_step(pack)
+            torch.cuda.synchronize()
+            res[mode] = (loss.clone(), model._flat.g.clone())
+    finally:
+        K.set_deterministic(prev)
+    assert torch.isfinite(res["1"][0]).all()
+    assert torch.equal(res["1"][0], res["0"][0]), (res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
+
+
 def test_decoder_sequencer_buffer_cache_is_bounded():
     """Real batches come in many shapes: the sequencer's persistent per-shape buffers are an LRU of a few shapes (Engine.DEC_CACHE_SHAPES),
     re-used when a shape returns, and the training steps stay finite across the changes."""

@@ -26,7 +26,7 @@ def timeit(fn, reps=30):
 
 
 torch.manual_seed(0)
-for N, Kd, name in (SHAPES if which not in ("grp", "grp1") else []):
+for N, Kd, name in (SHAPES if which not in ("grp", "grp1", "pad") else []):
     x = torch.randn(M, Kd, device="cuda").bfloat16()
     w = (torch.randn(N, Kd, device="cuda") * 0.05).bfloat16()
     b = torch.randn(N, device="cuda")
@@ -53,6 +53,24 @@ for N, Kd, name in (SHAPES if which not in ("grp", "grp1") else []):
             t = timeit(lambda: K.gemm_nn(dy, w, dx))
             line += f"  mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s"
     print(line, flush=True)
+
+if which == "pad":
+    # the CTC head (V = 4232: rows of 8464 B start 16 B further into a 128-B line each) with rows padded to 4288 columns (8576 B = 67 lines)
+    V, D = 4232, 512
+    for ld in (4232, 4288, 4352):
+        x = torch.randn(M, D, device="cuda").bfloat16()
+        w = (torch.randn(V, D, device="cuda") * 0.05).bfloat16()
+        b = torch.randn(V, device="cuda")
+        buf = torch.randn(M, ld, device="cuda").bfloat16()
+        out = buf[:, :V]
+        wt = (torch.randn(D, ld, device="cuda") * 0.05).bfloat16()[:, :V]      # transposed weight copy, padded the same way
+        dx = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        dw = torch.zeros(V, D, device="cuda"); db = torch.zeros(V, device="cuda")
+        fl = 2.0 * M * V * D
+        t_lo = timeit(lambda: K.gemm_nt(x, w, b, out))
+        t_dx = timeit(lambda: K.gemm_nt(out, wt, None, dx))
+        t_dw = timeit(lambda: K.gemm_tn(out, x, dw, accumulate=True, dbias=db))
+        print(f"ld={ld}: ctc_lo {t_lo:6.1f} us {fl / t_lo / 1e6:5.0f} TF/s | ctc_dx {t_dx:6.1f} us {fl / t_dx / 1e6:5.0f} TF/s | ctc_dw {t_dw:6.1f} us {fl / t_dw / 1e6:5.0f} TF/s", flush=True)
 
 if which in ("grp", "all"):
     # one encoder layer's four weight gradients: four launches vs one grouped launch
