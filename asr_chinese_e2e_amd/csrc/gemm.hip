@@ -16,6 +16,8 @@
 //       wave-instruction adds two 128-byte row segments).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "asr_common.h"
 
 namespace {
@@ -699,19 +701,39 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
                     for (int mi = 0; mi < MI; ++mi) acc[ni][mi][4 * g4 + e] = bv;
                 }
             }
-        u32x4 hm0[4];
-        auto load_masks = [&](u32x4 (&dst)[4], int mi) {
+        // ReLU mask / residual tile (64 KiB per workgroup): the pieces of store rounds 0 and 1 are fetched under the k-loop (from k-step
+        // 2 on: the ring is primed by then), rounds 2 and 3 under the first two store rounds.  Fetched where the tail starts (round 0 at the last
+        // k-step, round mi + 1 under round mi) every workgroup asked for its 64 KiB at the same moment - 16 MB at once, 11 us per launch
+        // on top of the plain product's 22 (tools/gemm_bench.py mask).
+        constexpr bool MASKED = ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES;
+        constexpr int NPF = 2;      // rounds fetched under the k-loop (three: the kernel spills)
+        u32x4 hmp[NPF][4];
+        const int pf_k = nk > 2 ? 2 : nk - 1;
+        // A tile that lies wholly inside the matrix (all but the last row / column of tiles) loads and stores without predicates:
+        // the compiler then counts the outstanding memory operations (vmcnt(N), N > 0) and a round never waits for the stores of
+        // the round before it; behind per-lane predicates it falls back to vmcnt(0) in front of every use of a fetched piece.
+        const bool full = tm * PBM + PBM <= M && tn * PBN + PBN <= N;      // wave-uniform
+        auto load_masks = [&](u32x4 (&dst)[4], int mi, auto full_c) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = q * 8 + srow, ch = lane & 7;
                 const int m = m0 + mi * 32 + row, n = n0 + ch * 8;
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                dst[q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
+                if constexpr (decltype(full_c)::value) dst[q] = *(const u32x4*)(mask + (size_t)m * ldc + n);
+                else dst[q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
             }
         };
         for (int c_k = 0; c_k < nk; ++c_k) {
             __builtin_amdgcn_s_barrier();
-            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && c_k == nk - 1) load_masks(hm0, 0);
+            if (MASKED && c_k == pf_k) {
+                if (full) {
+#pragma unroll
+                    for (int mi = 0; mi < NPF; ++mi) load_masks(hmp[mi], mi, std::true_type{});
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < NPF; ++mi) load_masks(hmp[mi], mi, std::false_type{});
+                }
+            }
             const char* sb = smem_s + c_slot * PSTAGE;
             c_slot = c_slot == PRING - 1 ? 0 : c_slot + 1;
             bf16x8 af[2][MI], wf[2][2];
@@ -736,70 +758,72 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
         // ---- store tail: four rounds of 32 rows x 64 columns through a wave-private 4-KiB buffer in the slot consumed last
         __builtin_amdgcn_s_barrier();
         char* epi = smem_s + (c_slot == 0 ? PRING - 1 : c_slot - 1) * PSTAGE + w * 4096;
-        // ReLU mask / residual pieces: round 0 was fetched under the tile's last k-step, round mi + 1 is fetched while round mi is
-        // transposed and stored (loaded right where they are used they cost the old kernel 8.8 us per launch)
-        u32x4 hm[4], hm_next[4];
-        if (ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) {
+        auto store_tail = [&](auto full_c) {
+            u32x4 hm[4], hmt[MI - NPF][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hm[q] = hm0[q];
-        }
+            for (int mi = 0; mi < MI; ++mi) {
+                if (MASKED) {
+                    if (mi == 0) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && mi + 1 < MI) load_masks(hm_next, mi + 1);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[ni][mi][4 * g4 + e];
-                        if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
-                        o[e] = x;
+                        for (int m2 = NPF; m2 < MI; ++m2) load_masks(hmt[m2 - NPF], m2, full_c);
                     }
-                    store4<bf16_t>((bf16_t*)(epi + r * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hm[q] = mi < NPF ? hmp[mi < NPF ? mi : 0][q] : hmt[mi < NPF ? 0 : mi - NPF][q];
                 }
-            __builtin_amdgcn_wave_barrier();
-            u32x4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = q * 8 + srow, ch = lane & 7;
-                v[q] = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-            }
-            if (ACT == NT_ACT_ADD_RES) {
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t a = v[q][e], r2 = hm[q][e];
-                        const bf16_t lo_ = (bf16_t)(__uint_as_float(a << 16) + __uint_as_float(r2 << 16));
-                        const bf16_t hi_ = (bf16_t)(__uint_as_float(a & 0xffff0000u) + __uint_as_float(r2 & 0xffff0000u));
-                        v[q][e] = (uint32_t)__builtin_bit_cast(unsigned short, lo_) | ((uint32_t)__builtin_bit_cast(unsigned short, hi_) << 16);
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[ni][mi][4 * g4 + e];
+                            if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
+                            o[e] = x;
+                        }
+                        store4<bf16_t>((bf16_t*)(epi + r * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
                     }
-            }
-            if (ACT == ASR_ACT_RELU_MASK) {
+                __builtin_amdgcn_wave_barrier();
+                u32x4 v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * 8 + srow, ch = lane & 7;
+                    v[q] = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                }
+                if (ACT == NT_ACT_ADD_RES) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t h = hm[q][e];
-                        const uint32_t lo_ = ((h & 0x7fffu) != 0u && !(h & 0x8000u)) ? 0x0000ffffu : 0u;
-                        const uint32_t hi_ = ((h & 0x7fff0000u) != 0u && !(h & 0x80000000u)) ? 0xffff0000u : 0u;
-                        v[q][e] &= lo_ | hi_;
-                    }
-            }
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = q * 8 + srow, ch = lane & 7;
-                const int m = m0 + mi * 32 + row, n = n0 + ch * 8;
-                if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
-            }
-            __builtin_amdgcn_wave_barrier();
-            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && mi + 1 < MI) {
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t a = v[q][e], r2 = hm[q][e];
+                            const bf16_t lo_ = (bf16_t)(__uint_as_float(a << 16) + __uint_as_float(r2 << 16));
+                            const bf16_t hi_ = (bf16_t)(__uint_as_float(a & 0xffff0000u) + __uint_as_float(r2 & 0xffff0000u));
+                            v[q][e] = (uint32_t)__builtin_bit_cast(unsigned short, lo_) | ((uint32_t)__builtin_bit_cast(unsigned short, hi_) << 16);
+                        }
+                }
+                if (ACT == ASR_ACT_RELU_MASK) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hm[q] = hm_next[q];
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t h = hm[q][e];
+                            const uint32_t lo_ = ((h & 0x7fffu) != 0u && !(h & 0x8000u)) ? 0x0000ffffu : 0u;
+                            const uint32_t hi_ = ((h & 0x7fff0000u) != 0u && !(h & 0x80000000u)) ? 0xffff0000u : 0u;
+                            v[q][e] &= lo_ | hi_;
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * 8 + srow, ch = lane & 7;
+                    const int m = m0 + mi * 32 + row, n = n0 + ch * 8;
+                    if constexpr (decltype(full_c)::value) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
+                    else if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-        }
+        };
+        if (full) store_tail(std::true_type{});
+        else store_tail(std::false_type{});
     }
 }
 

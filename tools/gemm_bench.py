@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from asr_chinese_e2e_amd import kernels as K
+from asr_chinese_e2e_amd._lib import ACT_RELU, ACT_RELU_MASK
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 M = int(os.environ.get("BENCH_M", "16000"))
@@ -26,7 +27,7 @@ def timeit(fn, reps=30):
 
 
 torch.manual_seed(0)
-for N, Kd, name in (SHAPES if which not in ("grp", "grp1", "pad") else []):
+for N, Kd, name in (SHAPES if which not in ("grp", "grp1", "pad", "mask") else []):
     x = torch.randn(M, Kd, device="cuda").bfloat16()
     w = (torch.randn(N, Kd, device="cuda") * 0.05).bfloat16()
     b = torch.randn(N, device="cuda")
@@ -53,6 +54,21 @@ for N, Kd, name in (SHAPES if which not in ("grp", "grp1", "pad") else []):
             t = timeit(lambda: K.gemm_nn(dy, w, dx))
             line += f"  mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s"
     print(line, flush=True)
+
+if which == "mask":
+    # the w_2 input gradient: dH = (dY W_2) masked by the ReLU of the w_1 activations (N = 1024 outputs, reduction 512), against the
+    # same product without the mask
+    x = torch.randn(M, 512, device="cuda").bfloat16()
+    wt = (torch.randn(1024, 512, device="cuda") * 0.05).bfloat16()
+    act = torch.randn(M, 1024, device="cuda").bfloat16()
+    out = torch.empty(M, 1024, device="cuda", dtype=torch.bfloat16)
+    fl = 2.0 * M * 1024 * 512
+    t0 = timeit(lambda: K.gemm_nt(x, wt, None, out))
+    t1 = timeit(lambda: K.gemm_nt(x, wt, None, out, act=ACT_RELU_MASK, res=act))
+    t2 = timeit(lambda: K.gemm_nt(x, wt, None, out, res=act))
+    b = torch.randn(1024, device="cuda")
+    t3 = timeit(lambda: K.gemm_nt(x, wt, b, out, act=ACT_RELU))
+    print(f"w2_dx plain {t0:6.1f} us {fl / t0 / 1e6:5.0f} TF/s | ReLU mask {t1:6.1f} us {fl / t1 / 1e6:5.0f} TF/s | residual add {t2:6.1f} us | w1 fwd bias+ReLU {t3:6.1f} us", flush=True)
 
 if which == "pad":
     # the CTC head (V = 4232: rows of 8464 B start 16 B further into a 128-B line each) with rows padded to 4288 columns (8576 B = 67 lines)
