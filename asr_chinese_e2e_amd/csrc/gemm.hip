@@ -608,6 +608,8 @@ static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bia
 // one k-sub-step ahead) and store.  Same tile (256 x 128 x 64), same ring (3 x 48 KiB), same one s_barrier per k-step, same tile
 // order; a loader and a consumer share each SIMD, so DMA issue and matrix issue come from different instruction streams.  Every output
 // element sees the same k order as in the kernel above: identical bits.
+typedef float f32x8u __attribute__((ext_vector_type(8), aligned(4)));      // eight floats at any 4-byte aligned address (scalar loads)
+
 template <int ACT, bool KRAG = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
                                                               bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int tiles_n, int ntiles,
@@ -684,25 +686,37 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
     const int a_row = (wm * 128 + r) * 128;                  // + mi * 32 * 128
     const int w_row = PBM * 128 + (wn * 64 + r) * 128;       // + ni * 32 * 128
     int c_slot = 0;
+    const uint32_t lane_off = ((uint32_t)srow * (uint32_t)ldc + (uint32_t)(lane & 7) * 8u) * 2u;      // this lane's piece inside an 8-row group of C (BYTES: zext(offset) + uniform base is the scalar-base address form)
     for (int c_tile = first; c_tile < hi; c_tile += nb_x) {
         const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
         const int m0 = tm * PBM + wm * 128, n0 = tn * PBN + wn * 64;
-        f32x16 acc[2][MI];  // [ni][mi]: C^T blocks (n in registers, m on the lane), starting at the bias (scalar loads)
+        // [ni][mi]: C^T blocks (n in registers, m on the lane), starting at the bias: eight scalar loads of eight floats (one uniform test
+        // of the pointer; as 64 single loads behind 64 tests of it this prologue kept the tile's first MFMA waiting for ~1 us)
+        f32x16 acc[2][MI];
+        if (!(ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && bias) {      // the masked / residual forms are launched without a bias (the host sends bias + mask to the all-in-one kernel)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = min(n0 + ni * 32 + 8 * g4, N - 8);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int nb = __builtin_amdgcn_readfirstlane(min(n0 + ni * 32 + 8 * g4, N - 8));
+                    const f32x8u b8 = *(const f32x8u*)(bias + nb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
-                    const float bv = hh ? b_hi : b_lo;
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = hh ? b8[4 + e] : b8[e];
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[ni][mi][4 * g4 + e] = bv;
+                        for (int mi = 0; mi < MI; ++mi) acc[ni][mi][4 * g4 + e] = bv;
+                    }
                 }
-            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ni][mi][i] = 0.f;
+        }
         // ReLU mask / residual tile (64 KiB per workgroup): the pieces of store rounds 0 and 1 are fetched under the k-loop (from k-step
-        // 2 on: the ring is primed by then), rounds 2 and 3 under the first two store rounds.  Fetched where the tail starts (round 0 at the last
+        // 2 on: the ring is primed by then), rounds 2 and 3 two store rounds ahead of their use.  Fetched where the tail starts (round 0 at the last
         // k-step, round mi + 1 under round mi) every workgroup asked for its 64 KiB at the same moment - 16 MB at once, 11 us per launch
         // on top of the plain product's 22 (tools/gemm_bench.py mask).
         constexpr bool MASKED = ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES;
@@ -719,8 +733,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
                 const int row = q * 8 + srow, ch = lane & 7;
                 const int m = m0 + mi * 32 + row, n = n0 + ch * 8;
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                if constexpr (decltype(full_c)::value) dst[q] = *(const u32x4*)(mask + (size_t)m * ldc + n);
-                else dst[q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
+                // uniform row pointer + one per-lane 32-bit offset (scalar base addressing: no 64-bit address pair per piece)
+                const bf16_t* rowp = mask + (size_t)(m0 + mi * 32 + q * 8) * ldc + n0;
+                if constexpr (decltype(full_c)::value) dst[q] = *(const u32x4*)((const char*)rowp + lane_off);
+                else dst[q] = (m < M && n + 8 <= N) ? *(const u32x4*)((const char*)rowp + lane_off) : z;
             }
         };
         for (int c_k = 0; c_k < nk; ++c_k) {
@@ -763,10 +779,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 if (MASKED) {
-                    if (mi == 0) {
-#pragma unroll
-                        for (int m2 = NPF; m2 < MI; ++m2) load_masks(hmt[m2 - NPF], m2, full_c);
-                    }
+                    if (mi + NPF < MI) load_masks(hmt[mi], mi + NPF, full_c);      // two rounds ahead; round mi - 1's registers are free by now
 #pragma unroll
                     for (int q = 0; q < 4; ++q) hm[q] = mi < NPF ? hmp[mi < NPF ? mi : 0][q] : hmt[mi < NPF ? 0 : mi - NPF][q];
                 }
@@ -816,8 +829,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
                 for (int q = 0; q < 4; ++q) {
                     const int row = q * 8 + srow, ch = lane & 7;
                     const int m = m0 + mi * 32 + row, n = n0 + ch * 8;
-                    if constexpr (decltype(full_c)::value) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
-                    else if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
+                    bf16_t* rowp = C + (size_t)(m0 + mi * 32 + q * 8) * ldc + n0;
+                    if constexpr (decltype(full_c)::value) stream_store(v[q], (u32x4*)((char*)rowp + lane_off));
+                    else if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)((char*)rowp + lane_off));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -2176,7 +2190,7 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     if (act == ASR_ACT_RELU_MASK) {   // C = (A W^T + bias) where res > 0, else 0: persistent kernel only
         if (!res || (uintptr_t)res % 16 || K % DBK || K < 2 * PBK || N % 8 || ldc % 8 || ((uintptr_t)C % 16))
             ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: ASR_ACT_RELU_MASK needs the mask in `res`, K %% 64 == 0, K >= 128, N, ldc %% 8 == 0 and 16-byte aligned pointers");
-        if (spec) launch_nt_spec<ASR_ACT_RELU_MASK>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+        if (spec && !bias) launch_nt_spec<ASR_ACT_RELU_MASK>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         else
         launch_nt_persist<ASR_ACT_RELU_MASK, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
@@ -2184,7 +2198,7 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     }
     if (res && act == ASR_ACT_NONE && K % DBK == 0 && K >= 2 * PBK && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)res % 16) == 0) {
         // residual add in the persistent kernel's store tail (res = C accumulates in place: every element is read and written by one lane)
-        if (spec) launch_nt_spec<NT_ACT_ADD_RES>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+        if (spec && !bias) launch_nt_spec<NT_ACT_ADD_RES>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         else
         launch_nt_persist<NT_ACT_ADD_RES, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
