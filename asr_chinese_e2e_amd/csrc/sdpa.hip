@@ -840,17 +840,16 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
 
     // ---- K * scale * log2(e) of every key -> LDS (rows >= klen are zeros: padded keys never contribute); dS images start
     //      as zeros (rows of waves without keys are never written and are read by the unrolled dQ loop)
-    for (int c = tid; c < FB_KEYS * 8; c += FB_THREADS) {
-        const int row = c >> 3, ch = c & 7;
-        u32x4 x = zero4;
-        if (row < klen) {
-            x = *(const u32x4*)(kb + (size_t)row * ldk + ch * 8);
+    // all eight 16-byte pieces of a thread are requested before the first is used (as a rolled loop every piece waited for its own
+    // round trip to memory: eight in a row, with every workgroup of the chip in this prologue at once)
+    constexpr int KPIECES = FB_KEYS * 8 / FB_THREADS;
+    u32x4 kx[KPIECES];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = scale_bf16_pair(x[e], sc2);
-        }
-        *(u32x4*)(Kimg + row * TS + ch * 8) = x;
+    for (int i = 0; i < KPIECES; ++i) {
+        const int c = tid + i * FB_THREADS, row = c >> 3, ch = c & 7;
+        kx[i] = *(const u32x4*)(kb + (size_t)min(row, max(klen - 1, 0)) * ldk + ch * 8);      // unpredicated (a valid row of this block); rows >= klen are zeroed below
     }
-    for (int c = tid; c < 2 * FB_DS_BYTES / 16; c += FB_THREADS) *(u32x4*)((char*)dSimg + c * 16) = zero4;
+    for (int c = tid; c < 2 * FB_DS_BYTES / 16; c += FB_THREADS) *(u32x4*)((char*)dSimg + c * 16) = zero4;      // under the loads' latency
     if (tid < 32) s_neg[tid] = -1.0e30f;
     // ---- this wave's V rows as B-operand fragments (key on the lane)
     bf16x8 vf[2][4];
@@ -876,21 +875,21 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     const size_t ldA = is_do ? (size_t)ldo : (size_t)ldq;
     u32x4 pa = zero4, po = zero4;
     float pl = 0.f;
+    // FB_PREFETCH only ISSUES the loads of a tile (rows clamped into the matrix, no use of the loaded values); FB_COMMIT, a tile later,
+    // zeroes what lies past the end and stores the tile.  With the selects on the loaded values written next to the loads the compiler
+    // waited for the memory round trip right there - once per tile, in every wave, between the barrier and the dQ block.
 #define FB_PREFETCH(Q0)                                                                                   \
     do {                                                                                                  \
-        const int qi_ = (Q0) + prow;                                                                      \
-        const bool ok_ = qi_ < Tq;                                                                        \
-        const size_t row_ = (size_t)(ok_ ? qi_ : 0);                                                      \
+        const size_t row_ = (size_t)min((Q0) + prow, Tq - 1);                                             \
         pa = *(const u32x4*)(srcA + row_ * ldA + pch * 8);                                                \
         po = *(const u32x4*)(ob + row_ * ldo + pch * 8);                                                  \
-        if (!ok_) { pa = zero4; po = zero4; }                                                             \
-        const int ql_ = min((Q0) + (tid & 31), Tq - 1);                                                   \
-        const float lr_ = lseb[ql_];                                                                      \
-        pl = ((Q0) + (tid & 31) >= Tq || lr_ == -INFINITY) ? -1.0e30f : -lr_ * LOG2E;                     \
+        pl = lseb[min((Q0) + (tid & 31), Tq - 1)];                                                        \
     } while (0)
     // rows past the end / rows that saw no key get -1e30: p = 0.  (Every thread loads one lse value: no divergent path.)
-#define FB_COMMIT(BUF)                                                                                    \
+#define FB_COMMIT(BUF, Q0)                                                                                \
     do {                                                                                                  \
+        if ((Q0) + prow >= Tq) { pa = zero4; po = zero4; }                                                \
+        const float pl_ = ((Q0) + (tid & 31) >= Tq || pl == -INFINITY) ? -1.0e30f : -pl * LOG2E;          \
         bf16_t* T_ = tiles + (BUF) * 2 * FB_TILE_ELEMS + (is_do ? FB_TILE_ELEMS : 0);                     \
         *(u32x4*)(T_ + prow * TS + pch * 8) = pa;                                                         \
         float* st_ = stats + (BUF) * 64;                                                                  \
@@ -903,7 +902,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         d_ += __shfl_xor(d_, 2, 64);                                                                      \
         d_ += __shfl_xor(d_, 4, 64);                                                                      \
         if (is_do && pch == 0) st_[32 + prow] = -d_;                                                      \
-        if (tid < FB_QT) st_[tid] = pl;                                                                   \
+        if (tid < FB_QT) st_[tid] = pl_;                                                                  \
     } while (0)
 
     f32x16 dka[2][2], dva[2][2];
@@ -1082,19 +1081,29 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     const int t_lo = BAND ? max(0, (kblk0 - (FB_QT - 1) - window + FB_QT - 1) / FB_QT) : 0;
     const int t_hi = BAND ? min(ntiles, (kblk0 + Tk + window + FB_QT - 1) / FB_QT) : ntiles;
     FB_PREFETCH(t_lo * FB_QT);
-    FB_COMMIT(t_lo & 1);
+#pragma unroll
+    for (int i = 0; i < KPIECES; ++i) {      // K * scale * log2(e) -> LDS (rows >= klen stay zero)
+        const int c = tid + i * FB_THREADS, row = c >> 3, ch = c & 7;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kx[i][e] = row < klen ? scale_bf16_pair(kx[i][e], sc2) : 0u;
+        *(u32x4*)(Kimg + row * TS + ch * 8) = kx[i];
+    }
+    FB_COMMIT(t_lo & 1, t_lo * FB_QT);
     if (t_lo + 1 < t_hi) FB_PREFETCH((t_lo + 1) * FB_QT);
     __syncthreads();         // K image, zeroed dS images, first tile
     // One barrier per tile.  Before barrier t: key phase of tile t (writes dS image t & 1, last read by the dQ block of
     // tile t - 2, i.e. before barrier t - 1) and the store of tile t + 1 into tile buffer (t + 1) & 1 (last read by the key
     // phase of tile t - 1).  After it: the dQ block of tile t, while other waves already run the key phase of tile t + 1.
     // (Giving the two waves of a SIMD opposite phase orders through a wave-uniform switch was 10 us SLOWER: 92 vs 82.)
+#ifndef SDPA_SKIP
+#define SDPA_SKIP 0      // diagnostic builds only (make sdpa-skip SDPA_SKIP=n): 1 = no dQ phase, 2 = no key phase, 4 = neither; WRONG results, timing only
+#endif
     for (int t = t_lo; t < t_hi; ++t) {
-        if (active) phase_keys(t);
-        if (t + 1 < t_hi) FB_COMMIT((t + 1) & 1);
+        if (active && !(SDPA_SKIP & 6)) phase_keys(t);
+        if (t + 1 < t_hi) FB_COMMIT((t + 1) & 1, (t + 1) * FB_QT);
         __syncthreads();
         if (t + 2 < t_hi) FB_PREFETCH((t + 2) * FB_QT);
-        phase_dq(t);
+        if (!(SDPA_SKIP & 5)) phase_dq(t);
     }
 #undef FB_PREFETCH
 #undef FB_COMMIT
