@@ -779,14 +779,52 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
 // (A 4-wave form with the whole 512-entry register file per wave - operand sets shared by four key blocks, a third of
 // the LDS traffic - measured 102 us against 82 us for this form: one wave per SIMD exposes every LDS and MFMA latency.)
 constexpr int FB_WAVES = 8, FB_KEYS = 64 * FB_WAVES, FB_QT = 32, FB_THREADS = 64 * FB_WAVES;
-constexpr int FB_K_BYTES = FB_KEYS * TS * 2;                  // 73728
+// K image and Q / dO tiles: rows of 128 B, unpadded; the 16-byte chunk c of row r sits at chunk c ^ ff_swz(r) (the forward kernel's layout):
+// the ds_read_b128 row fragments AND the transposed ds_read_b64_tr_b16 fragments (32x32x16 and 16x16x32 forms) are bank-conflict
+// free.  (Rows padded to 144 B served the row fragments only: the transposed reads of a half-wave - rows r, r + 1, r + 2, r + 3 and
+// r + 8 .. - landed two deep on the banks: 31 % of the LDS cycles of round 2's kernel were conflicts.)
+constexpr int FBS = 64;                                       // row stride in elements
+constexpr int FB_K_BYTES = FB_KEYS * FBS * 2;                 // 65536
 constexpr int FB_DS_BYTES = FB_KEYS * FB_QT * 2;              // 32768 per buffer
-constexpr int FB_TILE_ELEMS = FB_QT * TS;
+constexpr int FB_TILE_ELEMS = FB_QT * FBS;
 constexpr int FB_STATS = (2 * 64 + 32) * 4;                   // [2 buffers][-lse log2e (32) | -delta (32)] + a row of -1e30
-constexpr int FB_LDS = FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2 + FB_STATS;   // 158336 B
+constexpr int FB_LDS = FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2 + FB_STATS;   // 148096 B
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
+// Fragments out of the swizzled images.  ff_swz(r) depends on (r >> 1) & 7 only, so for rows that differ by a multiple of 16 a lane's
+// swizzled chunk is the same: every fragment address is one of a few per-lane byte offsets (FbOffsets, computed once) plus an
+// IMMEDIATE (image, 16- or 32-row block) - as cheap to address as a padded layout.
+struct FbOffsets {
+    int row[4];      // row fragment, k-step ks: (r, hh) -> row r, chunk (2 ks + hh) ^ swz(r)
+    int tr[2][2];    // 32x32x16 transposed fragment, [column block db][lo / hi half]: rows 4 (G >> 1) + (i >> 2) (+ 8)
+    int tr16[2];     // 16x16x32 transposed fragment of columns d0 .., [lo / hi]: rows 8 g + (i >> 2) (+ 4)
+};
+__device__ __forceinline__ FbOffsets fb_offsets(int lane, int d0) {
+    FbOffsets o;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o.row[ks] = r * 128 + (((2 * ks + hh) ^ ff_swz(r)) << 4);
+    const int G = lane >> 4, i = lane & 15, sub = 8 * (i & 1);
+    const int rt = 4 * (G >> 1) + (i >> 2);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int chunk = 4 * db + 2 * (G & 1) + ((i & 3) >> 1);
+        o.tr[db][0] = rt * 128 + ((chunk ^ ff_swz(rt)) << 4) + sub;
+        o.tr[db][1] = (rt + 8) * 128 + ((chunk ^ ff_swz(rt + 8)) << 4) + sub;
+    }
+    const int r16 = 8 * G + (i >> 2), c16 = (d0 >> 3) + ((i & 3) >> 1);
+    o.tr16[0] = r16 * 128 + ((c16 ^ ff_swz(r16)) << 4) + sub;
+    o.tr16[1] = (r16 + 4) * 128 + ((c16 ^ ff_swz(r16 + 4)) << 4) + sub;
+    return o;
+}
+// img: image start; blk: byte offset of the 16- / 32-row block (a multiple of 2048: compile-time where the caller's is)
+__device__ __forceinline__ bf16x8 fbs_row(const bf16_t* img, int blk, int off) { return *(const bf16x8*)((const char*)img + blk + off); }
+__device__ __forceinline__ bf16x8 fbs_tr(const bf16_t* img, int blk, const int (&off)[2]) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)((const char*)img + blk + off[0]));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)((const char*)img + blk + off[1]));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 // 16x16x32 operand by transposed LDS reads: lane (i = l & 15, g = l >> 4) gets img[row0 + 8 g + j][col0 + i], j = 0..7
 template <int LD>
 __device__ __forceinline__ bf16x8 frag_tr16(const bf16_t* img, int row0, int col0, int lane) {
@@ -891,7 +929,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         if ((Q0) + prow >= Tq) { pa = zero4; po = zero4; }                                                \
         const float pl_ = ((Q0) + (tid & 31) >= Tq || pl == -INFINITY) ? -1.0e30f : -pl * LOG2E;          \
         bf16_t* T_ = tiles + (BUF) * 2 * FB_TILE_ELEMS + (is_do ? FB_TILE_ELEMS : 0);                     \
-        *(u32x4*)(T_ + prow * TS + pch * 8) = pa;                                                         \
+        *(u32x4*)(T_ + prow * FBS + ((pch ^ ff_swz(prow)) << 3)) = pa;                                                         \
         float* st_ = stats + (BUF) * 64;                                                                  \
         float d_ = 0.f;   /* delta = rowsum(dO o O): 8 lanes per row (the Q half computes a throw-away value) */ \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                \
@@ -914,6 +952,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
             for (int i = 0; i < 16; ++i) { dka[a][c][i] = 0.f; dva[a][c][i] = 0.f; }
     const int ntiles = (Tq + FB_QT - 1) / FB_QT;
     const int d0 = 16 * (w >> 1), q0l = 16 * (w & 1);     // this wave's 16 x 16 block of dQ^T
+    const FbOffsets fo = fb_offsets(lane, d0);
     bf16_t* dqb = dq + (size_t)b * Tq * ldq + h * DK;
     // dS image addressing: 8-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7)
     const int kjl = lane & 31;                              // key inside a 32-key block (f(key) does not depend on the block: 32 rows = 16 pairs)
@@ -956,8 +995,8 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Qt, 0, ks, lane), frag_row(Kimg, key0, ks, lane), st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(Dt, 0, ks, lane), vf[kbk][ks], dp, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbs_row(Qt, 0, fo.row[ks]), fbs_row(Kimg, key0 * 128, fo.row[ks]), st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbs_row(Dt, 0, fo.row[ks]), vf[kbk][ks], dp, 0, 0, 0);
             }
             if (MASKED) {
                 const int gk0 = kblk0 + key0;
@@ -1008,8 +1047,8 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                 const bf16x8 dfr = acc_to_frag(dp, s2);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    dva[kbk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Dt, 0, 32 * db, s2, lane), pfr, dva[kbk][db], 0, 0, 0);
-                    dka[kbk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 0, 32 * db, s2, lane), dfr, dka[kbk][db], 0, 0, 0);
+                    dva[kbk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbs_tr(Dt, s2 * 2048, fo.tr[db]), pfr, dva[kbk][db], 0, 0, 0);
+                    dka[kbk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbs_tr(Qt, s2 * 2048, fo.tr[db]), dfr, dka[kbk][db], 0, 0, 0);
                 }
                 // dS -> [key][query] image: the fragment of k-step s2 holds registers 8 s2 .. 8 s2 + 7 = the pieces g4 = 2 s2, 2 s2 + 1
                 const u32x4 dw = __builtin_bit_cast(u32x4, dfr);
@@ -1029,7 +1068,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                 bf16x8 ka[2], da[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    ka[u] = frag_tr16<TS>(Kimg, 32 * (2 * wv + u), d0, lane);
+                    ka[u] = fbs_tr(Kimg, 4096 * (2 * wv + u), fo.tr16);
                     const bf16_t* pr = dSr + 32 * (2 * wv + u) * FB_QT;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[0]));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[1]));
@@ -1043,7 +1082,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
             bf16x8 ka[4], da[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ka[u] = frag_tr16<TS>(Kimg, 32 * (s4 + u), d0, lane);
+                ka[u] = fbs_tr(Kimg, 4096 * (s4 + u), fo.tr16);
                 const bf16_t* pr = dSr + 32 * (s4 + u) * FB_QT;
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[0]));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pr + ds_rd[1]));
@@ -1086,7 +1125,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         const int c = tid + i * FB_THREADS, row = c >> 3, ch = c & 7;
 #pragma unroll
         for (int e = 0; e < 4; ++e) kx[i][e] = row < klen ? scale_bf16_pair(kx[i][e], sc2) : 0u;
-        *(u32x4*)(Kimg + row * TS + ch * 8) = kx[i];
+        *(u32x4*)(Kimg + row * FBS + ((ch ^ ff_swz(row)) << 3)) = kx[i];
     }
     FB_COMMIT(t_lo & 1, t_lo * FB_QT);
     if (t_lo + 1 < t_hi) FB_PREFETCH((t_lo + 1) * FB_QT);
