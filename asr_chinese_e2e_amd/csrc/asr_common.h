@@ -92,15 +92,32 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 }
 
 // ---- wave-level reductions (64 lanes, DPP/shuffle, no LDS) ----------------------------------
+// Wave-wide reductions on the vector ALU's lane crossbar (DPP), result in every lane: four butterfly steps inside each row of
+// 16 lanes (quad swaps, half-row and row mirrors), two row broadcasts, one v_readlane.  As six __shfl_xor steps each of them was a
+// ds_bpermute_b32 through the LDS crossbar followed by s_waitcnt lgkmcnt(0): ~100 cycles of exposed latency per step, and the
+// one-wave-per-row kernels (LayerNorm) run two to four such reductions per row.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float wave_dpp(float v) {      // lanes outside ROW_MASK, and lanes without a source, get 0 / keep v's identity
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += wave_dpp<0xB1>(v);             // quad_perm [1,0,3,2]
+    v += wave_dpp<0x4E>(v);             // quad_perm [2,3,0,1]
+    v += wave_dpp<0x141>(v);            // row_half_mirror
+    v += wave_dpp<0x140>(v);            // row_mirror: every lane of a row holds the row's sum
+    v += wave_dpp<0x142, 0xA>(v);       // row_bcast15 into rows 1 and 3
+    v += wave_dpp<0x143, 0xC>(v);       // row_bcast31 into rows 2 and 3: row 3 holds the wave's sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    // old = v for the masked steps: a lane outside the row mask must keep its own value under max (0 would be wrong for negatives)
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xC, 0xf, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // block-wide sum for blocks of up to 1024 threads; `red` is >= 16 floats of LDS.  All threads
 // get the result.  Contains two barriers.

@@ -16,7 +16,50 @@ constexpr int LN_WAVES = 4;  // waves (rows in flight) per workgroup
 
 // per-lane slice of one row: N values. VEC8: value c*8+j is column c*512 + lane*8 + j;
 // otherwise value k is column k*64 + lane (masked by col < d).
+// eight consecutive elements as they sit in memory (no conversion: a conversion right behind its load makes the load a wait)
+template <typename T> struct Pack8;
+template <> struct Pack8<bf16_t> { bf16x8 v; };
+template <> struct Pack8<float> { f32x4 a, b; };
+__device__ __forceinline__ void fetch8(const bf16_t* p, Pack8<bf16_t>& r) { r.v = *(const bf16x8*)p; }
+__device__ __forceinline__ void fetch8(const float* p, Pack8<float>& r) { r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); }
+__device__ __forceinline__ void unpack8(const Pack8<bf16_t>& r, float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
+}
+__device__ __forceinline__ void unpack8(const Pack8<float>& r, float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
+}
+
 template <typename T, int N, bool VEC8> struct RowSlice {
+    // Two-step form of load(): fetch() only issues the loads of a row slice, unpack() converts.  The kernels fetch every operand of
+    // every row of a trip before the first unpack: with load() = load + convert per operand (and the optional operand behind a
+    // branch) the compiler put a full s_waitcnt vmcnt(0) between the operands of ONE row.
+    struct Raw {
+        Pack8<T> p[VEC8 ? N / 8 : 1];
+        T s[VEC8 ? 1 : N];
+    };
+    static __device__ __forceinline__ void fetch(const T* p, int d, int lane, Raw& r) {
+        if constexpr (VEC8) {
+#pragma unroll
+            for (int c = 0; c < N / 8; ++c) fetch8(p + c * 512 + lane * 8, r.p[c]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int col = k * 64 + lane;
+                r.s[k] = p[col < d ? col : 0];
+            }
+        }
+    }
+    static __device__ __forceinline__ void unpack(const Raw& r, int d, int lane, float (&v)[N]) {
+        if constexpr (VEC8) {
+#pragma unroll
+            for (int c = 0; c < N / 8; ++c) unpack8(r.p[c], &v[c * 8]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = (k * 64 + lane < d) ? to_f32<T>(r.s[k]) : 0.f;
+        }
+    }
     static __device__ __forceinline__ void load(const T* p, int d, int lane, float (&v)[N]) {
         if constexpr (VEC8) {
 #pragma unroll
@@ -76,7 +119,7 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
     T* __restrict__ y, T* __restrict__ xhat, float* __restrict__ rstd_out, int rows, int T_, int d,
     uint32_t seed, uint32_t thr, float dscale) {
     using RS = RowSlice<T, N, VEC8>;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: row indices, and with them lens[b], live in scalar registers
     float g[N], bt[N];
     RS::loadf(gamma, d, lane, g);
     RS::loadf(beta, d, lane, bt);
@@ -87,12 +130,18 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_fwd_kernel(
     const int stride = gridDim.x * LN_WAVES;
     for (int row0 = blockIdx.x * LN_WAVES + w; row0 < rows; row0 += LN_U * stride) {
         float z[LN_U][N], r[LN_U][N];
+        {
+            typename RS::Raw zx[LN_U], zr[LN_U];
 #pragma unroll
-        for (int u = 0; u < LN_U; ++u) {
-            const int row = row0 + u * stride;
-            if (row < rows) {      // wave-uniform
-                RS::load(x + (size_t)row * d, d, lane, z[u]);
-                if (res) RS::load(res + (size_t)row * d, d, lane, r[u]);
+            for (int u = 0; u < LN_U; ++u) {
+                const int row = min(row0 + u * stride, rows - 1);      // a row past the end re-reads the last row (its result is not used)
+                RS::fetch(x + (size_t)row * d, d, lane, zx[u]);
+                RS::fetch((res ? res : x) + (size_t)row * d, d, lane, zr[u]);      // no residual: the same line again (a cache hit), not used
+            }
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                RS::unpack(zx[u], d, lane, z[u]);
+                RS::unpack(zr[u], d, lane, r[u]);
             }
         }
 #pragma unroll
@@ -152,7 +201,7 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
     const int32_t* __restrict__ lens, T* __restrict__ dz, T* __restrict__ dx, float* __restrict__ ws, int rows, int T_,
     int d, uint32_t seed, uint32_t thr, float dscale) {
     using RS = RowSlice<T, N, VEC8>;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: row indices, and with them lens[b], live in scalar registers
     float g[N], acc_g[N], acc_b[N], acc_z[N];
     RS::loadf(gamma, d, lane, g);
 #pragma unroll
@@ -164,19 +213,34 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
     for (int row0 = blockIdx.x * LN_WAVES + w; row0 < rows; row0 += LN_U * stride) {
         float gy[LN_U][N], xh[LN_U][N], e[LN_U][N], rs[LN_U];
         bool keep[LN_U];
+        {
+            // the lengths first (scalar loads: row indices are uniform), then every operand of both rows before the first conversion;
+            // a padded row (no gradient) costs no memory traffic (see below)
+            typename RS::Raw rg[LN_U], re[LN_U], rx[LN_U];
 #pragma unroll
-        for (int u = 0; u < LN_U; ++u) {
-            const int row = row0 + u * stride;
-            keep[u] = false;
-            if (row < rows) {      // wave-uniform
-                const int b = row / T_, t = row - b * T_;
-                keep[u] = lens ? (t < lens[b]) : true;
-                if (keep[u]) {
-                    RS::load(dy + (size_t)row * d, d, lane, gy[u]);
-                    if (dy2) RS::load(dy2 + (size_t)row * d, d, lane, e[u]);
-                    RS::load(xhat + (size_t)row * d, d, lane, xh[u]);
-                    rs[u] = rstd_in[row];
+            for (int u = 0; u < LN_U; ++u) {
+                const int row = row0 + u * stride;
+                keep[u] = false;
+                if (row < rows) {      // wave-uniform
+                    const int b = row / T_, t = row - b * T_;
+                    keep[u] = lens ? (t < lens[b]) : true;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                // no branch around the loads (behind `if (keep)` the compiler threads the whole row - loads, conversion, arithmetic -
+                // into one arm, one row after the other): a padded row reads row 0 instead, the same line for every such row
+                const size_t lrow = keep[u] ? (size_t)(row0 + u * stride) : 0;
+                RS::fetch(dy + lrow * d, d, lane, rg[u]);
+                RS::fetch((dy2 ? dy2 : dy) + lrow * d, d, lane, re[u]);
+                RS::fetch(xhat + lrow * d, d, lane, rx[u]);
+                rs[u] = rstd_in[lrow];
+            }
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                RS::unpack(rg[u], d, lane, gy[u]);
+                RS::unpack(re[u], d, lane, e[u]);
+                RS::unpack(rx[u], d, lane, xh[u]);
             }
         }
 #pragma unroll
