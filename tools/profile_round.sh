@@ -32,4 +32,11 @@ python3 tools/pmc_summary.py $(find $OUT/bfetch -name "*counter_collection.csv")
 B=8 T=2000 WINDOW=50 python3 tools/sdpa_bench.py > $OUT/band_bench_plain.txt 2>&1
 B=8 T=2000 WINDOW=50 ASR_SDPA_BWD_SPLIT=1 python3 tools/sdpa_bench.py > $OUT/band_bench_pair.txt 2>&1
 rm -rf $OUT/bfetch $OUT/bwrite
+# SQ counters of the attention kernels at the config-2 shape (issue mix, LDS bank conflicts), two passes
+cd /tmp
+REPS=5 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU -d $OUT/sq1 -o p --output-format csv -- python3 $R/tools/sdpa_bench.py > /dev/null 2> $OUT/sq1.err
+REPS=5 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/sq2 -o p --output-format csv -- python3 $R/tools/sdpa_bench.py > /dev/null 2> $OUT/sq2.err
+cd $R
+python3 tools/sq_counters.py $OUT/sq_counters_attention.json $(find $OUT/sq1 $OUT/sq2 -name "*counter_collection.csv") > $OUT/sq_counters_attention.txt
+rm -rf $OUT/sq1 $OUT/sq2
 ls -la $OUT
