@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -103,6 +103,8 @@ SIGNATURES = {
     "asr_adam_step": (I, [P, P, P, P, P, Z, P, P, F, F, F, F, I, P]),
     "asr_loss_combine": (I, [P, I, P, P, I, F, F, P, P]),
     "asr_gemm_nt_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "asr_gemm_nt_relu_bits_bytes": (Z, [I, I, I]),
+    "asr_gemm_nt_relu_bits_bf16": (I, [P, P, P, P, Z, P, I, I, I, I, I, I, I, P]),
     "asr_gemm_small_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "asr_gemm_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "asr_gemm_nt_add_ln_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),

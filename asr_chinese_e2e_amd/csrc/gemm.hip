@@ -335,6 +335,11 @@ static void launch_nt_dma(const bf16_t* a, const bf16_t* w, const float* bias, b
 //     row-panels and W served by that XCD's L2).
 constexpr int PBM = 256, PBN = 128, PBK = 64, PRING = 3;
 constexpr int NT_ACT_ADD_RES = 3;      // kernel-internal: ASR_ACT_NONE with a residual operand (C = A W^T + bias + res; res may be C itself)
+// ReLU mask as ONE BIT per element (asr_gemm_nt_relu_bits_bf16; loader / consumer kernel only).  Forward: C = relu(A W^T + bias) and every
+// lane of a store round writes one dword = the "> 0" bits of its 32 output elements; backward: C = (A W^T) where the bit is set.  The bits
+// are private to the two launches (same M, N: same tiles; dword index ((tile * 4 + wave) * 4 + round) * 64 + lane) - 2 MB instead of the
+// 32-MB activation tensor that the ASR_ACT_RELU_MASK form re-reads, beside a weight-gradient GEMM that streams the same tensor.
+constexpr int NT_ACT_RELU_SAVE = 4, NT_ACT_MASK_BITS = 5;
 constexpr int PSTAGE = (PBM + PBN) * 128;          // 49152 B
 constexpr int PLDS = PRING * PSTAGE;               // 147456 B
 template <int NW> struct PCfg {                    // NW waves as (NW/2) x 2; wave tile (32*MI) x 64
@@ -722,6 +727,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
         constexpr bool MASKED = ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES;
         constexpr int NPF = 2;      // rounds fetched under the k-loop (three: the kernel spills)
         u32x4 hmp[NPF][4];
+        uint32_t bitw[MI];      // NT_ACT_MASK_BITS: this lane's mask bits of the four store rounds
         const int pf_k = nk > 2 ? 2 : nk - 1;
         // A tile that lies wholly inside the matrix (all but the last row / column of tiles) loads and stores without predicates:
         // the compiler then counts the outstanding memory operations (vmcnt(N), N > 0) and a round never waits for the stores of
@@ -741,6 +747,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
         };
         for (int c_k = 0; c_k < nk; ++c_k) {
             __builtin_amdgcn_s_barrier();
+            if (ACT == NT_ACT_MASK_BITS && c_k == pf_k) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) bitw[mi] = ((const uint32_t*)mask)[((size_t)(c_tile * 4 + w) * 4 + mi) * 64 + lane];
+            }
             if (MASKED && c_k == pf_k) {
                 if (full) {
 #pragma unroll
@@ -791,7 +801,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = acc[ni][mi][4 * g4 + e];
-                            if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
+                            if (ACT == ASR_ACT_RELU || ACT == NT_ACT_RELU_SAVE) x = fmaxf(x, 0.f);
                             o[e] = x;
                         }
                         store4<bf16_t>((bf16_t*)(epi + r * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
@@ -812,6 +822,28 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
                             const bf16_t lo_ = (bf16_t)(__uint_as_float(a << 16) + __uint_as_float(r2 << 16));
                             const bf16_t hi_ = (bf16_t)(__uint_as_float(a & 0xffff0000u) + __uint_as_float(r2 & 0xffff0000u));
                             v[q][e] = (uint32_t)__builtin_bit_cast(unsigned short, lo_) | ((uint32_t)__builtin_bit_cast(unsigned short, hi_) << 16);
+                        }
+                }
+                if (ACT == NT_ACT_RELU_SAVE) {      // bit 8 q + 2 e (+ 1): element 2 e (+ 1) of piece q is > 0 (the values are relu outputs: >= 0)
+                    uint32_t bits = 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bits |= ((v[q][e] & 0x7fffu) != 0u ? 1u : 0u) << (8 * q + 2 * e);
+                            bits |= ((v[q][e] & 0x7fff0000u) != 0u ? 1u : 0u) << (8 * q + 2 * e + 1);
+                        }
+                    ((uint32_t*)mask)[((size_t)(c_tile * 4 + w) * 4 + mi) * 64 + lane] = bits;
+                }
+                if (ACT == NT_ACT_MASK_BITS) {
+                    const int bw = (int)bitw[mi];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t lo_ = (uint32_t)__builtin_amdgcn_sbfe(bw, 8 * q + 2 * e, 1);          // 0 or all ones
+                            const uint32_t hi_ = (uint32_t)__builtin_amdgcn_sbfe(bw, 8 * q + 2 * e + 1, 1);
+                            v[q][e] &= (lo_ & 0x0000ffffu) | (hi_ & 0xffff0000u);
                         }
                 }
                 if (ACT == ASR_ACT_RELU_MASK) {
@@ -2271,6 +2303,32 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     else
         ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
     ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
+    return ASR_OK;
+}
+
+// ReLU mask as bits (see NT_ACT_RELU_SAVE above).  0 bytes = no bit-mask form for this shape / these options: use ASR_ACT_RELU + ASR_ACT_RELU_MASK.
+extern "C" size_t asr_gemm_nt_relu_bits_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 8 || K % DBK || K < 2 * PBK) return 0;
+    const int tile_opt = asr_option(ASR_OPT_NT_TILE);
+    if (tile_opt != 0) return 0;      // the loader / consumer kernel only
+    static const int cfg = getenv("ASR_GEMM_CFG") ? atoi(getenv("ASR_GEMM_CFG")) : 0;
+    if (cfg != 0) return 0;
+    return (size_t)ceil_div(N, PBN) * ceil_div(M, PBM) * 4096;
+}
+
+extern "C" int asr_gemm_nt_relu_bits_bf16(const void* A, const void* W, const float* bias, void* bits, size_t bits_bytes, void* C, int M, int N, int K, int lda,
+                                          int ldb, int ldc, int backward, void* stream) {
+    if (!A || !W || !C || !bits) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: null pointer");
+    const size_t need = asr_gemm_nt_relu_bits_bytes(M, N, K);
+    if (!need) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: no bit-mask form for M=%d N=%d K=%d with the current options (asr_gemm_nt_relu_bits_bytes = 0)", M, N, K);
+    if (bits_bytes < need || ((uintptr_t)bits % 4)) ASR_FAIL(ASR_EWORKSPACE, "asr_gemm_nt_relu_bits_bf16: bit buffer %zu < %zu bytes (or misaligned)", bits_bytes, need);
+    if (lda % 8 || ldb % 8 || ldc % 8 || lda < K || ldb < K || ldc < N) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: lda, ldb, ldc must be multiples of 8 (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16) || (bias && (uintptr_t)bias % 16)) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: misaligned pointer");
+    if (backward && bias) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: the backward form takes no bias");
+    hipStream_t st = (hipStream_t)stream;
+    if (backward) launch_nt_spec<NT_ACT_MASK_BITS>((const bf16_t*)A, (const bf16_t*)W, nullptr, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)bits);
+    else launch_nt_spec<NT_ACT_RELU_SAVE>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)bits);
+    ASR_CHECK_LAUNCH("asr_gemm_nt_relu_bits_bf16");
     return ASR_OK;
 }
 

@@ -404,6 +404,11 @@ class Engine:
         self.defer_wgrad = tuple(t for t in os.environ.get("ASR_WGRAD_DEFER", "fc").split(",") if t)
         self._defer_point = os.environ.get("ASR_WGRAD_DEFER_POINT", "before")      # release before / after the attention backward launch
         self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
+        # ReLU mask of the encoder FFN as one bit per element (see _relu_bits): opt-in.  The w_2 input gradient then reads 2 MB instead of
+        # the 32-MB activation tensor, but the step is 1 % SLOWER (3.128 vs 3.097 ms, joint 5.150 vs 5.110; A/B in one process): the
+        # weight-gradient GEMM on the side stream streams the same tensor at the same time, so the second reader was nearly free, and
+        # the bit packing costs the forward's store tail more than the backward saves
+        self.relu_bits = os.environ.get("ASR_RELU_BITS", "0") == "1"
         self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
         self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
         self._ln_part, self._ln_pending = {}, []
@@ -661,15 +666,31 @@ class Engine:
             self.flush_wgrads()
         return dx, dz
 
+    def _relu_bits(self, f, x):
+        """Byte size of the ReLU bit mask when the feed-forward pair can keep it as bits (asr_gemm_nt_relu_bits_bf16: the loader /
+        consumer NT kernel on both sides - many rows, bf16, aligned operands, transposed copy of w_2 present), else 0."""
+        if not (self.relu_bits and self.fuse_relu_bwd and x.dtype == torch.bfloat16 and x.shape[0] >= 4096 and f.w2.wlpT is not None
+                and not f.w1.small(x, f.w1.K) and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+            return 0
+        M = x.shape[0]
+        n = K.relu_bits_bytes(M, f.w1.N, f.w1.K)
+        return n if n and n == K.relu_bits_bytes(M, f.w1.N, f.w2.N) else 0      # forward reduces over d, backward over w_2's outputs: both must have the form
+
     def _ffn_block_fwd(self, f, x, B, T, lens, site):
-        h = f.w1.fwd(x, act=ACT_RELU)
+        nbits = self._relu_bits(f, x)
+        bits = None
+        if nbits:      # ReLU mask as one bit per element, written by the w_1 GEMM's store tail (2 MB instead of re-reading h in the backward pass)
+            bits = torch.empty(nbits, dtype=torch.uint8, device=x.device)
+            h = K.gemm_nt_relu_bits(x, f.w1.wlp, f.w1.b32, bits, torch.empty(x.shape[0], f.w1.N, dtype=x.dtype, device=x.device))
+        else:
+            h = f.w1.fwd(x, act=ACT_RELU)
         pf, sf = self._drop(site)          # after w_2, before residual + LN (module.py:73)
         if self._fuse_ln(f.w2, h, x, pf):
             y, xhat, rstd = K.gemm_nt_add_ln(h, f.w2.wlp, f.w2.b32, x, f.ln.g, f.ln.b, lens, B, T)
         else:
             o = f.w2.fwd(h)
             y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o, drop_p=pf, drop_seed=sf, drop_mode=1)
-        return y, dict(x=x, h=h, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T), drop=(pf, sf))
+        return y, dict(x=x, h=h, bits=bits, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T), drop=(pf, sf))
 
     def _ffn_block_bwd(self, f, c, dy, dy2):
         B, T = c["dims"]
@@ -678,7 +699,11 @@ class Engine:
         self._wgrad(f.w2, dxg, c["h"])
         fused_relu = self.fuse_relu_bwd and (f.w2.own_dgrad(dxg) or f.w2.small(dxg, f.w2.N) or dxg.dtype == torch.float32) and c["h"].is_contiguous() \
             and c["h"].data_ptr() % 16 == 0
-        dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)     # ReLU backward in the GEMM's store tail
+        if c.get("bits") is not None and fused_relu and f.w2.own_dgrad(dxg):
+            f.w2._fresh_transpose()
+            dh = K.gemm_nt_relu_bits(dxg, f.w2.wlpT, None, c["bits"], torch.empty(dxg.shape[0], f.w2.K, dtype=dxg.dtype, device=dxg.device), backward=True)
+        else:
+            dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)     # ReLU backward in the GEMM's store tail
         fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
         if not fused_relu:
             K.relu_bwd_(dh, c["h"], None if fused else f.w1.gb, self.ws)

@@ -533,6 +533,26 @@ def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None, family="gemm_nt"):
     return out
 
 
+def relu_bits_bytes(M, N, K):
+    """Size of the bit-mask buffer of gemm_nt_relu_bits for an (M, N) output and reduction length K, 0 = no such form (asr_hip.h)."""
+    return int(lib.asr_gemm_nt_relu_bits_bytes(M, N, K))
+
+
+def gemm_nt_relu_bits(a, w, bias, bits, out, backward=False, family="gemm_nt"):
+    """backward = False: out = relu(a @ w^T + bias), `bits` (uint8) receives one "> 0" bit per element;
+    backward = True: out = (a @ w^T) where the bit is set, else 0 (the input gradient through the ReLU).  include/asr_hip.h:
+    asr_gemm_nt_relu_bits_bf16."""
+    assert a.dtype == w.dtype == out.dtype == torch.bfloat16 and bits.dtype == torch.uint8 and bits.is_contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and out.shape == (M, N) and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    _chk_f32(bias)
+    timed(family, 2.0 * M * N * K, lambda: check(
+        lib.asr_gemm_nt_relu_bits_bf16(_p(a), _p(w), _p(bias), _p(bits), bits.numel(), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+                                       int(bool(backward)), _stream()), "asr_gemm_nt_relu_bits_bf16"))
+    return out
+
+
 def set_option(name, value):
     """Process-wide tuning switch between correct kernel variants (include/asr_hip.h: asr_set_option); returns the previous value."""
     prev = ctypes.c_int(0)

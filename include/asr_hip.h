@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 6
+#define ASR_ABI_VERSION 7
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -363,6 +363,17 @@ int asr_loss_combine(const float* row_nll, int M, const float* n_valid, const fl
  */
 int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void* res, void* C,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, void* stream);
+/* The feed-forward pair with the ReLU mask kept as ONE BIT per element (ABI 7): `PositionwiseFeedForwardUseConv` (module.py:68-75:
+ * w_2(relu(w_1(x)))) and autograd's ReLU backward through it.
+ *   backward = 0:  C (M, N) = relu(A (M, K) W (N, K)^T + bias), and `bits` receives the "> 0" bit of every element of C;
+ *   backward = 1:  C (M, N) = (A W^T) where the element's bit is set, else 0  - the w_2 input gradient (A = dY, W = W_2^T), no bias.
+ * The bit layout is private to the pair (both calls must see the same M and N; the K of the two calls differ): the backward reads 2 MB
+ * instead of the 32-MB activation tensor (ASR_ACT_RELU_MASK of asr_gemm_nt_bf16), which the weight-gradient GEMM on the side stream is
+ * streaming at the same time.  asr_gemm_nt_relu_bits_bytes = size of `bits` for (M, N) and a reduction length K, or 0 when this form
+ * does not exist for the shape or the current tuning options (then use ASR_ACT_RELU / ASR_ACT_RELU_MASK). */
+size_t asr_gemm_nt_relu_bits_bytes(int M, int N, int K);
+int asr_gemm_nt_relu_bits_bf16(const void* A, const void* W, const float* bias, void* bits, size_t bits_bytes, void* C,
+                               int M, int N, int K, int lda, int ldb, int ldc, int backward, void* stream);
 /* Small-M form of the projections (the decoder's B*To ~ 550 rows; transformer_official.py:446-458 through attention.py:43-59 and
  * module.py:70-71): 64 x 64 tiles, many short workgroups instead of a dozen long ones.
  *   trans_b = 0: C (M, N) = act(A (M, K) * Bm (N, K)^T + bias)        forward, Bm = the weight as stored

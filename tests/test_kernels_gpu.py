@@ -592,6 +592,37 @@ def test_gemm_nt_loader_consumer_form(K, M, N, K_, mode):
     assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
 
 
+@pytest.mark.parametrize("M,N,K1,K2", [(16000, 1024, 512, 512), (4500, 1024, 512, 512), (5000, 1000, 256, 512), (300, 256, 128, 192)])
+def test_gemm_nt_relu_mask_as_bits(K, M, N, K1, K2):
+    """The feed-forward pair with the ReLU mask kept as one bit per element (asr_gemm_nt_relu_bits_bf16): the forward writes the same
+    activations as ASR_ACT_RELU, the backward the same masked input gradient as ASR_ACT_RELU_MASK reading those activations - identical
+    bits, edge tiles (rows and columns past a whole tile) included; a short bit buffer is refused."""
+    from asr_chinese_e2e_amd._lib import ACT_RELU, ACT_RELU_MASK
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K1, device=DEV).bfloat16()
+    w1 = (torch.randn(N, K1, device=DEV) * 0.1).bfloat16()
+    b1 = torch.randn(N, device=DEV) * 0.2
+    dy = torch.randn(M, K2, device=DEV).bfloat16()
+    w2t = (torch.randn(N, K2, device=DEV) * 0.1).bfloat16()      # W_2^T: (ff, d) - the NT operand of the input gradient
+    nb = K.relu_bits_bytes(M, N, K1)
+    assert nb == K.relu_bits_bytes(M, N, K2) and nb == ((M + 255) // 256) * ((N + 127) // 128) * 4096
+    h_ref = K.gemm_nt(x, w1, b1, torch.empty(M, N, dtype=torch.bfloat16, device=DEV), ACT_RELU)
+    dh_ref = K.gemm_nt(dy, w2t, None, torch.empty(M, N, dtype=torch.bfloat16, device=DEV), ACT_RELU_MASK, h_ref)
+    bits = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    h = K.gemm_nt_relu_bits(x, w1, b1, bits, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV))
+    dh = K.gemm_nt_relu_bits(dy, w2t, None, bits, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV), backward=True)
+    assert torch.equal(h, h_ref) and torch.equal(dh, dh_ref), float((dh.float() - dh_ref.float()).abs().max())
+    frac = float((h_ref > 0).float().mean())
+    assert 0.2 < frac < 0.8      # the mask is not trivial
+    with pytest.raises(RuntimeError, match="bit buffer"):
+        K.gemm_nt_relu_bits(x, w1, b1, bits[: nb - 4096], torch.empty(M, N, dtype=torch.bfloat16, device=DEV))
+    prev = K.set_option("nt_tile", 1)      # the all-in-one kernel has no bit form: the size query says so
+    try:
+        assert K.relu_bits_bytes(M, N, K1) == 0
+    finally:
+        K.set_option("nt_tile", prev)
+
+
 @pytest.mark.parametrize("M,N,K_,ta,tb,act,acc,bias", [
     (420, 512, 80, False, True, 0, False, True),       # forward x W^T + b (linear_in of the d_model 512 golden case)
     (420, 1024, 512, False, True, 1, False, True),     # forward with ReLU (w_1)
