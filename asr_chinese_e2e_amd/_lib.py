@@ -65,6 +65,8 @@ SIGNATURES = {
     "asr_abi_version": (I, []),
     "asr_last_error": (I, [c_char_p, Z]),
     "asr_stream_fork": (I, [P, P]),
+    "asr_stream_arm": (I, [P, P]),
+    "asr_stream_arm_pending": (I, []),
     "asr_stream_create": (I, [I, P]),
     "asr_set_option": (I, [c_char_p, I, P]),
     "asr_get_deterministic": (I, []),

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <hip/hip_ext.h>
+
 #include "../../include/asr_hip.h"
 
 typedef __bf16 bf16_t;
@@ -218,3 +220,22 @@ __device__ __forceinline__ int xcd_virtual_id(int id, int nwg) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- armed launches (asr_stream_arm): the completion event of ONE kernel launch, without a marker packet in its queue ------------
+// hipEventRecord puts a barrier packet behind the kernel it follows: the next kernel of that queue then starts ~3.5 us later than it
+// would (step timeline, round 3: every weight-gradient hand-over to the side stream showed as a 6.3-us gap on the main stream instead
+// of 2.8).  hipExtLaunchKernelGGL binds an event to the dispatch packet's own completion signal instead.  An entry point that supports
+// arming launches its LAST kernel through asr_launch_armed(): when the caller armed this stream (asr_stream_arm) the kernel carries the
+// event and the armed stream waits for it; otherwise it is an ordinary launch.
+bool asr_arm_take(hipStream_t st, hipStream_t* to, hipEvent_t* ev);      // misc.hip: true once, if `st` is armed
+template <typename... KArgs, typename... Args>
+static inline void asr_launch_armed(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    hipStream_t to;
+    hipEvent_t ev;
+    if (asr_arm_take(st, &to, &ev)) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, nullptr, ev, 0, static_cast<KArgs>(args)...);
+        (void)hipStreamWaitEvent(to, ev, 0);
+    } else {
+        kernel<<<grid, block, lds, st>>>(static_cast<KArgs>(args)...);
+    }
+}

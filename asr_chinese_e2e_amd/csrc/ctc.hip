@@ -848,7 +848,7 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     if (dlogits) {
         int g3 = rows < 2048 ? rows : 2048;
         if (rows_path && ctc_split) {
-            ctc_label_fix_kernel<<<g1, 256, 0, st>>>((bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, grad_scale_div);
+            asr_launch_armed(ctc_label_fix_kernel, dim3(g1), dim3(256), 0, st, (bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, grad_scale_div);      // last kernel: may carry an armed completion event
         } else if (rows_path) {
 #define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, grad_scale_div)
             ROWS_DISPATCH(K3);

@@ -883,7 +883,7 @@ static void launch_nt_spec(const bf16_t* a, const bf16_t* w, const float* bias, 
     }
     const int t_n = ceil_div(N, PBN), t_m = ceil_div(M, PBM), ntiles = t_n * t_m;
     const int grid = ntiles < cu_count() ? ntiles : cu_count();
-    gemm_nt_spec_kernel<ACT, KRAG><<<grid, 512, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask, zero_page);
+    asr_launch_armed(gemm_nt_spec_kernel<ACT, KRAG>, dim3(grid), dim3(512), PLDS, st, a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask, zero_page);
 }
 
 // ------------------------------------------------------------------------- NT, persistent, 256 x 256 tiles

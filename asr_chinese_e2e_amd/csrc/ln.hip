@@ -374,8 +374,9 @@ static void launch_ln_bwd(const void* dy, const void* dy2, const void* xhat, con
                           const float* gamma, const int32_t* lens, void* dz, void* dx, float* ws, int rows,
                           int T_, int d, uint32_t seed, uint32_t thr, float dscale, hipStream_t st) {
     const int grid = ln_grid(rows);
+    // the partial-sum form (no dgamma: the sums stay in ws) ends with this kernel: it may carry an armed completion event (asr_stream_arm)
 #define LN_BWD(N, V)                                                                      \
-    add_ln_bwd_kernel<T, N, V, DROP><<<grid, LN_WAVES * WAVE, (size_t)LN_WAVES * d * sizeof(float), st>>>(                    \
+    asr_launch_armed(add_ln_bwd_kernel<T, N, V, DROP>, dim3(grid), dim3(LN_WAVES * WAVE), (size_t)LN_WAVES * d * sizeof(float), st,    \
         (const T*)dy, (const T*)dy2, (const T*)xhat, rstd, gamma, lens, (T*)dz, (T*)dx, ws, rows, T_, d, seed, thr, dscale)
     if (d % 512 == 0 && d <= 2048) {
         switch (d / 512) {

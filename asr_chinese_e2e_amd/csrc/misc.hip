@@ -98,6 +98,36 @@ extern "C" int asr_stream_fork(void* from_stream, void* to_stream) {
     return ASR_OK;
 }
 
+// Armed hand-over (see asr_launch_armed in asr_common.h): one pending (from, to) pair per process - the engine arms, calls ONE entry
+// point, and checks that the arm was taken.
+static hipStream_t g_arm_from = nullptr, g_arm_to = nullptr;
+static bool g_arm_set = false;
+extern "C" int asr_stream_arm(void* from_stream, void* to_stream) {
+    if (!g_fork_init) {
+        for (int i = 0; i < 256; ++i)
+            if (hipEventCreateWithFlags(&g_fork_events[i], hipEventDisableTiming) != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_arm: hipEventCreateWithFlags failed");
+        g_fork_init = true;
+    }
+    g_arm_from = (hipStream_t)from_stream;
+    g_arm_to = (hipStream_t)to_stream;
+    g_arm_set = true;
+    return ASR_OK;
+}
+// 1 while an arm is still waiting for its kernel (the entry point called since had no armed launch, or launched on another stream):
+// the caller then falls back to asr_stream_fork.  Clears the arm.
+extern "C" int asr_stream_arm_pending(void) {
+    const int p = g_arm_set ? 1 : 0;
+    g_arm_set = false;
+    return p;
+}
+bool asr_arm_take(hipStream_t st, hipStream_t* to, hipEvent_t* ev) {
+    if (!g_arm_set || st != g_arm_from) return false;
+    g_arm_set = false;
+    *to = g_arm_to;
+    *ev = g_fork_events[g_fork_next++ & 255u];
+    return true;
+}
+
 // A stream of the HIP runtime this library is linked against (the one torch loaded first), at the lowest (priority < 0),
 // default (0) or highest (> 0) priority the device offers.
 extern "C" int asr_stream_create(int priority, void** out_stream) {

@@ -1434,10 +1434,11 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         }
 #define FB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
         const bool masked = causal || window >= 0;
-        if (dthr && masked) sdpa_bwd_fused_bf16_kernel<true, true><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
-        else if (dthr) sdpa_bwd_fused_bf16_kernel<true, false><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
-        else if (masked) sdpa_bwd_fused_bf16_kernel<false, true><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
-        else sdpa_bwd_fused_bf16_kernel<false, false><<<B * H, FB_THREADS, FB_LDS, st>>>(FB_ARGS);
+        // the only kernel of this path: it may carry an armed completion event (asr_stream_arm)
+        if (dthr && masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
+        else if (dthr) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
+        else if (masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
+        else asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
 #undef FB_ARGS
     } else if (mfma && !bwd_split && sdpa_band_shape(Tq, Tk, dk, causal, window, dtype) && delta_bytes >= asr_sdpa_bwd_workspace_bytes(B, H, Tq, Tk, dk, causal, window, dtype)
                && ((uintptr_t)delta % 16) == 0) {

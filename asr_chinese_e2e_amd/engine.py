@@ -404,6 +404,8 @@ class Engine:
         self.defer_wgrad = tuple(t for t in os.environ.get("ASR_WGRAD_DEFER", "fc").split(",") if t)
         self._defer_point = os.environ.get("ASR_WGRAD_DEFER_POINT", "before")      # release before / after the attention backward launch
         self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
+        self.armed_fork = os.environ.get("ASR_ARMED_FORK", "1") == "1"      # see _arm
+        self._armed = False
         # ReLU mask of the encoder FFN as one bit per element (see _relu_bits): opt-in.  The w_2 input gradient then reads 2 MB instead of
         # the 32-MB activation tensor, but the step is 1 % SLOWER (3.128 vs 3.097 ms, joint 5.150 vs 5.110; A/B in one process): the
         # weight-gradient GEMM on the side stream streams the same tensor at the same time, so the second reader was nearly free, and
@@ -485,8 +487,22 @@ class Engine:
         self._ev_next = (self._ev_next + 1) & 63
         return ev
 
+    def _arm(self):
+        """The NEXT library entry point called on the current stream hands its output over to the weight-gradient stream by itself: its
+        last kernel carries the completion event (asr_stream_arm), and the next _fork(self.side) is then a no-op.  Without it the
+        hand-over is an event record behind the producer - a barrier packet that delays the next main-stream kernel by ~3.5 us, ~26
+        times per step.  Only for producers that are ONE armed-capable call (see include/asr_hip.h); anything else falls back."""
+        if self.armed_fork and self.overlap_wgrad and not torch.cuda.is_current_stream_capturing() and not self._in_decoder:
+            K.stream_arm(self._side_handle)
+            self._armed = True
+
     def _fork(self, stream):
         """`stream` continues after everything queued on the current stream so far."""
+        if self._armed:
+            self._armed = False
+            taken = not K.stream_arm_pending()      # clears the arm either way
+            if taken and stream is self.side:
+                return                               # the producer's own completion event is already queued on the side stream
         if torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event()
             ev.record()
@@ -629,14 +645,23 @@ class Engine:
         H, dk, hd = self.H, self.dk, self.H * self.dk
         B, Tq, Tk = c["dims"]
         pa, sa, pf, sf = c["drop"]
+        fc_deferred = bool(self.defer_wgrad) and self.overlap_wgrad and not self._in_decoder and m.fc.tag in self.defer_wgrad
+        if not fc_deferred:
+            self._arm()
         dz, dxg = self._ln_bwd(m.ln, m.fc.gb, dy, dy2, c["xhat"], c["rstd"], c["q_lens"], B, Tq, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(m.fc, dxg, c["ctx"])
+        if fc_deferred and not c["cross"] and self._defer_point != "after" and m.fc.own_dgrad(dxg):
+            self._arm()      # the held-back weight gradient is released right behind this input-gradient GEMM: its completion is the hand-over
         dctx = m.fc.dgrad(dxg)
         if not c["cross"]:
             qkv = c["qkv"]
             dqkv = torch.empty_like(qkv)
             if self._defer_point != "after":
                 self._release_deferred()
+            if self._armed:      # nothing was released: the arm must not leak into the attention kernel's launch
+                self._armed = False
+                K.stream_arm_pending()
+            self._arm()
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
                        dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa)
             if self._defer_point == "after":
@@ -695,10 +720,13 @@ class Engine:
     def _ffn_block_bwd(self, f, c, dy, dy2):
         B, T = c["dims"]
         pf, sf = c["drop"]
+        self._arm()
         dz, dxg = self._ln_bwd(f.ln, f.w2.gb, dy, dy2, c["xhat"], c["rstd"], c["lens"], B, T, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(f.w2, dxg, c["h"])
         fused_relu = self.fuse_relu_bwd and (f.w2.own_dgrad(dxg) or f.w2.small(dxg, f.w2.N) or dxg.dtype == torch.float32) and c["h"].is_contiguous() \
             and c["h"].data_ptr() % 16 == 0
+        if fused_relu and f.w2.own_dgrad(dxg):      # dh then comes out of ONE launch of the NT kernel
+            self._arm()
         if c.get("bits") is not None and fused_relu and f.w2.own_dgrad(dxg):
             f.w2._fresh_transpose()
             dh = K.gemm_nt_relu_bits(dxg, f.w2.wlpT, None, c["bits"], torch.empty(dxg.shape[0], f.w2.K, dtype=dxg.dtype, device=dxg.device), backward=True)
@@ -781,6 +809,8 @@ class Engine:
         buf = torch.empty(B * T, self.ld_v, dtype=enc.dtype, device=enc.device)      # rows padded to whole lines (see self.ld_v)
         logits = self.ctc_lo.fwd(enc, out=buf[:, :self.V])
         frames = buf.view(B, T, self.ld_v)[:, :, :self.V]
+        if want_grad:
+            self._arm()      # the head's weight gradient follows the loss kernels directly
         nll, dl = K.ctc_fwd_bwd(frames, wave_len, labels32, lab_len, ws if ws is not None else self.ws, blank=0, grad_scale=grad_scale,
                                 dlogits=frames if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div)
         if not want_grad:

@@ -53,6 +53,17 @@ def stream_fork(to_stream_handle, from_stream_handle=None):
     check(lib.asr_stream_fork(frm, to_stream_handle), "asr_stream_fork")
 
 
+def stream_arm(to_stream_handle, from_stream_handle=None):
+    """The next armed-capable entry point (include/asr_hip.h: asr_stream_arm) signals `to` from its last kernel on `from`."""
+    frm = _stream() if from_stream_handle is None else from_stream_handle
+    check(lib.asr_stream_arm(frm, to_stream_handle), "asr_stream_arm")
+
+
+def stream_arm_pending():
+    """True when the arm was NOT taken by a launch (cleared either way): fall back to stream_fork."""
+    return bool(lib.asr_stream_arm_pending())
+
+
 def bind_device(device):
     """One process drives ONE GPU: the launch stream is looked up on this device from now on.  Called when a model
     builds its engine; a model on a device other than torch's current one is refused (its kernels would be issued

@@ -65,6 +65,14 @@ int asr_last_error(char* buf, size_t n);
  * synchronises every step (trainer11.py:73-74); the engine runs weight gradients / the CTC branch / communication on side
  * streams and forks ~50 times per step.  Must not be called while either stream is being captured into a hipGraph. */
 int asr_stream_fork(void* from_stream, void* to_stream);
+/* Hand-over WITHOUT a marker packet in the producer's queue (ABI 7).  asr_stream_arm(from, to): the next entry point of this library
+ * that supports it (asr_gemm_nt_bf16 on the loader / consumer kernel, asr_add_ln_bwd in its partial-sum form, the fused asr_sdpa_bwd,
+ * asr_ctc_fwd_bwd with a gradient) launches its LAST kernel on `from` with the completion event bound to the dispatch packet itself
+ * (hipExtLaunchKernelGGL) and makes `to` wait for it - hipEventRecord would put a barrier packet behind that kernel, and the next
+ * kernel of the queue starts ~3.5 us later.  asr_stream_arm_pending() returns 1 (and clears the arm) when no launch took it: the
+ * caller then uses asr_stream_fork.  One arm at a time; host-side state only. */
+int asr_stream_arm(void* from_stream, void* to_stream);
+int asr_stream_arm_pending(void);
 /* A non-blocking stream created by the HIP runtime THIS library is bound to: priority < 0 = the lowest priority the device
  * offers (weight-gradient stream: off the critical path of the step), 0 = default, > 0 = the highest.  Lives as long as the
  * process.  (The reference has one stream, trainer11.py:73-74; torch.cuda.Stream offers no low priority.) */

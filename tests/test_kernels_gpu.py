@@ -592,6 +592,36 @@ def test_gemm_nt_loader_consumer_form(K, M, N, K_, mode):
     assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
 
 
+def test_armed_hand_over_orders_the_other_stream(K):
+    """asr_stream_arm: the next armed-capable launch (here the NT GEMM) carries its own completion event and the other stream waits for
+    it - no event record behind the kernel.  A copy of the GEMM's output queued on the other stream right after the launch sees the
+    finished output, every time; an arm that no launch takes is reported as pending (the caller then forks)."""
+    torch.manual_seed(5)
+    side = torch.cuda.Stream()
+    a = torch.randn(16000, 512, device=DEV).bfloat16()
+    w = (torch.randn(1536, 512, device=DEV) * 0.1).bfloat16()
+    ref = K.gemm_nt(a, w, None, torch.empty(16000, 1536, dtype=torch.bfloat16, device=DEV))
+    torch.cuda.synchronize()
+    for it in range(6):
+        out = torch.zeros(16000, 1536, dtype=torch.bfloat16, device=DEV)
+        copy = torch.full_like(out, 3.0)
+        torch.cuda.synchronize()
+        K.stream_arm(side.cuda_stream)
+        K.gemm_nt(a, w, None, out)
+        assert not K.stream_arm_pending()      # the launch took the arm
+        K.STREAM_OVERRIDE = side.cuda_stream
+        try:
+            K.cast(out, copy)                  # bf16 -> bf16 copy on the other stream
+        finally:
+            K.STREAM_OVERRIDE = None
+        torch.cuda.synchronize()
+        assert torch.equal(copy, ref), it
+    K.stream_arm(side.cuda_stream)
+    K.cast(ref, torch.empty_like(ref))         # not an armed-capable entry point
+    assert K.stream_arm_pending() and not K.stream_arm_pending()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K1,K2", [(16000, 1024, 512, 512), (4500, 1024, 512, 512), (5000, 1000, 256, 512), (300, 256, 128, 192)])
 def test_gemm_nt_relu_mask_as_bits(K, M, N, K1, K2):
     """The feed-forward pair with the ReLU mask kept as one bit per element (asr_gemm_nt_relu_bits_bf16): the forward writes the same

@@ -912,6 +912,37 @@ def test_padded_head_rows_match_dense_rows(name, monkeypatch):
     assert torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
 
 
+@pytest.mark.parametrize("name", ["TransformerCTC", "TransformerOffical"])
+def test_armed_hand_over_matches_event_fork(name, monkeypatch):
+    """The weight-gradient stream is handed its operands by the producer kernel's own completion event (ASR_ARMED_FORK=1, the default)
+    or by an event record behind it (0): same kernels, same order - in deterministic mode loss and gradients are bit-identical."""
+    from asr_chinese_e2e_amd import kernels as K
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, ctc_weight=0.3)
+    if name == "TransformerCTC":
+        over.update(use_decoder=False, ctc_weight=1.0)
+    cfg, sd, batch = oracle_case(9, 500, 80, 56, 12, over, seed=19)
+    pack = to_pack(batch)
+    prev = K.set_deterministic(True)
+    try:
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ASR_ARMED_FORK", mode)
+            model = build(cfg, 56, name, dtype="bf16").cuda()
+            model.load_state_dict(sd)
+            model.train()
+            eng = model._ensure_engine(DEV)
+            assert eng.armed_fork == (mode == "1")
+            for _ in range(3):      # a few steps: a missing dependency shows as a race, not every time
+                model.zero_flat_grads()
+                loss, _ = model.train_step(pack)
+            torch.cuda.synchronize()
+            res[mode] = (loss.clone(), model._flat.g.clone())
+    finally:
+        K.set_deterministic(prev)
+    assert torch.isfinite(res["1"][0]).all()
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
+
+
 def test_relu_bit_mask_matches_activation_mask(monkeypatch):
     """ASR_RELU_BITS=1: the encoder's feed-forward blocks keep the ReLU mask as one bit per element (written by the w_1 GEMM, read by the
     w_2 input gradient) instead of re-reading the activations in the backward pass (the default): same loss and, in deterministic
