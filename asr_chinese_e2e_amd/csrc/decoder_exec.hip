@@ -85,14 +85,18 @@ extern "C" int asr_decoder_layer_bwd(const asr_dec_layer_plan* p, const void* dy
     DEC_TRY(asr_gemm_small_bf16(dxg_c, p->w_fc_c, nullptr, nullptr, p->dctx, M, hd, d, d, hd, hd, 1, ASR_ACT_NONE, stream));
     char* kv = (char*)p->kv_c;
     char* gkv = (char*)p->g_kvc;
+    // d_enc += dK|dV W_kv (a (B*T)-row GEMM off the decoder's dependent chain, on aux_stream) needs only the attention backward's dK|dV:
+    // that kernel hands over by its own completion event (no event record - a barrier packet - in front of the chain's next kernel)
+    const bool kv_dgrad = p->d_enc && p->w_kv_c_T;
+    if (kv_dgrad && aux_stream) DEC_TRY(asr_stream_arm(stream, aux_stream));
     DEC_TRY(asr_sdpa_bwd(p->q_c, kv, kv + hd * e, p->ctx_c, p->dctx, p->lse_c, p->delta, p->delta_bytes, p->g_qc, gkv, gkv + hd * e, p->cross_len, B, H, To, T, dk, hd,
                          2 * hd, 2 * hd, hd, 0, -1, scale, p->drop_p, p->seed[2], ASR_BF16, stream));
-    DEC_TRY(asr_gemm_small_bf16(p->g_qc, p->w_q_c, nullptr, nullptr, p->dx_c, M, d, hd, hd, d, d, 1, ASR_ACT_NONE, stream));
-    if (p->d_enc && p->w_kv_c_T) {      // d_enc += dK|dV W_kv: a (B*T)-row GEMM off the decoder's dependent chain
+    if (kv_dgrad) {
         void* st2 = aux_stream ? aux_stream : stream;
-        if (aux_stream) DEC_TRY(asr_stream_fork(stream, aux_stream));
+        if (aux_stream && asr_stream_arm_pending()) DEC_TRY(asr_stream_fork(stream, aux_stream));      // the attention path taken had no armed launch
         DEC_TRY(asr_gemm_nt_bf16(p->g_kvc, p->w_kv_c_T, nullptr, p->d_enc, p->d_enc, B * T, d, 2 * hd, 2 * hd, p->ld_kv_c_T, d, ASR_ACT_NONE, st2));
     }
+    DEC_TRY(asr_gemm_small_bf16(p->g_qc, p->w_q_c, nullptr, nullptr, p->dx_c, M, d, hd, hd, d, d, 1, ASR_ACT_NONE, stream));
     // ---- self-attention block
     void* dxg_s = drop ? p->g_as : p->dz_s;
     DEC_TRY(asr_add_ln_bwd(p->dx_c, p->dz_c, p->a_s, p->rstd_s, p->g_s, p->dec_len, p->dz_s, drop ? p->g_as : nullptr, nullptr, nullptr, p->gb_fc_s, p->part_s, part_bytes,
@@ -102,6 +106,7 @@ extern "C" int asr_decoder_layer_bwd(const asr_dec_layer_plan* p, const void* dy
     char* gq = (char*)p->g_qkv;
     DEC_TRY(asr_sdpa_bwd(qkv, qkv + hd * e, qkv + 2 * hd * e, p->ctx_s, p->dctx, p->lse_s, p->delta, p->delta_bytes, gq, gq + hd * e, gq + 2 * hd * e, p->dec_len, B, H, To,
                          To, dk, 3 * hd, 3 * hd, 3 * hd, hd, 1, -1, scale, p->drop_p, p->seed[0], ASR_BF16, stream));
+    if (p->wgrad_stream) DEC_TRY(asr_stream_arm(stream, p->wgrad_stream));      // the layer's last kernel hands over to the weight-gradient stream
     DEC_TRY(asr_gemm_small_bf16(p->g_qkv, p->w_qkv_s, nullptr, nullptr, p->dx_s, M, d, 3 * hd, 3 * hd, d, d, 1, ASR_ACT_NONE, stream));
     return ASR_OK;
 }

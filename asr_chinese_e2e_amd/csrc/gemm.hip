@@ -2355,7 +2355,7 @@ extern "C" int asr_gemm_small_bf16(const void* A, const void* Bm, const float* b
         (void)hipFuncSetAttribute((const void*)gemm_small_kernel<false, ASR_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, small_lds_bytes<false>());
         attr = true;
     }
-#define SMALL(TB_, ACT_) gemm_small_kernel<TB_, ACT_><<<grid, 256, small_lds_bytes<TB_>(), st>>>(a, b, bias, mk, c, M, N, K, lda, ldb, ldc, tiles_n)
+#define SMALL(TB_, ACT_) asr_launch_armed(gemm_small_kernel<TB_, ACT_>, dim3(grid), dim3(256), small_lds_bytes<TB_>(), st, a, b, bias, mk, c, M, N, K, lda, ldb, ldc, tiles_n)      /* may carry an armed completion event */
     if (trans_b) {
         if (act == ASR_ACT_RELU_MASK) SMALL(true, ASR_ACT_RELU_MASK);
         else if (act == ASR_ACT_RELU) SMALL(true, ASR_ACT_RELU);

@@ -926,8 +926,11 @@ class Engine:
                 torch.cuda.current_stream().wait_event(d_enc_ready)
                 d_enc_ready = None
             pl.d_enc = d_enc.data_ptr() if cross.kv.wlpT is not None else None
+            hand_over = self.armed_fork and self.overlap_wgrad and not torch.cuda.is_current_stream_capturing()
+            pl.wgrad_stream = self._side_handle if hand_over else None      # the layer's last kernel signals the weight-gradient stream itself
             _lib.check(_lib.fast.asr_decoder_layer_bwd(ctypes.addressof(pl), dy.data_ptr(), None if dy2 is None else dy2.data_ptr(), main, aux),
                        "asr_decoder_layer_bwd")
+            self._armed = hand_over      # consumed (or found pending) by the next _fork(self.side)
             if cross.kv.wlpT is None:      # no transposed copy (odd widths): the accumulating input gradient through the generic path
                 cross.kv.dgrad(t["g_kvc"], out=d_enc, accumulate=True)
             # weight gradients of the layer (one grouped launch on the side stream) and the LayerNorm parameter-gradient partial sums

@@ -478,6 +478,9 @@ typedef struct asr_dec_layer_plan {
     float* delta;                          /* scratch of asr_sdpa_bwd */
     size_t delta_bytes;
     void* d_enc;                           /* (B*T, d) bf16 gradient wrt the encoder output, accumulated in place (or NULL) */
+    void* wgrad_stream;                    /* backward (ABI 7): stream that will run the layer's weight gradients, or NULL.  The LAST kernel of
+                                              asr_decoder_layer_bwd then hands over to it by its own completion event (asr_stream_arm): check
+                                              asr_stream_arm_pending() afterwards and fall back to asr_stream_fork when it returns 1 */
 } asr_dec_layer_plan;
 int asr_decoder_layer_fwd(const asr_dec_layer_plan* plan, void* stream);
 /* (dy, dy2): gradient wrt y_f (dy2 may be NULL; the two are added).  Results: plan->dx_s and plan->dz_s = gradient wrt x_in through the
