@@ -82,13 +82,21 @@ extern "C" int asr_last_error(char* buf, size_t n) {
 // to its side streams ~50 times per step; through torch.cuda.Event objects that costs the host ~12 us each (measured),
 // through this entry point ~2 us.  Re-using an event is safe: a wait refers to the record that preceded it at call time.
 // Not for use during stream capture (captured events belong to their graph): the caller keeps torch events there.
+// Events that only order streams of THIS device: a device-scope release when the event is recorded / when the kernel it is bound to
+// completes (hipEventReleaseToDevice).  The default is a system-scope release - the L2 written back so that the host or another device
+// could look at the data - and the main queue started its next kernel ~5 us late after every kernel that carried such an event
+// (step timeline, round 3).  ASR_EVENT_SCOPE=system restores the default (A/B runs).
+static unsigned fork_event_flags() {
+    const char* e = getenv("ASR_EVENT_SCOPE");
+    return hipEventDisableTiming | ((e && !strcmp(e, "system")) ? 0u : hipEventReleaseToDevice);
+}
 static hipEvent_t g_fork_events[256];
 static unsigned g_fork_next = 0;
 static bool g_fork_init = false;
 extern "C" int asr_stream_fork(void* from_stream, void* to_stream) {
     if (!g_fork_init) {
         for (int i = 0; i < 256; ++i)
-            if (hipEventCreateWithFlags(&g_fork_events[i], hipEventDisableTiming) != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_fork: hipEventCreateWithFlags failed");
+            if (hipEventCreateWithFlags(&g_fork_events[i], fork_event_flags()) != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_fork: hipEventCreateWithFlags failed");
         g_fork_init = true;
     }
     hipEvent_t ev = g_fork_events[g_fork_next++ & 255u];
@@ -105,7 +113,7 @@ static bool g_arm_set = false;
 extern "C" int asr_stream_arm(void* from_stream, void* to_stream) {
     if (!g_fork_init) {
         for (int i = 0; i < 256; ++i)
-            if (hipEventCreateWithFlags(&g_fork_events[i], hipEventDisableTiming) != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_arm: hipEventCreateWithFlags failed");
+            if (hipEventCreateWithFlags(&g_fork_events[i], fork_event_flags()) != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_stream_arm: hipEventCreateWithFlags failed");
         g_fork_init = true;
     }
     g_arm_from = (hipStream_t)from_stream;
