@@ -641,10 +641,16 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
                         if (t + 5 < ntile) dma_tile(t + 5);
                     }
                     if (!active) continue;
+#ifdef SDPA_FWD_SKIP
+                    if (SDPA_FWD_SKIP & 1) continue;      // diagnostic builds: the first pass only streams (WRONG results, timing only)
+#endif
                     FF_LOAD_K(t);
                 } else if (!PREFETCH) {
                     FF_LOAD_K(t);
                 }
+#ifdef SDPA_FWD_SKIP
+                if ((SDPA_FWD_SKIP & 2) && !stream) continue;      // diagnostic builds: no work in the second (resident) pass
+#endif
                 if (!MASKED && qbk == 0 && t == t1 - 1 && q0 + 32 < Tq) frags_from_global(qnext, qb, ldq, q0 + 32, Tq, lane);
                 f32x16 st[2];
 #pragma unroll
