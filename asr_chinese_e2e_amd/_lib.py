@@ -76,6 +76,8 @@ SIGNATURES = {
     "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, F, U, I, I, P]),
     "asr_add_ln_bwd_reduce_batched": (I, [P, I, I, P]),
     "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
+    "asr_sdpa_drop_bits_bytes": (Z, [I, I, I, I, I, I]),
+    "asr_sdpa_drop_bits": (I, [P, Z]),
     "asr_sdpa_bwd_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),
     "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, Z, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
     "asr_dropout_mask": (I, [P, I, I, F, U, P]),

@@ -405,6 +405,10 @@ class Engine:
         self._defer_point = os.environ.get("ASR_WGRAD_DEFER_POINT", "before")      # release before / after the attention backward launch
         self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
         self.armed_fork = os.environ.get("ASR_ARMED_FORK", "1") == "1"      # see _arm
+        # attention dropout: keep mask handed to the backward kernel as bits (asr_sdpa_drop_bits) instead of hashed again there.  Opt-in:
+        # the backward gains 10 us (104 -> 94 stand-alone) but the forward pays 4.5 (48.2 -> 52.7: 64 v_writelane per tile move the
+        # compares' lane masks onto the lanes) and is not overlapped with anything: step 3.521 vs 3.504 ms at dropout 0.1
+        self.drop_bits = os.environ.get("ASR_DROP_BITS", "0") == "1"
         self._armed = False
         # ReLU mask of the encoder FFN as one bit per element (see _relu_bits): opt-in.  The w_2 input gradient then reads 2 MB instead of
         # the 32-MB activation tensor, but the step is 1 % SLOWER (3.128 vs 3.097 ms, joint 5.150 vs 5.110; A/B in one process): the
@@ -628,7 +632,13 @@ class Engine:
             c["q"], c["kv"] = q, kv
         pa, sa = self._drop(site)          # attention probabilities (attention.py:83)
         pf, sf = self._drop(site + 1)      # after fc, before residual + LN (attention.py:59)
-        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa)
+        dbits = None
+        if pa > 0.0 and self.drop_bits:      # the keep mask goes to the backward kernel as bits (it then does not hash again)
+            nb = K.sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, q.dtype)
+            if nb and q.shape[0] * H >= 4096:      # encoder-sized attention only: for the decoder's few rows the hash is cheaper than 8 MB of words
+                dbits = torch.empty(nb, dtype=torch.uint8, device=q.device)
+        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa, drop_bits=dbits)
+        c["drop_bits"] = dbits
         if self._fuse_ln(m.fc, ctx, x, pf):      # out-projection + residual + LayerNorm in one kernel
             y, xhat, rstd = K.gemm_nt_add_ln(ctx, m.fc.wlp, m.fc.b32, x, m.ln.g, m.ln.b, q_lens, B, Tq)
         else:
@@ -663,7 +673,7 @@ class Engine:
                 K.stream_arm_pending()
             self._arm()
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
-                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa)
+                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa, drop_bits=c.get("drop_bits"))
             if self._defer_point == "after":
                 self._release_deferred()
             self._wgrad(m.qkv, dqkv, c["x"], bias_from=dqkv)
@@ -673,7 +683,7 @@ class Engine:
             dq = torch.empty_like(q)
             dkv = torch.empty_like(kv)
             K.sdpa_bwd(q, kv[:, :hd], kv[:, hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk, dq, dkv[:, :hd], dkv[:, hd:],
-                       c["causal"], c["window"], drop_p=pa, drop_seed=sa)
+                       c["causal"], c["window"], drop_p=pa, drop_seed=sa, drop_bits=c.get("drop_bits"))
             self._wgrad(m.q, dq, c["x"], bias_from=dq)
             self._wgrad(m.kv, dkv, c["kv_src"], bias_from=dkv)
             dx = m.q.dgrad(dq)

@@ -228,8 +228,18 @@ def _strided_rows(t, H, dk):
     return t.stride(0)
 
 
-def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None, drop_p=0.0, drop_seed=0):
-    """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer)."""
+def sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, dtype):
+    """Size of the buffer that carries the attention dropout's keep mask from sdpa_fwd to sdpa_bwd as bits (0: this shape has no such
+    hand-over - the backward regenerates the mask from the counter hash)."""
+    return int(lib.asr_sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, _dt(torch.empty(0, dtype=dtype))))
+
+
+def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None, drop_p=0.0, drop_seed=0, drop_bits=None):
+    """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer).
+    drop_bits (uint8 tensor of sdpa_drop_bits_bytes, with drop_p > 0): receives the keep mask for sdpa_bwd(drop_bits=...)."""
+    if drop_bits is not None and drop_p > 0.0:
+        assert drop_bits.dtype == torch.uint8 and drop_bits.is_contiguous()
+        check(lib.asr_sdpa_drop_bits(_p(drop_bits), drop_bits.numel()), "asr_sdpa_drop_bits")
     ldq, ldk, ldv = _strided_rows(q, H, dk), _strided_rows(k, H, dk), _strided_rows(v, H, dk)
     assert q.shape[0] == B * Tq and k.shape[0] == B * Tk and v.shape[0] == B * Tk
     assert q.dtype == k.dtype == v.dtype
@@ -248,7 +258,10 @@ def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=No
 
 
 def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=False, window=-1, scale=None, delta=None,
-             drop_p=0.0, drop_seed=0):
+             drop_p=0.0, drop_seed=0, drop_bits=None):
+    if drop_bits is not None and drop_p > 0.0:      # the keep mask the forward call wrote (same shape, seed and drop_p)
+        assert drop_bits.dtype == torch.uint8 and drop_bits.is_contiguous()
+        check(lib.asr_sdpa_drop_bits(_p(drop_bits), drop_bits.numel()), "asr_sdpa_drop_bits")
     ldq, ldk, ldv, ldo = (_strided_rows(t, H, dk) for t in (q, k, v, o))
     assert _strided_rows(do, H, dk) == ldo and _strided_rows(dq, H, dk) == ldq
     assert _strided_rows(dk_, H, dk) == ldk and _strided_rows(dv, H, dk) == ldv

@@ -158,6 +158,14 @@ int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* ls
                  int ldv, int ldo, int causal, int window, float scale, float drop_p,
                  uint32_t drop_seed, int dtype, void* stream);
 
+/* Hand-over of the attention dropout's keep mask from the forward to the backward call as bits (ABI 7), for the shapes both fused
+ * kernels take (bf16, dk = 64, Tk <= 512): asr_sdpa_drop_bits(bits, bytes) gives the buffer to the NEXT asr_sdpa_fwd (which writes
+ * it: one 32-bit word per key and 32-query block) or asr_sdpa_bwd (which reads it instead of hashing again - the backward's loop is
+ * where the hash hurts: 97 vs 65 us at config 2); the call after that has no buffer again.  Same mask as without the buffer.
+ * asr_sdpa_drop_bits_bytes: size needed, 0 = no hand-over for this shape (a buffer given anyway makes the call fail). */
+size_t asr_sdpa_drop_bits_bytes(int B, int H, int Tq, int Tk, int dk, int dtype);
+int asr_sdpa_drop_bits(void* bits, size_t bytes);
+
 /* Backward: given do (same layout as o) computes dq, dk, dv (layouts/strides of q, k, v).
  * delta: f32 scratch of delta_bytes >= asr_sdpa_bwd_workspace_bytes(...) bytes, written by the call: (B, H, Tq) row sums
  * rowsum(do*o) for the two-kernel paths, or - bf16 self-attention inside a +-window band over more than 512 keys (the long-form

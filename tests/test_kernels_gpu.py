@@ -1179,6 +1179,42 @@ def test_sdpa_dropout(K, dtype, B, H, Tq, Tk, dk, causal):
     close(dg[:, d:].reshape(B, Tk, H, dk), vr.grad, **gt, what="sdpa dropout dv")
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,causal", [(2, 8, 500, 500, False), (2, 4, 130, 130, True), (1, 8, 70, 500, False), (3, 2, 33, 512, False)])
+def test_sdpa_dropout_keep_mask_as_bits(K, B, H, Tq, Tk, causal):
+    """The fused kernels hand the dropout keep mask from the forward to the backward call as bits (asr_sdpa_drop_bits: one word per key
+    and 32-query block, written from the lane masks of the forward's compares) instead of hashing again: outputs and gradients are
+    bit-identical to the regenerating path; a buffer that the call cannot use is refused."""
+    torch.manual_seed(Tq + Tk)
+    dk, p, seed = 64, 0.15, 4242
+    d = H * dk
+    qkv = torch.randn(B * max(Tq, Tk), 3 * d, device=DEV).bfloat16()
+    q, k, v = qkv[: B * Tq, :d], qkv[: B * Tk, d:2 * d], qkv[: B * Tk, 2 * d:]
+    klen = torch.tensor([Tk, max(Tk - 37, 1), max(Tk // 2, 1)][:B], dtype=torch.int32, device=DEV)
+    do = torch.randn(B * Tq, d, device=DEV).bfloat16()
+    nb = K.sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, torch.bfloat16)
+    assert nb == B * H * ((Tq + 31) // 32) * 512 * 4
+    res = {}
+    for use_bits in (False, True):
+        bits = torch.zeros(nb, dtype=torch.uint8, device=DEV) if use_bits else None
+        o, lse = K.sdpa_fwd(q, k, v, klen, B, H, Tq, Tk, dk, causal, -1, drop_p=p, drop_seed=seed, drop_bits=bits)
+        dqkv = torch.zeros_like(qkv)      # gradients in the layout of their operands
+        K.sdpa_bwd(q, k, v, o, do, lse, klen, B, H, Tq, Tk, dk, dqkv[: B * Tq, :d], dqkv[: B * Tk, d:2 * d], dqkv[: B * Tk, 2 * d:], causal, -1,
+                   drop_p=p, drop_seed=seed, drop_bits=bits)
+        res[use_bits] = (o, lse, dqkv)
+        if use_bits:      # the words really carry the mask: their density is the keep probability
+            words = bits.view(torch.int32).view(B * H, (Tq + 31) // 32, 512)[:, 0, : min(Tk, 64)]
+            ones = sum(int(((words >> b) & 1).sum()) for b in range(min(32, Tq)))
+            frac = ones / (words.numel() * min(32, Tq))
+            assert abs(frac - (1 - p)) < 0.03, frac
+    for a, b_, name in zip(res[False], res[True], ("o", "lse", "dqkv")):
+        assert torch.equal(a, b_), (name, float((a.float() - b_.float()).abs().max()))
+    # Tk = 600 takes the tiled kernels: no hand-over, and a buffer given anyway is an error
+    assert K.sdpa_drop_bits_bytes(1, 2, 600, 600, dk, torch.bfloat16) == 0
+    big = torch.randn(600, 3 * 2 * dk, device=DEV).bfloat16()
+    with pytest.raises(RuntimeError, match="cannot use it"):
+        K.sdpa_fwd(big[:, :128], big[:, 128:256], big[:, 256:], None, 1, 2, 600, 600, dk, drop_p=p, drop_seed=1, drop_bits=torch.zeros(64, dtype=torch.uint8, device=DEV))
+
+
 def test_embed_dropout(K):
     torch.manual_seed(0)
     V, d, B, To, p, seed = 30, 48, 3, 6, 0.25, 5

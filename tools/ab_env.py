@@ -19,7 +19,7 @@ def apply(val):
         K.set_option(name[4:], int(val))
 def build(val):
     apply(val)
-    cfg = M.get_default_config()(); cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=0.0, ctc_weight=0.3 if JOINT else 1.0, cer_in_iterate=False))
+    cfg = M.get_default_config()(); cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=float(os.environ.get("AB_DROPOUT", "0.0")), ctc_weight=0.3 if JOINT else 1.0, cer_in_iterate=False))
     model = M(cfg, Vocab.synthetic(4232)).cuda()
     opt = NoamOpt(512, 1, 4000, FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
     for _ in range(10): model.iterate(pack, optimizer=opt)
