@@ -130,7 +130,21 @@ class AsrHipError(RuntimeError):
     pass
 
 
+def _check_runtime_env(env=None):
+    """Refuse HIP runtime settings under which the multi-stream step cannot make progress.
+    ROC_SYSTEM_SCOPE_SIGNAL=0: the step orders its streams by waits on completion signals of other queues (asr_stream_fork /
+    asr_stream_arm: hipStreamWaitEvent on pooled events and on a dispatch packet's own completion signal); with system-scope signal
+    completion switched off those waits never see the signal and the step hangs without an error (round 3: a run was cut after 7
+    silent minutes).  Inherited from a user's environment it would hang the product silently - fail at import instead."""
+    env = os.environ if env is None else env
+    v = env.get("ROC_SYSTEM_SCOPE_SIGNAL")
+    if v is not None and v.strip() == "0":
+        raise RuntimeError("ROC_SYSTEM_SCOPE_SIGNAL=0 is set: the two-stream training step of asr_chinese_e2e_amd waits on completion signals "
+                           "across HIP queues and would hang silently under it - unset the variable (or set it to 1)")
+
+
 def _load():
+    _check_runtime_env()
     if not os.path.isfile(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "

@@ -11,10 +11,15 @@
 // and autograd through them.  Weight gradients, LayerNorm parameter-gradient reductions and data-parallel marks stay with the caller.
 #include "asr_common.h"
 
+// a failing call ends the layer: an arm this sequencer set (asr_stream_arm) must not survive it - the next armed-capable launch of the
+// process would otherwise carry a completion event nobody asked for, and the caller's next fork would be skipped
 #define DEC_TRY(call)                \
     do {                             \
         const int rc__ = (call);     \
-        if (rc__ != ASR_OK) return rc__; \
+        if (rc__ != ASR_OK) {        \
+            asr_stream_arm_pending(); \
+            return rc__;             \
+        }                            \
     } while (0)
 
 static int dec_check(const asr_dec_layer_plan* p, const char* who) {

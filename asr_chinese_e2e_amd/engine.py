@@ -401,6 +401,14 @@ class Engine:
         self.group_wgrad = None if (self.group_wgrad == "0" or self.deterministic) else self.group_wgrad
         self._pending = []
         self._deferred = []
+        # Operands of kernels issued on the weight-gradient / auxiliary streams are kept alive HERE until the step has joined those
+        # streams (encoder_bwd's end), instead of being marked with Tensor.record_stream: a marked block is not reusable when its
+        # tensor dies but only once an event recorded at that moment has completed, which the caching allocator polls at later
+        # allocations - early steps then find the pool empty and call hipMalloc (a device synchronisation) until the pool has
+        # grown past what the step needs (round 3: the extra bench configurations ran 12 - 38 % slower under 5 warm-up steps
+        # than under 30).  Holding references costs nothing (the blocks are the step's own) and makes the allocation sequence
+        # of every step identical from the second step on.
+        self._keep = []
         self.defer_wgrad = tuple(t for t in os.environ.get("ASR_WGRAD_DEFER", "fc").split(",") if t)
         self._defer_point = os.environ.get("ASR_WGRAD_DEFER_POINT", "before")      # release before / after the attention backward launch
         self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
@@ -410,6 +418,7 @@ class Engine:
         # compares' lane masks onto the lanes) and is not overlapped with anything: step 3.521 vs 3.504 ms at dropout 0.1
         self.drop_bits = os.environ.get("ASR_DROP_BITS", "0") == "1"
         self._armed = False
+        self._arm_covers_pending = False      # set by _dec_exec_bwd while it collects a layer's weight gradients behind its armed last kernel
         # ReLU mask of the encoder FFN as one bit per element (see _relu_bits): opt-in.  The w_2 input gradient then reads 2 MB instead of
         # the 32-MB activation tensor, but the step is 1 % SLOWER (3.128 vs 3.097 ms, joint 5.150 vs 5.110; A/B in one process): the
         # weight-gradient GEMM on the side stream streams the same tensor at the same time, so the second reader was nearly free, and
@@ -500,6 +509,15 @@ class Engine:
             K.stream_arm(self._side_handle)
             self._armed = True
 
+    def _disarm(self):
+        """Drop an arm that no _fork(self.side) consumed right behind its producer.  If the producer's launch took it, the side stream
+        merely waits for that kernel (harmless); what must not happen is that a LATER _fork finds `_armed` set and skips its event
+        although other main-stream kernels ran since (round-3 ADVICE: ASR_WGRAD_DEFER=w2 at B*T < 4096, ASR_WGRAD_GROUP=block with
+        ASR_FUSE_RELU_BWD=0 - the side stream then read a dY ordered only behind the armed kernel)."""
+        if self._armed:
+            self._armed = False
+            K.stream_arm_pending()
+
     def _fork(self, stream):
         """`stream` continues after everything queued on the current stream so far."""
         if self._armed:
@@ -514,6 +532,17 @@ class Engine:
         else:
             K.stream_fork(stream.cuda_stream)
 
+    def _release_kept(self, joined=False):
+        """Drop the references of self._keep.  joined: the caller has just made the current stream wait for the side streams (the end
+        of a training step).  Otherwise (an evaluation forward pass, a step that raised) the current stream first waits for both, so
+        that whatever reuses the blocks is ordered behind their last reader."""
+        if self._keep:
+            if not joined and not torch.cuda.is_current_stream_capturing():
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self.side)
+                cur.wait_stream(self.ctc_stream)
+            self._keep.clear()
+
     def refresh_transposes(self):
         """W^T copies for the own-kernel input gradients: one launch on the side stream, which is idle during the
         forward pass; the backward pass waits for it (wait_transposes) before its first input-gradient GEMM.
@@ -521,6 +550,7 @@ class Engine:
         module's train / eval flag says."""
         if self._tr_tiles is None:
             return
+        self._disarm()      # an arm left by a step that raised must not skip this hand-over (the copies must follow the optimizer update)
         self._fork(self.side)
         K.STREAM_OVERRIDE = self._side_handle
         try:
@@ -562,8 +592,7 @@ class Engine:
         # replay overwrote dY / X tensors that the side stream's weight-gradient kernel had not read yet (round 3: gradients of the
         # replayed step differed from the eager step; tests/test_train_loop_gpu.py::test_graphed_step_matches_eager)
         for dy, x, _, _ in probs:
-            dy.record_stream(self.side)
-            x.record_stream(self.side)
+            self._keep += (dy, x)
 
     def _release_deferred(self):
         """Launch the weight gradients held back by ASR_WGRAD_DEFER (see _wgrad)."""
@@ -584,11 +613,14 @@ class Engine:
             # 83-us attention kernel: step 3.53 -> 3.50 ms.  Holding back any other projection (w1, w2, qkv) or releasing after
             # the attention launch is slower (3.56 .. 3.73 ms, tools/env_sweep.sh): the side stream has no slack to give.
             self._deferred.append((lin, dy, x, bias_from))
+            self._disarm()      # no fork here: the arm must not outlive its producer (a later _fork would skip its event)
             return
         fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
         if self.group_wgrad and (self.group_wgrad != "decoder" or self._in_decoder) and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
                 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
             self._pending.append((dy, x, lin.gw, lin.gb if fused else None))     # launched by flush_wgrads (end of the layer)
+            if not self._arm_covers_pending:      # only the decoder sequencer's arm (its layer's LAST kernel) orders everything collected here
+                self._disarm()
             return
         if not self.overlap_wgrad:
             if bias_from is not None and not fused:
@@ -610,8 +642,7 @@ class Engine:
                 if bias_from is not None and not fused:
                     lin.bgrad(bias_from, self.ws_side)
                 lin.wgrad(dy, x, with_bias=fused)
-        for t in (dy, x):      # also while capturing (see flush_wgrads)
-            t.record_stream(self.side)
+        self._keep += (dy, x)      # also while capturing (see flush_wgrads)
 
     def _attn_block_fwd(self, m, x, kv_src, B, Tq, Tk, k_len, q_lens, causal, window, cross, site, kv_pre=None):
         """x: (B*Tq, d) queries + residual; kv_src: (B*Tk, d).  Returns output and cache."""
@@ -668,9 +699,7 @@ class Engine:
             dqkv = torch.empty_like(qkv)
             if self._defer_point != "after":
                 self._release_deferred()
-            if self._armed:      # nothing was released: the arm must not leak into the attention kernel's launch
-                self._armed = False
-                K.stream_arm_pending()
+            self._disarm()      # nothing was released: the arm must not leak into the attention kernel's launch
             self._arm()
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
                        dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa, drop_bits=c.get("drop_bits"))
@@ -694,7 +723,7 @@ class Engine:
                 self._fork(self.ctc_stream)
                 with torch.cuda.stream(self.ctc_stream):
                     m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
-                dkv.record_stream(self.ctc_stream)
+                self._keep.append(dkv)
             else:
                 m.kv.dgrad(dkv, out=d_kv_src, accumulate=True)
         if self._block_flush:
@@ -744,6 +773,7 @@ class Engine:
             dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)     # ReLU backward in the GEMM's store tail
         fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
         if not fused_relu:
+            self._disarm()      # dh is finished by the masking kernel below, not by the (possibly armed) GEMM above
             K.relu_bwd_(dh, c["h"], None if fused else f.w1.gb, self.ws)
         elif not fused:
             f.w1.bgrad(dh, self.ws)
@@ -760,6 +790,8 @@ class Engine:
         self._deferred.clear()
         self._pending.clear()        # work queued by a step that did not finish (an exception between backward and
         self._ln_pending.clear()     # its flush) must not be launched into this step's gradients
+        self._disarm()               # ... nor may its arm skip this step's first hand-over (refresh_transposes clears it too)
+        self._release_kept()
         x_in = wave.reshape(B * T, F)
         e0 = self.lin_in.fwd(x_in)
         p0, s0 = self._drop(1)             # dropout(LN(linear_in(x)) + PE)  (transformer_official.py:175-177)
@@ -794,6 +826,9 @@ class Engine:
         self._block_flush = self.group_wgrad == "block"
         self.flush_ln_reduce()
         self.join_side()
+        # every stream has been joined (the auxiliary stream at the end of decoder_bwd; without a decoder nothing runs on it): the
+        # operands held for them can go back to the pool - what reuses them is ordered behind this point on the current stream
+        self._release_kept(joined=True)
         self._ready("encoder.linear_in.weight")
 
     # ------------------------------------------------------------------ CTC head
@@ -808,10 +843,9 @@ class Engine:
             nll, d_enc = self.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale, grad_scale_div=grad_scale_div, ws=self.ws_ctc)
             done = torch.cuda.Event()
             done.record(self.ctc_stream)
-        for t in (enc, wave_len, labels32, lab_len):
-            t.record_stream(self.ctc_stream)
-        for t in (nll, d_enc):
-            t.record_stream(main)
+        # inputs read on the auxiliary stream, and the two results (blocks of that stream's pool, read on the main stream): alive until
+        # the step has joined the stream (decoder_bwd), see self._keep
+        self._keep += (enc, wave_len, labels32, lab_len, nll, d_enc)
         return nll, d_enc, done
 
     def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None, ws=None):
@@ -853,11 +887,16 @@ class Engine:
         next forward pass touches these buffers)."""
         key = (B, To, T, bool(drop))
         hit = self._dec_cache.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if hit is not None:
             self._dec_cache.move_to_end(key)
+            # a captured hipGraph bakes these buffers' addresses into its kernel arguments: the shape stays for the life of the engine
+            hit["pinned"] = hit["pinned"] or capturing
             return hit
-        while len(self._dec_cache) >= self.DEC_CACHE_SHAPES:      # real batches come in many shapes: keep the most recent few, free the rest
-            self._dec_cache.popitem(last=False)
+        # real batches come in many shapes: keep the most recent few, free the rest - never one a graph replays into
+        evictable = [k for k, v in self._dec_cache.items() if not v["pinned"]]
+        while len(evictable) >= self.DEC_CACHE_SHAPES:
+            del self._dec_cache[evictable.pop(0)]
         dev, M, d, hd, ff, H = self.flat.device, B * To, self.d, self.H * self.dk, self.ff, self.H
         bf = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -891,7 +930,7 @@ class Engine:
             pl.delta, pl.delta_bytes = delta.data_ptr(), delta.numel() * 4
             t["kv_event"] = torch.cuda.Event()
             layers.append((pl, t))
-        hit = self._dec_cache[key] = dict(layers=layers, delta=delta)
+        hit = self._dec_cache[key] = dict(layers=layers, delta=delta, pinned=capturing)
         return hit
 
     def _dec_exec_fwd(self, x, enc, dec_len, cross_len, B, To, T):
@@ -906,7 +945,7 @@ class Engine:
                     cross.kv.fwd(enc, out=t["kv_c"])
                     t["kv_event"].record(self.ctc_stream)
                     pl.kv_ready_event = t["kv_event"].cuda_event
-            enc.record_stream(self.ctc_stream)
+            self._keep.append(enc)
         for i, ((pl, t), (_, cross, _)) in enumerate(zip(bufs["layers"], self.dec)):
             if not overlap:
                 cross.kv.fwd(enc, out=t["kv_c"])
@@ -940,7 +979,7 @@ class Engine:
             pl.wgrad_stream = self._side_handle if hand_over else None      # the layer's last kernel signals the weight-gradient stream itself
             _lib.check(_lib.fast.asr_decoder_layer_bwd(ctypes.addressof(pl), dy.data_ptr(), None if dy2 is None else dy2.data_ptr(), main, aux),
                        "asr_decoder_layer_bwd")
-            self._armed = hand_over      # consumed (or found pending) by the next _fork(self.side)
+            self._armed = self._arm_covers_pending = hand_over      # consumed (or found pending) by the next _fork(self.side): flush_wgrads in _ready
             if cross.kv.wlpT is None:      # no transposed copy (odd widths): the accumulating input gradient through the generic path
                 cross.kv.dgrad(t["g_kvc"], out=d_enc, accumulate=True)
             # weight gradients of the layer (one grouped launch on the side stream) and the LayerNorm parameter-gradient partial sums
@@ -955,6 +994,7 @@ class Engine:
                                  (t["part_s"], slf.ln.gg, slf.ln.gb, slf.fc.gb, M)]
             dy, dy2 = t["dx_s"], t["dz_s"]
             self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
+            self._arm_covers_pending = False
         return dy, dy2
 
     # ------------------------------------------------------------------ decoder
@@ -981,11 +1021,9 @@ class Engine:
                     kv = cross.kv.fwd(enc)
                     e = torch.cuda.Event()
                     e.record(self.ctc_stream)
-                    kv.record_stream(torch.cuda.current_stream())
                     kv_pre[i] = (kv, e)
-            enc.record_stream(self.ctc_stream)
-            for kv, _ in kv_pre:
-                kv.record_stream(torch.cuda.current_stream())
+            self._keep.append(enc)
+            self._keep += [kv for kv, _ in kv_pre]      # blocks of the auxiliary stream's pool, read on the main stream
         for i, (slf, cross, ffn) in enumerate(self.dec):
             x1, c1 = self._attn_block_fwd(slf, x, x, B, To, To, dec_len, dec_len, True, -1, False, site=100 + 8 * i)
             x2, c2 = self._attn_block_fwd(cross, x1, enc, B, To, T, cross_len, dec_len, False, -1, True, site=102 + 8 * i, kv_pre=kv_pre[i])

@@ -201,15 +201,38 @@ class Run:
         for _ in range(n):
             self.last, _ = runner.iterate(self.pack, optimizer=self.opt, is_train=True)
 
-    def timed(self, warmup, steps):
+    def timed(self, warmup, steps, strict=True):
+        """`warmup` untimed steps, then exactly `steps` timed ones between barrier + synchronize.  The caching allocator must not
+        grow inside the timed region (a hipMalloc synchronises the device): the engine keeps the operands of its side-stream kernels
+        alive itself instead of Tensor.record_stream, so the allocation sequence repeats from the second step on (DESIGN.md section 5,
+        round 4) - counted here, and with `strict` a non-zero count ends the run instead of reporting a number measured across it."""
+        torch = self.torch
         self.steps(warmup)
         self.barrier()
         if self.dp is not None:
             self.dp.bucketer.exposed_ms()      # drop the warm-up steps' samples
+        a0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
         t0 = time.perf_counter()
         self.steps(steps)
         self.barrier()
-        return time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        self.alloc_growth = torch.cuda.memory_stats().get("num_device_alloc", 0) - a0
+        if self.alloc_growth:
+            log(f"{self.alloc_growth} device allocation(s) INSIDE the timed region ({'joint' if self.joint else 'ctc'} model, {warmup} warm-up steps)")
+            if strict:
+                raise SystemExit("bench: the caching allocator grew inside a timed region - the number would include hipMalloc synchronisations")
+        return dt
+
+    def replica_checksum(self):
+        """(min, max) over the ranks of the sum of all parameters after the timed steps: equal unless the replicas diverged
+        (the bf16 wire format rounds, but every rank receives the SAME reduced bucket and applies the same update)."""
+        torch = self.torch
+        cs = self.model._flat.p.double().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        return float(lo), float(hi)
 
     def kernel_pass(self, n_inst):
         """The SAME steps once more with HIP events around every launch of the listed kernel families (recorded on
@@ -229,7 +252,10 @@ class Run:
                 self.lib_gemm_calls += 1
                 return fn(*a, **k)
             return wrapped
-        for owner, name in ((torch, "mm"), (torch, "addmm"), (torch, "matmul"), (torch, "bmm"), (torch.Tensor, "addmm_"), (torch.Tensor, "matmul"), (torch.Tensor, "mm")):
+        import torch.nn.functional as F
+        for owner, name in ((torch, "mm"), (torch, "addmm"), (torch, "matmul"), (torch, "bmm"), (torch, "baddbmm"), (torch, "einsum"), (torch, "mv"), (F, "linear"),
+                            (torch.Tensor, "addmm_"), (torch.Tensor, "addmm"), (torch.Tensor, "matmul"), (torch.Tensor, "mm"), (torch.Tensor, "bmm"),
+                            (torch.Tensor, "__matmul__"), (torch.Tensor, "__rmatmul__")):
             saved[(owner, name)] = getattr(owner, name)
             setattr(owner, name, counting(saved[(owner, name)]))
         try:
@@ -240,6 +266,7 @@ class Run:
                 setattr(owner, name, fn)
             K.TIMER = None
             self.model._engine.overlap_wgrad = not self.model._engine.deterministic
+        self.lib_gemm_calls_per_step = self.lib_gemm_calls / max(n_inst, 1)
         if self.lib_gemm_calls:
             raise SystemExit(f"bench: {self.lib_gemm_calls} library GEMM call(s) in {n_inst} steps - every projection is expected on an own kernel")
         return timer.summary()
@@ -307,11 +334,14 @@ def main():
 
     run = Run(args, config, args.dropout, rank, dev, use_dp)
     log(f"rank {rank}/{world}: {config} model on {dev}, warm-up {args.warmup} steps")
-    dt = run.timed(args.warmup, args.steps)
+    dt = run.timed(args.warmup, args.steps, strict=(world == 1))      # N > 1 has never run on xGMI: count and report, do not end the run
+    alloc_growth = run.alloc_growth
     log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
     summary, n_inst = None, min(args.steps, 10)
+    lib_gemm_per_step = None
     if not args.no_kernel_timer:
         summary = run.kernel_pass(n_inst)
+        lib_gemm_per_step = run.lib_gemm_calls_per_step
     if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -325,29 +355,48 @@ def main():
         ex = torch.tensor([run.dp.bucketer.exposed_ms(reset=False) or 0.0], device=dev, dtype=torch.float64)
         if world > 1:
             torch.distributed.all_reduce(ex, op=torch.distributed.ReduceOp.MAX)
+        lo, hi = run.replica_checksum()
+        esz = 2 if run.dp.bucketer.wire is not None else 4
         wire = {"bytes_per_step": run.dp.bucketer.bytes_on_wire, "buckets": len(run.dp.bucketer.buckets),
-                "dtype": "bf16" if run.dp.bucketer.wire is not None else "fp32", "backend": backend, "comm_exposed_ms": float(ex)}
+                "bucket_bytes": [int((e - s) * esz) for s, e in run.dp.bucketer.buckets],
+                "dtype": "bf16" if run.dp.bucketer.wire is not None else "fp32", "backend": backend, "comm_exposed_ms": float(ex),
+                "comm_exposed_note": "time the compute stream waited for the communication stream after backward; only meaningful under the "
+                                     "RCCL backend (gloo blocks the host instead)",
+                # replicas must stay identical: every rank receives the same reduced buckets and applies the same fused update
+                "replica_param_checksum_min": lo, "replica_param_checksum_max": hi, "replicas_identical": lo == hi,
+                "nccl_env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE")
+                             if os.environ.get(k) is not None}}
+        if lo != hi:
+            log(f"REPLICAS DIVERGED: parameter checksum min {lo!r} max {hi!r} over {world} ranks")
 
     extras = {}
     if world == 1 and not use_dp and not args.no_extras and rank == 0:
         # the other single-GPU configurations, timed the same way (shorter): configs[2] and the reference's dropout recipe
+        # The blocks of the finished Run go back to the caching allocator and the next Run takes them from there: NO
+        # torch.cuda.empty_cache() in between.  Round 3 had one, and the driver's numbers for these keys were 12 - 38 % above the
+        # 200 / 30 runs: after the hipFree of ~3 GB every following configuration ran 6 - 10 steps at 2 - 2.5x the step time
+        # (Tensor.record_stream in the engine kept freed blocks unusable until an event poll; the pool had to regrow by hipMalloc)
+        # and, with that fixed, still showed one 10 - 20 ms stall a few steps in (tools/alloc_diag.py; absent when nothing was freed).
+        import gc
         del run
-        torch.cuda.empty_cache()
-        es, ew = max(10, min(args.steps, 50)), max(5, min(args.warmup, 15))
+        gc.collect()
+        es, ew = max(10, min(args.steps, 50)), max(10, min(args.warmup, 15))
         other = "joint" if config == "ctc" else "ctc"
         r2 = Run(args, other, args.dropout, rank, dev, False)
         d2 = r2.timed(ew, es)
         extras[f"{other}_ms_per_step"] = 1e3 * d2 / es
         extras[f"{other}_utterances_per_s"] = args.batch * es / d2
+        extras_alloc = {other: r2.alloc_growth}
         del r2
-        torch.cuda.empty_cache()
+        gc.collect()
         if args.dropout == 0.0:
             r3 = Run(args, config, 0.1, rank, dev, False)
             d3 = r3.timed(ew, es)
             extras["dropout_0.1_ms_per_step"] = 1e3 * d3 / es      # reference recipe: transformer_official.py:115-122
             extras["dropout_0.1_utterances_per_s"] = args.batch * es / d3
+            extras_alloc["dropout_0.1"] = r3.alloc_growth
             del r3
-            torch.cuda.empty_cache()
+            gc.collect()
         # BASELINE.json configs[4] per GPU: long-form utterances (T = 2000 frames, +-50-frame attention band, batch 8), joint model
         r4 = Run(args, "joint", args.dropout, rank, dev, False, batch=8, frames=2000, window=50)
         d4 = r4.timed(ew, es)
@@ -358,8 +407,11 @@ def main():
             ks = r4.kernel_pass(min(es, 5))
             extras["long_form_kernels"] = {k: {"avg_us": v["avg_us"], "launches_per_step": v["launches"] / min(es, 5)}
                                            for k, v in ks.items() if k in ("sdpa_fwd", "sdpa_bwd", "ctc", "gemm_nt", "gemm_tn")}
+        extras_alloc["long_form"] = r4.alloc_growth
         del r4
-        torch.cuda.empty_cache()
+        gc.collect()
+        extras["extras_protocol"] = f"{ew} warm-up + {es} timed steps each, caching allocator kept between configurations"
+        extras["allocator_growth_in_timed_regions"] = dict(extras_alloc, headline=alloc_growth)
         log(f"extras: {extras}")
 
     if rank == 0:
@@ -369,7 +421,7 @@ def main():
             "metric": "training throughput (utterances/s; frames/s = x T), AISHELL-1-shaped 80-mel T=500",
             "value": utt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic", "ranks_formed": world,
+            "dtype": "bf16", "data": "synthetic", "ranks_formed": world, "allocator_growth_in_timed_region": alloc_growth,
             "frames_per_s": utt * args.frames, "final_loss": loss,
             "config": {"workload": (("configs[3]: data-parallel " if world > 1 else "configs[2]: ") + "joint CTC/attention (lambda=0.3) encoder-decoder" if joint else
                                     "configs[1]: 6-layer Transformer encoder + CTC-only") +
@@ -387,7 +439,9 @@ def main():
             out["scaling_reference"] = {"n1_key": "joint_utterances_per_s", "workload": "joint CTC/attention model, same per-GPU batch"}
         out.update(extras)
         if summary:
-            out["library_gemm_calls_per_step"] = 0      # asserted by kernel_pass (torch.mm / addmm / matmul / bmm are counted there)
+            # counted by kernel_pass over its instrumented steps (torch.mm / addmm / matmul / bmm / baddbmm / einsum / F.linear / the @
+            # operator are wrapped there; a non-zero count ends the run): the value measured, not a literal
+            out["library_gemm_calls_per_step"] = lib_gemm_per_step
             fam = {k: v for k, v in summary.items() if k in ("gemm_nt", "gemm_tn")}
             dom = max(fam, key=lambda k: fam[k]["total_ms"]) if fam else None
             if dom:

@@ -475,3 +475,16 @@ def test_decoder_plan_struct_layout_matches_header(tmp_path):
         if line:
             n, off = line.split()
             assert getattr(DecLayerPlan, n).offset == int(off), n
+
+
+def test_library_refuses_runtime_settings_that_hang_the_step():
+    """ROC_SYSTEM_SCOPE_SIGNAL=0 stalls the cross-queue waits of the two-stream step silently (round 3: a run cut after 7 silent
+    minutes): the binding refuses to load under it, with the reason, instead of hanging later."""
+    from asr_chinese_e2e_amd import _lib
+    _lib._check_runtime_env({})
+    _lib._check_runtime_env({"ROC_SYSTEM_SCOPE_SIGNAL": "1"})
+    with pytest.raises(RuntimeError, match="ROC_SYSTEM_SCOPE_SIGNAL"):
+        _lib._check_runtime_env({"ROC_SYSTEM_SCOPE_SIGNAL": "0"})
+    env = dict(os.environ, ROC_SYSTEM_SCOPE_SIGNAL="0")
+    r = subprocess.run([sys.executable, "-c", "import asr_chinese_e2e_amd._lib"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "ROC_SYSTEM_SCOPE_SIGNAL" in r.stderr

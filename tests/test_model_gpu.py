@@ -943,6 +943,43 @@ def test_armed_hand_over_matches_event_fork(name, monkeypatch):
     assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
 
 
+@pytest.mark.parametrize("env", [dict(ASR_WGRAD_DEFER="w2"), dict(ASR_WGRAD_GROUP="block", ASR_FUSE_RELU_BWD="0"), dict(ASR_WGRAD_DEFER="w2,fc", ASR_FUSE_RELU_BWD="0")])
+def test_arm_does_not_outlive_its_producer(env, monkeypatch):
+    """Round-3 ADVICE: with a weight gradient held back (ASR_WGRAD_DEFER=w2 at B*T < 4096) or collected for a grouped launch
+    (ASR_WGRAD_GROUP=block with the ReLU backward as its own kernel) `_wgrad` returns without forking, and the arm set for the LayerNorm
+    backward used to survive until a later `_fork(side)` - which then skipped its event although other main-stream kernels had produced
+    the operand since: the weight-gradient stream read a dY ordered only behind the armed kernel.  The arm is now dropped wherever no
+    fork follows its producer: with the two streams live (NOT deterministic mode) the gradients of armed and event-record hand-overs
+    agree to the atomics' round-off over several steps."""
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, use_decoder=False, ctc_weight=1.0)
+    cfg, sd, batch = oracle_case(6, 400, 80, 56, 12, over, seed=23)      # 2400 rows: below the 4096-row limit of the own input-gradient kernel
+    pack = to_pack(batch)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ASR_ARMED_FORK", mode)
+        model = build(cfg, 56, "TransformerCTC", dtype="bf16").cuda()
+        model.load_state_dict(sd)
+        model.train()
+        eng = model._ensure_engine(DEV)
+        assert eng.armed_fork == (mode == "1") and eng.overlap_wgrad
+        for _ in range(4):      # a missing dependency shows as a race, not every time
+            model.zero_flat_grads()
+            loss, _ = model.train_step(pack)
+        torch.cuda.synchronize()
+        assert not eng._armed and not eng._keep      # nothing left armed or held after a finished step
+        res[mode] = (loss.clone(), model._flat.g.clone())
+    assert torch.isfinite(res["1"][0]).all() and torch.isfinite(res["1"][1]).all()
+    torch.testing.assert_close(res["1"][0], res["0"][0], rtol=1e-5, atol=1e-6)
+    f = model._flat
+    for name, (off, shape) in f.index.items():
+        n = int(np.prod(shape))
+        a, b = res["1"][1][off:off + n], res["0"][1][off:off + n]
+        gmax = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * gmax + 1e-9, (name, float((a - b).abs().max()), gmax)
+
+
 def test_relu_bit_mask_matches_activation_mask(monkeypatch):
     """ASR_RELU_BITS=1: the encoder's feed-forward blocks keep the ReLU mask as one bit per element (written by the w_1 GEMM, read by the
     w_2 input gradient) instead of re-reading the activations in the backward pass (the default): same loss and, in deterministic

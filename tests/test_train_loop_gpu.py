@@ -583,3 +583,50 @@ def test_graphed_step_matches_eager(mode):
         d = (p.detach() - q.detach()).abs()
         assert float(d.max()) <= 3 * 3 * o1._rate, (n, float(d.max()), o1._rate)
         assert float((d > 1e-6 + 1e-3 * q.detach().abs()).float().mean()) < 0.05, n
+
+
+@pytest.mark.gpu
+def test_graphed_shapes_keep_their_decoder_buffers():
+    """Round-3 ADVICE: the decoder sequencer's persistent buffers live in a least-recently-used cache of a few batch shapes, and a
+    captured hipGraph bakes their addresses into its kernel arguments - a shape a graph replays into must never be evicted.  Eight
+    joint batch shapes are captured (more than Engine.DEC_CACHE_SHAPES), eager evaluation batches of other shapes pass in between, then
+    the FIRST graph is replayed again: its buffers are still the cached ones and it follows the eager model."""
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+    from asr_chinese_e2e_amd.graph import GraphedModel
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+
+    def build():
+        torch.manual_seed(5)
+        M = Models.TransformerOffical
+        cfg = M.get_default_config()()
+        cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=1, dropout=0.0, ctc_weight=0.3, dtype="bf16"))
+        m = M(cfg, Vocab.synthetic(60)).cuda()
+        return m, NoamOpt(512, 1, 10, FusedAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+
+    packs = [synthetic_pack(3, 64, 80, 60, seed=20 + i, ragged=True, Lmin=2 + i, Lmax=2 + i, device="cuda", dtype=torch.bfloat16) for i in range(8)]
+    assert len({tuple(p.tgt_for_input.shape) for p in packs}) == 8
+    m1, o1 = build()
+    m2, o2 = build()
+    g = GraphedModel(m2)
+    eng = m2._ensure_engine(torch.device("cuda", torch.cuda.current_device()))
+    assert eng._dec_exec_ok(3, 4, 64)
+    for p in packs:
+        a, _ = m1.iterate(p, optimizer=o1)
+        b, _ = g.iterate(p, optimizer=o2)
+    first = eng._dec_cache[next(iter(eng._dec_cache))]
+    ptrs = [t["qkv_s"].data_ptr() for _, t in first["layers"]]
+    for i in range(8):      # eager shapes (drop flag differs in eval mode only when dropout > 0; here: other lengths)
+        extra = synthetic_pack(3, 64, 80, 60, seed=40 + i, ragged=True, Lmin=12 + i, Lmax=12 + i, device="cuda", dtype=torch.bfloat16)
+        m2.train_step(extra)
+    torch.cuda.synchronize()
+    assert len(g.graphs) == 8
+    pinned = [k for k, v in eng._dec_cache.items() if v["pinned"]]
+    assert len(pinned) == 8, (len(pinned), len(eng._dec_cache))
+    assert len(eng._dec_cache) <= 8 + eng.DEC_CACHE_SHAPES
+    assert [t["qkv_s"].data_ptr() for _, t in first["layers"]] == ptrs
+    # the eager detour above moved m2's gradients only (train_step has no optimizer): replaying the first shape follows the eager model
+    a, _ = m1.iterate(packs[0], optimizer=o1)
+    b, _ = g.iterate(packs[0], optimizer=o2)
+    torch.cuda.synchronize()
+    assert abs(float(a.loss) - float(b.loss)) < 2e-3 * abs(float(a.loss)), (float(a.loss), float(b.loss))
