@@ -226,10 +226,22 @@ class _SpeechTransformer(BaseModel):
             eng.step_seed = self._step_seed
         x = wave if wave.dtype == eng.dtype else wave.to(eng.dtype)
         x = x.contiguous()
-        wave_len = input.wave_len.to(torch.int32)
         tgt = input.tgt_for_input.contiguous()
-        prep = K.dec_preprocess(tgt, SOS_ID, EOS_ID)
+        # the batch contract hands lengths over as int64 (ai_shell_1.py:75-88): the label preprocessing launch also makes the int32 copies
+        lens64 = [t.contiguous() for t in (input.wave_len, input.tgt_len) if t is not None and t.dtype == torch.int64 and t.device == tgt.device]
+        out = K.dec_preprocess(tgt, SOS_ID, EOS_ID, lens64=lens64)
+        prep, lens32 = out[:6], (out[6] if lens64 else ())
+        wave_len = self._len32_of(input.wave_len, lens64, lens32)
+        self._tgt_len32 = self._len32_of(input.tgt_len, lens64, lens32) if input.tgt_len is not None else None
         return eng, x, wave_len, prep
+
+    @staticmethod
+    def _len32_of(t, lens64, lens32):
+        """int32 copy of a length vector: the one dec_preprocess made when the vector went through it, else a cast."""
+        for a, b in zip(lens64, lens32):
+            if a.data_ptr() == t.data_ptr() and a.numel() == t.numel():
+                return b
+        return t.to(torch.int32)
 
     def forward(self, input):
         """transformer_official.py:68-81 (inference-style forward; no gradients)."""
@@ -239,7 +251,7 @@ class _SpeechTransformer(BaseModel):
         pack = Pack()
         pack.add(encoder_out=enc.view(B, T, -1))
         if self.use_decoder:
-            cross_len = input.tgt_len.to(torch.int32) if self.cross_mask == "ref_compat" else wave_len
+            cross_len = self._tgt_len32 if self.cross_mask == "ref_compat" else wave_len
             pred, _ = eng.decoder_fwd(prep, enc, cross_len, B, T)
             pack.add(pred=pred.view(B, -1, self.V), gold=prep[1].long())
         if self.use_ctc:
@@ -341,9 +353,10 @@ class _SpeechTransformer(BaseModel):
         ctc_scale = dict(grad_scale=lam * loss_scale, grad_scale_div=batch_div) if batch_div is not None else dict(grad_scale=lam * loss_scale / float(B))
         ctc_async = (self.use_decoder and self.use_ctc and eng.overlap_ctc and not eng.deterministic and not torch.cuda.is_current_stream_capturing())
         if ctc_async:      # joint model: the CTC branch runs beside the decoder's forward pass
+            eng.decoder_kv_async(prep, enc, B, T)      # ... behind the K|V projections the decoder's first cross-attention waits for
             nll, d_enc, ctc_done = eng.ctc_branch_async(enc, wave_len, labels32, lab_len, B, T, **ctc_scale)
         if self.use_decoder:
-            cross_len = input.tgt_len.to(torch.int32) if self.cross_mask == "ref_compat" else wave_len
+            cross_len = self._tgt_len32 if self.cross_mask == "ref_compat" else wave_len
             pred, dcache = eng.decoder_fwd(prep, enc, cross_len, B, T)
             if self.cer_in_iterate:
                 pg = (pred.view(B, -1, self.V).argmax(-1), ys_out)

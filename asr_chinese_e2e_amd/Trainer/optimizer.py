@@ -101,8 +101,7 @@ class NoamOpt:
             self._pending_state = None
         g = self.optimizer.param_groups[0]
         b1, b2 = g["betas"]
-        K.grad_sumsq(flat.g, sumsq, ws)
-        K.noam_hyper(step, hyper, self.model_size, self.warmup, self.factor, 0.0, b1, b2)
+        K.grad_sumsq_noam(flat.g, sumsq, ws, step, hyper, self.model_size, self.warmup, self.factor, 0.0, b1, b2)      # squared norm + Noam rate: two launches
         K.adam_step(flat.p, flat.g, flat.m, flat.v, flat.lp, hyper, sumsq, max_norm, b1, b2, g["eps"], write_clipped=True)
         flat.version += 1               # the bf16 weights changed: transposed copies (engine.refresh_transposes) are stale
         self._step += 1                 # host mirror of the device counter (no sync)

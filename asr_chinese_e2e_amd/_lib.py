@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -58,7 +58,7 @@ class DecLayerPlan(ctypes.Structure):
                                   "dz_s", "g_as", "g_qkv", "dx_s",
                                   "dctx", "gb_2", "gb_fc_c", "gb_fc_s",
                                   "part_f", "part_c", "part_s", "delta")] +
-                [("delta_bytes", Z), ("d_enc", P), ("wgrad_stream", P)])
+                [("delta_bytes", Z), ("d_enc", P), ("wgrad_stream", P), ("aux_cus", I)])
 
 # name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
 SIGNATURES = {
@@ -93,7 +93,7 @@ SIGNATURES = {
     "asr_beam_step": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "asr_cache_gather": (I, [P, P, P, I, I, I, I, I, I, P]),
     "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),
-    "asr_dec_preprocess": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "asr_dec_preprocess": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "asr_embed_pe_fwd": (I, [P, P, P, P, F, I, I, I, I, F, U, I, P]),
     "asr_embed_bwd": (I, [P, P, P, F, I, I, I, F, U, I, P]),
     "asr_relu_fwd": (I, [P, Z, I, P]),
@@ -104,6 +104,7 @@ SIGNATURES = {
     "asr_sumsq_workspace_bytes": (Z, [Z]),
     "asr_grad_sumsq": (I, [P, Z, P, P, Z, P]),
     "asr_noam_hyper": (I, [P, P, F, F, F, F, F, F, P]),
+    "asr_grad_sumsq_noam": (I, [P, Z, P, P, Z, P, P, F, F, F, F, F, F, P]),
     "asr_adam_step": (I, [P, P, P, P, P, Z, P, P, F, F, F, F, I, P]),
     "asr_loss_combine": (I, [P, I, P, P, I, F, F, P, P]),
     "asr_gemm_nt_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),

@@ -99,7 +99,11 @@ extern "C" int asr_decoder_layer_bwd(const asr_dec_layer_plan* p, const void* dy
     if (kv_dgrad) {
         void* st2 = aux_stream ? aux_stream : stream;
         if (aux_stream && asr_stream_arm_pending()) DEC_TRY(asr_stream_fork(stream, aux_stream));      // the attention path taken had no armed launch
-        DEC_TRY(asr_gemm_nt_bf16(p->g_kvc, p->w_kv_c_T, nullptr, p->d_enc, p->d_enc, B * T, d, 2 * hd, 2 * hd, p->ld_kv_c_T, d, ASR_ACT_NONE, st2));
+        // a (B*T)-row GEMM beside the chain of small kernels: sized for p->aux_cus CUs when the caller reserves the rest for the chain
+        const int old_lim = p->aux_cus > 0 ? asr_option_set(ASR_OPT_CU_LIMIT, p->aux_cus) : 0;
+        const int rc_kv = asr_gemm_nt_bf16(p->g_kvc, p->w_kv_c_T, nullptr, p->d_enc, p->d_enc, B * T, d, 2 * hd, 2 * hd, p->ld_kv_c_T, d, ASR_ACT_NONE, st2);
+        if (p->aux_cus > 0) asr_option_set(ASR_OPT_CU_LIMIT, old_lim);
+        DEC_TRY(rc_kv);
     }
     DEC_TRY(asr_gemm_small_bf16(p->g_qc, p->w_q_c, nullptr, nullptr, p->dx_c, M, d, hd, hd, d, d, 1, ASR_ACT_NONE, stream));
     // ---- self-attention block

@@ -304,7 +304,8 @@ static int cu_count() {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     }
-    return n;
+    const int lim = asr_option(ASR_OPT_CU_LIMIT);
+    return lim > 0 && lim < n ? (lim < 8 ? 8 : lim) : n;
 }
 
 template <int ACT, int BM_, int RING_, int DBG>

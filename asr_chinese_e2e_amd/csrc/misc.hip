@@ -37,12 +37,12 @@ extern "C" int asr_set_deterministic(int on) {
 // ---- tuning options: process-wide integer switches that select between CORRECT variants of a kernel (store policy, tile shape ...),
 // settable at run time so that two variants can be timed alternately inside one process (box-to-box noise is ~2 %).
 // Initial value: environment variable ASR_OPT_<NAME upper case>, else the built-in default.
-static const char* const g_opt_names[ASR_OPT_COUNT] = {"nt_store", "nt_tile", "tn_split", "sdpa_store", "tn_cfg", "spare"};
+static const char* const g_opt_names[ASR_OPT_COUNT] = {"nt_store", "nt_tile", "tn_split", "sdpa_store", "tn_cfg", "spare", "cu_limit"};
 static int g_opt_val[ASR_OPT_COUNT];
 static bool g_opt_init = false;
 static void opt_init() {
     if (g_opt_init) return;
-    static const int defaults[ASR_OPT_COUNT] = {ASR_OPT_NT_STORE_DEFAULT, 0, 0, 0, 0, 0};
+    static const int defaults[ASR_OPT_COUNT] = {ASR_OPT_NT_STORE_DEFAULT, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < ASR_OPT_COUNT; ++i) {
         char env[64] = "ASR_OPT_";
         size_t k = strlen(env);
@@ -56,6 +56,13 @@ static void opt_init() {
 int asr_option(int key) {
     opt_init();
     return (key >= 0 && key < ASR_OPT_COUNT) ? g_opt_val[key] : 0;
+}
+int asr_option_set(int key, int value) {
+    opt_init();
+    if (key < 0 || key >= ASR_OPT_COUNT) return 0;
+    const int old = g_opt_val[key];
+    g_opt_val[key] = value;
+    return old;
 }
 extern "C" int asr_set_option(const char* name, int value, int* previous) {
     opt_init();
@@ -262,12 +269,17 @@ static int cs_row_slots(int rows, int cols) {
 // ---- decoder target preparation --------------------------------------------------------------
 __global__ void dec_preprocess_kernel(const int64_t* __restrict__ tgt, int32_t* ys_in, int32_t* ys_out,
                                       int32_t* labels32, int32_t* dec_len, int32_t* lab_len, float* n_valid,
-                                      int B, int Lmax, int sos, int eos) {
+                                      int B, int Lmax, int sos, int eos, const int64_t* __restrict__ len_a, int32_t* len32_a,
+                                      const int64_t* __restrict__ len_b, int32_t* len32_b) {
     // one thread per utterance (B is small, rows are short); thread 0 also sums n_valid
     __shared__ int cnt[1024];
     const int b = threadIdx.x;
     int n = 0;
     if (b < B) {
+        // the batch's int64 length vectors (wave_len, tgt_len of the reference's batch contract) as the int32 the kernels take: two
+        // elementwise launches of ~6 us each in front of every step otherwise
+        if (len_a) len32_a[b] = (int32_t)len_a[b];
+        if (len_b) len32_b[b] = (int32_t)len_b[b];
         const int To = Lmax + 1;
         int32_t* yi = ys_in + (size_t)b * To;
         int32_t* yo = ys_out + (size_t)b * To;
@@ -376,13 +388,7 @@ __global__ __launch_bounds__(256) void sum_finalize_kernel(const float* __restri
     s = block_sum(s, red);
     if (threadIdx.x == 0) *out = s;
 }
-static int ss_grid(size_t n) {
-    size_t g = (n / 4 + SS_BLOCK - 1) / SS_BLOCK;
-    return (int)(g < 1024 ? (g ? g : 1) : 1024);
-}
-
-__global__ void noam_hyper_kernel(int32_t* step, float* hyper, float model_size, float warmup, float factor,
-                                  float lr_const, float b1, float b2) {
+__device__ __forceinline__ void noam_update(int32_t* step, float* hyper, float model_size, float warmup, float factor, float lr_const, float b1, float b2) {
     const int s = *step + 1;
     *step = s;
     const double sd = (double)s;
@@ -395,6 +401,27 @@ __global__ void noam_hyper_kernel(int32_t* step, float* hyper, float model_size,
     hyper[1] = (float)(1.0 - pow((double)b1, sd));
     hyper[2] = (float)sqrt(1.0 - pow((double)b2, sd));
     hyper[3] = (float)s;
+}
+// the finalizer of the squared gradient norm also advances the Noam schedule (asr_grad_sumsq_noam): one launch less between backward and Adam
+__global__ __launch_bounds__(256) void sum_finalize_noam_kernel(const float* __restrict__ part, int P, float* out, int32_t* step, float* hyper, float model_size,
+                                                                float warmup, float factor, float lr_const, float b1, float b2) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < P; i += 256) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        *out = s;
+        noam_update(step, hyper, model_size, warmup, factor, lr_const, b1, b2);
+    }
+}
+static int ss_grid(size_t n) {
+    size_t g = (n / 4 + SS_BLOCK - 1) / SS_BLOCK;
+    return (int)(g < 1024 ? (g ? g : 1) : 1024);
+}
+
+__global__ void noam_hyper_kernel(int32_t* step, float* hyper, float model_size, float warmup, float factor,
+                                  float lr_const, float b1, float b2) {
+    noam_update(step, hyper, model_size, warmup, factor, lr_const, b1, b2);
 }
 
 __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -545,11 +572,13 @@ extern "C" int asr_relu_bwd(void* da, const void* a, float* dbias, void* ws, siz
 }
 
 extern "C" int asr_dec_preprocess(const int64_t* tgt, int32_t* ys_in, int32_t* ys_out, int32_t* labels32, int32_t* dec_len,
-                                  int32_t* lab_len, float* n_valid, int B, int Lmax, int sos, int eos, void* stream) {
+                                  int32_t* lab_len, float* n_valid, int B, int Lmax, int sos, int eos, const int64_t* len_a, int32_t* len32_a,
+                                  const int64_t* len_b, int32_t* len32_b, void* stream) {
     if (!tgt || !ys_in || !ys_out || !labels32 || !dec_len || !lab_len || !n_valid) ASR_FAIL(ASR_EINVAL, "asr_dec_preprocess: null pointer");
+    if ((len_a && !len32_a) || (len_b && !len32_b)) ASR_FAIL(ASR_EINVAL, "asr_dec_preprocess: a length vector without its int32 output");
     if (B <= 0 || B > 1024 || Lmax <= 0) ASR_FAIL(ASR_EINVAL, "asr_dec_preprocess: bad shape B=%d Lmax=%d (B <= 1024)", B, Lmax);
     const int threads = ceil_div(B, 64) * 64;
-    dec_preprocess_kernel<<<1, threads, 0, (hipStream_t)stream>>>(tgt, ys_in, ys_out, labels32, dec_len, lab_len, n_valid, B, Lmax, sos, eos);
+    dec_preprocess_kernel<<<1, threads, 0, (hipStream_t)stream>>>(tgt, ys_in, ys_out, labels32, dec_len, lab_len, n_valid, B, Lmax, sos, eos, len_a, len32_a, len_b, len32_b);
     ASR_CHECK_LAUNCH("asr_dec_preprocess");
     return ASR_OK;
 }
@@ -615,6 +644,19 @@ extern "C" int asr_grad_sumsq(const float* g, size_t n, float* sumsq, void* ws, 
     sumsq_partial_kernel<<<grid, SS_BLOCK, 0, st>>>(g, n / 4, n, (float*)ws);
     sum_finalize_kernel<<<1, 256, 0, st>>>((const float*)ws, grid, sumsq);
     ASR_CHECK_LAUNCH("asr_grad_sumsq");
+    return ASR_OK;
+}
+
+extern "C" int asr_grad_sumsq_noam(const float* g, size_t n, float* sumsq, void* ws, size_t ws_bytes, int32_t* step, float* hyper, float model_size,
+                                   float warmup, float factor, float lr_const, float b1, float b2, void* stream) {
+    if (!g || !sumsq || !ws || !step || !hyper) ASR_FAIL(ASR_EINVAL, "asr_grad_sumsq_noam: null pointer");
+    if (ws_bytes < asr_sumsq_workspace_bytes(n)) ASR_FAIL(ASR_EWORKSPACE, "asr_grad_sumsq_noam: workspace too small");
+    if (((uintptr_t)g) % 16) ASR_FAIL(ASR_EINVAL, "asr_grad_sumsq_noam: g must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ss_grid(n);
+    sumsq_partial_kernel<<<grid, SS_BLOCK, 0, st>>>(g, n / 4, n, (float*)ws);
+    sum_finalize_noam_kernel<<<1, 256, 0, st>>>((const float*)ws, grid, sumsq, step, hyper, model_size, warmup, factor, lr_const, b1, b2);
+    ASR_CHECK_LAUNCH("asr_grad_sumsq_noam");
     return ASR_OK;
 }
 

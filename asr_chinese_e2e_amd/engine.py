@@ -399,6 +399,18 @@ class Engine:
         # four short ones spread over the layer: step 3.84 (layer) / 3.96 (block) vs 3.79 ms, joint 6.27 vs 6.16.
         self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "decoder")
         self.group_wgrad = None if (self.group_wgrad == "0" or self.deterministic) else self.group_wgrad
+        # The decoder of the joint model is a chain of ~25 small kernels per layer and direction on B*To ~ 550 rows whose workgroups need whole
+        # CUs (the small-M GEMM holds 132 - 141 KiB of LDS, attention K / V images 128 KiB); the large launches that run BESIDE the chain on the
+        # auxiliary / weight-gradient streams (CTC branch, cross-attention K|V projections and their input gradients, the layer's grouped
+        # weight gradients) are one-workgroup-per-CU kernels that hold every CU for 25 - 110 us: a chain kernel launched meanwhile waits
+        # for one of them to END (kernel trace, round 4: the 10-us w_1 input gradient took 42 - 50 us beside the grouped weight gradients).
+        # ASR_DEC_CU_LIMIT = n > 0 (default 192) sizes those large launches for n CUs (tuning option "cu_limit"), which leaves 256 - n CUs to
+        # the chain: joint step 5.01 -> 4.94 ms, and 4.82 with the K|V projections queued ahead of the CTC branch (A/B in one process; 144 .. 224
+        # within 1 % of each other; 0 = the whole device).  The head's weight gradient queued BEHIND its input gradient on the auxiliary stream
+        # instead of beside it on the weight-gradient stream: 4.880 vs 4.853 ms - not kept.
+        self.dec_cu_limit = int(os.environ.get("ASR_DEC_CU_LIMIT", "192"))
+        self.kv_first = os.environ.get("ASR_KV_FIRST", "1") == "1"      # cross-attention K|V projections ahead of the CTC branch (decoder_kv_async)
+        self._kv_ahead = None
         self._pending = []
         self._deferred = []
         # Operands of kernels issued on the weight-gradient / auxiliary streams are kept alive HERE until the step has joined those
@@ -584,10 +596,15 @@ class Engine:
             return
         self._fork(self.side)
         K.STREAM_OVERRIDE = self._side_handle
+        lim = self.dec_cu_limit if self._in_decoder else 0
         try:
+            if lim:
+                K.set_cu_limit(lim)
             K.gemm_tn_grouped(probs, accumulate=True)
         finally:
             K.STREAM_OVERRIDE = None
+            if lim:
+                K.set_cu_limit(0)
         # also while capturing: a graph's private pool DOES reuse a block freed earlier in the same capture, and without the mark a
         # replay overwrote dY / X tensors that the side stream's weight-gradient kernel had not read yet (round 3: gradients of the
         # replayed step differed from the eager step; tests/test_train_loop_gpu.py::test_graphed_step_matches_eager)
@@ -840,7 +857,13 @@ class Engine:
         main = torch.cuda.current_stream()
         self._fork(self.ctc_stream)
         with torch.cuda.stream(self.ctc_stream):
-            nll, d_enc = self.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale, grad_scale_div=grad_scale_div, ws=self.ws_ctc)
+            if self.dec_cu_limit:      # beside the decoder's forward chain: leave it some CUs (see self.dec_cu_limit)
+                K.set_cu_limit(self.dec_cu_limit)
+            try:
+                nll, d_enc = self.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, grad_scale, grad_scale_div=grad_scale_div, ws=self.ws_ctc)
+            finally:
+                if self.dec_cu_limit:
+                    K.set_cu_limit(0)
             done = torch.cuda.Event()
             done.record(self.ctc_stream)
         # inputs read on the auxiliary stream, and the two results (blocks of that stream's pool, read on the main stream): alive until
@@ -933,19 +956,44 @@ class Engine:
         hit = self._dec_cache[key] = dict(layers=layers, delta=delta, pinned=capturing)
         return hit
 
+    def _kv_exec_async(self, bufs, enc):
+        """The six cross-attention K|V projections of the encoder output (16000-row GEMMs, ~24 us each) on the auxiliary stream, one event
+        each: they do not depend on the decoder state, and the main stream works through the decoder's small kernels meanwhile."""
+        self._fork(self.ctc_stream)
+        with torch.cuda.stream(self.ctc_stream):
+            if self.dec_cu_limit:
+                K.set_cu_limit(self.dec_cu_limit)
+            try:
+                for (pl, t), (_, cross, _) in zip(bufs["layers"], self.dec):
+                    cross.kv.fwd(enc, out=t["kv_c"])
+                    t["kv_event"].record(self.ctc_stream)
+                    pl.kv_ready_event = t["kv_event"].cuda_event
+            finally:
+                if self.dec_cu_limit:
+                    K.set_cu_limit(0)
+        self._keep.append(enc)
+
+    def decoder_kv_async(self, prep, enc, B, T):
+        """Called by the training step BEFORE ctc_branch_async: queues the K|V projections on the auxiliary stream AHEAD of the CTC branch.
+        Issued from decoder_fwd they sat behind the whole branch (head GEMM, loss kernels, its input gradient: ~0.3 ms), and the
+        decoder's first cross-attention - ~80 us into the chain - waited for layer 0's projection at the end of that queue (kernel
+        trace, round 4: the chain stood still for ~240 us).  The CTC results are needed only when the decoder's backward pass starts."""
+        self._kv_ahead = None
+        To = prep[0].shape[1]
+        if not (self.aux_overlap and self.kv_first and not torch.cuda.is_current_stream_capturing() and self._dec_exec_ok(B, To, T)):
+            return
+        bufs = self._dec_bufs(B, To, T, self.training and self.drop_p > 0.0)
+        self._kv_exec_async(bufs, enc)
+        self._kv_ahead = (bufs, enc)
+
     def _dec_exec_fwd(self, x, enc, dec_len, cross_len, B, To, T):
         drop = self.training and self.drop_p > 0.0
         bufs = self._dec_bufs(B, To, T, drop)
         main = K._stream()
         overlap = self.aux_overlap and not torch.cuda.is_current_stream_capturing()
-        if overlap:      # the six K|V projections of the encoder output on the auxiliary stream, one event each (see decoder_fwd)
-            self._fork(self.ctc_stream)
-            with torch.cuda.stream(self.ctc_stream):
-                for (pl, t), (_, cross, _) in zip(bufs["layers"], self.dec):
-                    cross.kv.fwd(enc, out=t["kv_c"])
-                    t["kv_event"].record(self.ctc_stream)
-                    pl.kv_ready_event = t["kv_event"].cuda_event
-            self._keep.append(enc)
+        ahead, self._kv_ahead = self._kv_ahead, None
+        if overlap and not (ahead is not None and ahead[0] is bufs and ahead[1] is enc):      # not issued ahead of the CTC branch (decoder_kv_async)
+            self._kv_exec_async(bufs, enc)
         for i, ((pl, t), (_, cross, _)) in enumerate(zip(bufs["layers"], self.dec)):
             if not overlap:
                 cross.kv.fwd(enc, out=t["kv_c"])
@@ -977,6 +1025,7 @@ class Engine:
             pl.d_enc = d_enc.data_ptr() if cross.kv.wlpT is not None else None
             hand_over = self.armed_fork and self.overlap_wgrad and not torch.cuda.is_current_stream_capturing()
             pl.wgrad_stream = self._side_handle if hand_over else None      # the layer's last kernel signals the weight-gradient stream itself
+            pl.aux_cus = self.dec_cu_limit if aux is not None else 0
             _lib.check(_lib.fast.asr_decoder_layer_bwd(ctypes.addressof(pl), dy.data_ptr(), None if dy2 is None else dy2.data_ptr(), main, aux),
                        "asr_decoder_layer_bwd")
             self._armed = self._arm_covers_pending = hand_over      # consumed (or found pending) by the next _fork(self.side): flush_wgrads in _ready

@@ -416,11 +416,17 @@ def loss_combine(row_nll, n_valid, nll, w_ce, w_ctc, out=None):
 
 
 # --------------------------------------------------------------------------------- decoder glue
-def dec_preprocess(tgt, sos=2, eos=3):
-    """tgt (B, Lmax) int64 zero-padded -> ys_in, ys_out (B, Lmax+1) int32, labels32, dec_len, lab_len, n_valid."""
+def dec_preprocess(tgt, sos=2, eos=3, lens64=()):
+    """tgt (B, Lmax) int64 zero-padded -> ys_in, ys_out (B, Lmax+1) int32, labels32, dec_len, lab_len, n_valid.
+    lens64: up to two (B,) int64 length vectors of the batch (wave_len, tgt_len); their int32 copies are made by the same launch and
+    returned as a 7th element (a tuple)."""
     assert tgt.dtype == torch.int64 and tgt.is_contiguous() and tgt.dim() == 2
     B, Lmax = tgt.shape
     dev = tgt.device
+    lens64 = tuple(lens64)
+    assert len(lens64) <= 2 and all(t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B and t.device == dev for t in lens64)
+    lens32 = tuple(torch.empty(B, dtype=torch.int32, device=dev) for _ in lens64)
+    la, lb = (list(zip(lens64, lens32)) + [(None, None), (None, None)])[:2]
     ys_in = torch.empty(B, Lmax + 1, dtype=torch.int32, device=dev)
     ys_out = torch.empty(B, Lmax + 1, dtype=torch.int32, device=dev)
     labels32 = torch.empty(B, Lmax, dtype=torch.int32, device=dev)
@@ -428,7 +434,9 @@ def dec_preprocess(tgt, sos=2, eos=3):
     lab_len = torch.empty(B, dtype=torch.int32, device=dev)
     n_valid = torch.empty(1, dtype=torch.float32, device=dev)
     check(lib.asr_dec_preprocess(_p(tgt), _p(ys_in), _p(ys_out), _p(labels32), _p(dec_len), _p(lab_len), _p(n_valid),
-                                 B, Lmax, sos, eos, _stream()), "asr_dec_preprocess")
+                                 B, Lmax, sos, eos, _p(la[0]), _p(la[1]), _p(lb[0]), _p(lb[1]), _stream()), "asr_dec_preprocess")
+    if lens64:
+        return ys_in, ys_out, labels32, dec_len, lab_len, n_valid, lens32
     return ys_in, ys_out, labels32, dec_len, lab_len, n_valid
 
 
@@ -507,6 +515,18 @@ def grad_sumsq(g, out, ws):
     return out
 
 
+def grad_sumsq_noam(g, out, ws, step, hyper, model_size, warmup, factor, lr_const, b1, b2):
+    """grad_sumsq + noam_hyper with the schedule update inside the norm's finalizer (asr_grad_sumsq_noam)."""
+    _chk_f32(g, out, hyper)
+    _chk_i32(step)
+    assert hyper.numel() >= 4
+    w = ws.get(lib.asr_sumsq_workspace_bytes(g.numel()))
+    timed("grad_sumsq", 0.0, lambda: check(lib.asr_grad_sumsq_noam(_p(g), g.numel(), _p(out), _p(w), w.numel(), _p(step), _p(hyper), float(model_size),
+                                                                   float(warmup), float(factor), float(lr_const), float(b1), float(b2), _stream()),
+                                           "asr_grad_sumsq_noam"), 4.0 * g.numel())
+    return out
+
+
 def noam_hyper(step, hyper, model_size, warmup, factor, lr_const, b1, b2):
     _chk_i32(step)
     _chk_f32(hyper)
@@ -582,6 +602,15 @@ def set_option(name, value):
     prev = ctypes.c_int(0)
     check(_lib.lib.asr_set_option(name.encode(), int(value), ctypes.byref(prev)), "asr_set_option")
     return prev.value
+
+
+_CU_LIMIT_NAME = ctypes.create_string_buffer(b"cu_limit")
+
+
+def set_cu_limit(n):
+    """Tuning option "cu_limit" on the launch path (no ctypes foreign call): the one-workgroup-per-CU kernels launched from now on are sized
+    for n CUs (0 = the whole device).  The engine brackets the large launches that run beside the decoder's small kernels with it."""
+    check(lib.asr_set_option(ctypes.addressof(_CU_LIMIT_NAME), int(n), None), "asr_set_option")
 
 
 def deterministic():

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 7
+#define ASR_ABI_VERSION 8
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -80,7 +80,7 @@ int asr_stream_create(int priority, void** out_stream);
 /* Tuning options: process-wide integer switches between CORRECT variants of a kernel (every value gives correct results), settable at
  * run time so that two variants can be timed alternately inside one process.  Names: "nt_store" (store policy of the NT GEMM's output tile:
  * 0 nt, 1 sc1 write-through, 2 plain, 3 sc0 sc1), "nt_tile" (0: 256 x 128 tiles with loader / consumer waves, 1: 256 x 128 with every wave loading and computing, 2: 256 x 256 wherever the shape allows, 3: by shape), "tn_cfg" (weight-gradient kernel: 0 four waves with staggered M-splits, 1 loader / consumer waves, 3 equal M-splits), "spare" (spread of the
- * staggered splits in percent of their mean length), "tn_split" (M-splits of the weight-gradient kernel in percent of the plan's), "sdpa_store" (reserved).  Initial values: ASR_OPT_<NAME>
+ * staggered splits in percent of their mean length), "tn_split" (M-splits of the weight-gradient kernel in percent of the plan's), "sdpa_store" (reserved), "cu_limit" (> 0: the one-workgroup-per-CU kernels - persistent NT GEMM, weight-gradient M-splits - size their launches for this many CUs instead of the device's; the engine sets it around the large launches that run beside the decoder's small kernels).  Initial values: ASR_OPT_<NAME>
  * in the environment, else the defaults.  previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
 int asr_set_option(const char* name, int value, int* previous);
 int asr_get_deterministic(void);
@@ -305,10 +305,12 @@ int asr_xent_fwd_bwd(const void* logits, const int32_t* gold, const float* n_val
  * dec_len[b] = 1 + #nonzero(tgt[b]) (rows of ys_in that are not eos padding),
  * lab_len[b] = #nonzero(tgt[b]), labels32 = compacted labels (B, Lmax) int32 (for CTC),
  * *n_valid = number of non-zero entries of ys_out (f32).
+ * len_a / len_b (ABI 8, each may be NULL): (B) int64 length vectors of the batch contract (wave_len, tgt_len: collat.__call__
+ * ai_shell_1.py:75-88 hands them over as int64) copied to len32_a / len32_b as the int32 the kernels take, in the same launch.
  */
 int asr_dec_preprocess(const int64_t* tgt, int32_t* ys_in, int32_t* ys_out, int32_t* labels32,
-                       int32_t* dec_len, int32_t* lab_len, float* n_valid, int B, int Lmax,
-                       int sos, int eos, void* stream);
+                       int32_t* dec_len, int32_t* lab_len, float* n_valid, int B, int Lmax, int sos, int eos,
+                       const int64_t* len_a, int32_t* len32_a, const int64_t* len_b, int32_t* len32_b, void* stream);
 
 /* Embedding gather * scale + positional encoding.
  * Replaces:  tgt_word_emb(ys_in) * x_logit_scale + positional_encoding
@@ -362,6 +364,10 @@ size_t asr_sumsq_workspace_bytes(size_t n);
 int asr_grad_sumsq(const float* g, size_t n, float* sumsq, void* ws, size_t ws_bytes, void* stream);
 int asr_noam_hyper(int32_t* step, float* hyper, float model_size, float warmup, float factor,
                    float lr_const, float b1, float b2, void* stream);
+/* asr_grad_sumsq followed by asr_noam_hyper in two launches instead of three (ABI 8): the single-workgroup finalizer of the squared norm
+ * also advances the device-side step counter and writes the step's hyper-parameters. */
+int asr_grad_sumsq_noam(const float* g, size_t n, float* sumsq, void* ws, size_t ws_bytes, int32_t* step, float* hyper, float model_size,
+                        float warmup, float factor, float lr_const, float b1, float b2, void* stream);
 int asr_adam_step(float* p, float* g, float* m, float* v, void* p_lp, size_t n,
                   const float* hyper, const float* sumsq, float max_norm, float b1, float b2,
                   float eps, int write_clipped, void* stream);
@@ -489,6 +495,9 @@ typedef struct asr_dec_layer_plan {
     void* wgrad_stream;                    /* backward (ABI 7): stream that will run the layer's weight gradients, or NULL.  The LAST kernel of
                                               asr_decoder_layer_bwd then hands over to it by its own completion event (asr_stream_arm): check
                                               asr_stream_arm_pending() afterwards and fall back to asr_stream_fork when it returns 1 */
+    int aux_cus;                           /* backward (ABI 8): > 0 = the (B*T)-row GEMM d_enc += g_kvc W_kv that the layer puts on aux_stream is
+                                              sized for this many CUs (tuning option "cu_limit" around that one launch), so that the rest stay free
+                                              for the layer's own chain of small kernels; 0 = the whole device */
 } asr_dec_layer_plan;
 int asr_decoder_layer_fwd(const asr_dec_layer_plan* plan, void* stream);
 /* (dy, dy2): gradient wrt y_f (dy2 may be NULL; the two are added).  Results: plan->dx_s and plan->dz_s = gradient wrt x_in through the
