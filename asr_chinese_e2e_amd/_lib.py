@@ -76,8 +76,6 @@ SIGNATURES = {
     "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, F, U, I, I, P]),
     "asr_add_ln_bwd_reduce_batched": (I, [P, I, I, P]),
     "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
-    "asr_sdpa_drop_bits_bytes": (Z, [I, I, I, I, I, I]),
-    "asr_sdpa_drop_bits": (I, [P, Z]),
     "asr_sdpa_bwd_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),
     "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, Z, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
     "asr_dropout_mask": (I, [P, I, I, F, U, P]),
@@ -108,11 +106,8 @@ SIGNATURES = {
     "asr_adam_step": (I, [P, P, P, P, P, Z, P, P, F, F, F, F, I, P]),
     "asr_loss_combine": (I, [P, I, P, P, I, F, F, P, P]),
     "asr_gemm_nt_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
-    "asr_gemm_nt_relu_bits_bytes": (Z, [I, I, I]),
-    "asr_gemm_nt_relu_bits_bf16": (I, [P, P, P, P, Z, P, I, I, I, I, I, I, I, P]),
     "asr_gemm_small_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "asr_gemm_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
-    "asr_gemm_nt_add_ln_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "asr_decoder_layer_fwd": (I, [P, P]),
     "asr_decoder_layer_bwd": (I, [P, P, P, P, P]),
     "asr_gemm_tn_workspace_bytes": (Z, [I, I, I]),

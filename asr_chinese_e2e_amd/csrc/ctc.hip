@@ -542,98 +542,6 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     }
 }
 
-// bf16 fast path of kernel 3: ONE WAVE per frame, the row in registers, no LDS and no workgroup
-// barrier.  The posterior mass of the (at most L + 1) classes that occur in the label sequence is
-// subtracted by overwriting those few elements after the row has been stored.
-template <int NV>
-__global__ __launch_bounds__(256) void ctc_grad_rows_kernel(const bf16_t* __restrict__ logits, bf16_t* __restrict__ dlogits, const double* __restrict__ lp,
-                                                            const double* __restrict__ alpha, const double* __restrict__ beta,
-                                                            const float* __restrict__ lse_in, const int32_t* __restrict__ in_len,
-                                                            const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
-                                                            const float* __restrict__ nll_raw, int B, int T_, int V, int ld, int Lmax, int W, int blank,
-                                                            float scale_in, const float* __restrict__ scale_div) {
-    const float scale = scale_div ? scale_in / *scale_div : scale_in;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int rows = B * T_, nvec = V >> 3;
-    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
-        const int b = row / T_, t = row - b * T_;
-        bf16_t* dl = dlogits + (size_t)row * ld;
-        // padded frame, or infeasible utterance (nll = +inf): zero gradient
-        if (t >= in_len[b] || nll_raw[b] == INFINITY) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            for (int i = lane; i < nvec; i += 64) *(u32x4*)(dl + (size_t)i * 8) = z;
-            continue;
-        }
-        const bf16_t* x = logits + (size_t)row * ld;
-        u32x4 xv[NV];
-        wave_row_load<NV>(x, nvec, lane, xv);
-        const int L = lab_len[b];
-        const float lse = lse_in[row];
-        // posterior of a state at this frame, up to a per-frame constant: alpha * beta / y (both
-        // recursions include y_t).  sum_s alpha_t(s) beta_t(s) / y_t(l'_s) = p(l|x) for EVERY t, so
-        // normalising over s is exact and needs neither nll nor the scale factors.
-        const size_t o = (size_t)row * 2 * W;
-        double pb = 0.0, pl[4], yl[4];
-        int lab[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = lane + 64 * j;
-            pl[j] = 0.0;
-            yl[j] = 0.0;
-            lab[j] = -1;
-            if (i <= L && i < W) {
-                const double yb = lp[o + i];
-                pb += yb > 0.0 ? alpha[o + i] * beta[o + i] / yb : 0.0;
-                if (i < L) {
-                    yl[j] = lp[o + W + i];
-                    pl[j] = yl[j] > 0.0 ? alpha[o + W + i] * beta[o + W + i] / yl[j] : 0.0;
-                    lab[j] = labels[(size_t)b * Lmax + i];
-                }
-            }
-        }
-        double sum = pb + pl[0] + pl[1] + pl[2] + pl[3];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            sum += __shfl_xor(sum, off, 64);
-            pb += __shfl_xor(pb, off, 64);
-        }
-        const double inv = sum > 0.0 ? 1.0 / sum : 0.0;
-        // the row: scale * softmax
-        const float lb = lse * LOG2E;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int i = lane + 64 * k;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[2 * j] = scale * __builtin_amdgcn_exp2f(fmaf(bf16_lo(xv[k][j]), LOG2E, -lb));
-                v[2 * j + 1] = scale * __builtin_amdgcn_exp2f(fmaf(bf16_hi(xv[k][j]), LOG2E, -lb));
-            }
-            if (i < nvec) store8<bf16_t>(dl + (size_t)i * 8, v);
-        }
-        // occupancy of each label's class = sum over the positions that carry the same label
-        float occ[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            if (64 * jj >= L) break;
-            const int cnt = min(64, L - 64 * jj);
-            const float pj_all = (float)(pl[jj] * inv);
-            for (int q = 0; q < cnt; ++q) {
-                const int lq = __shfl(lab[jj], q, 64);
-                const float pq = __shfl(pj_all, q, 64);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) occ[j] += (lab[j] == lq) ? pq : 0.f;
-            }
-        }
-        // the row's stores must have reached L2 before the same wave overwrites some of its elements
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) dl[blank] = (bf16_t)(scale * ((float)lp[o] - (float)(pb * inv)));   // every blank state has the same y
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (lab[j] >= 0) dl[lab[j]] = (bf16_t)(scale * ((float)yl[j] - occ[j]));       // positions with equal labels write equal values
-    }
-}
-
 // Second half of the split gradient: the row already holds scale * softmax (ctc_lse_gather_rows_kernel<.., true>);
 // one wave per frame subtracts the posterior mass of the classes that occur in the label sequence by
 // overwriting those few elements, and zeroes the rows of infeasible utterances (nll = +inf).
@@ -655,7 +563,7 @@ __global__ __launch_bounds__(256) void ctc_label_fix_kernel(bf16_t* __restrict__
         }
         const int L = lab_len[b];
         // posterior of a state at this frame, up to a per-frame constant: alpha * beta / y; normalising over the
-        // states is exact (see ctc_grad_rows_kernel)
+        // states is exact (see ctc_grad_kernel: the sum over s of alpha beta / y is p(l | x) at EVERY t, so it needs neither nll nor the scale factors)
         const size_t o = (size_t)row * 2 * W;
         double pb = 0.0, pl[4], yl[4];
         int lab[4];
@@ -814,7 +722,6 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     if (g1 > 4096) g1 = 4096;
     // bf16 rows of whole 16-byte vectors that fit a wave's registers take the row-in-registers kernels
     const int need = ceil_div(V / 8, 64);
-    static const int ctc_split = getenv("ASR_CTC_SPLIT") ? atoi(getenv("ASR_CTC_SPLIT")) : 1;
     const bool rows_path = dtype == ASR_BF16 && V % 8 == 0 && ld % 8 == 0 && need <= 16 && ((uintptr_t)logits % 16) == 0 && (!dlogits || ((uintptr_t)dlogits % 16) == 0);
 #define ROWS_DISPATCH(CALL)           \
     do {                              \
@@ -826,9 +733,9 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
         else { CALL(16); }            \
     } while (0)
     if (rows_path) {
-        // with a gradient: the softmax part of it is written by the same wave that reduces the row (one pass over
-        // the logits less); ASR_CTC_SPLIT=0 keeps the separate gradient kernel (A/B runs)
-        if (dlogits && ctc_split) {
+        // with a gradient: the softmax part of it is written by the same wave that reduces the row (one pass over the logits less than
+        // with a separate row-in-registers gradient kernel: 110 vs 127 us; that kernel, ctc_grad_rows_kernel, is in the git history)
+        if (dlogits) {
 #define K1(NV) ctc_lse_gather_rows_kernel<NV, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, (bf16_t*)dlogits, grad_scale, grad_scale_div)
             ROWS_DISPATCH(K1);
 #undef K1
@@ -847,12 +754,8 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
 #undef AB
     if (dlogits) {
         int g3 = rows < 2048 ? rows : 2048;
-        if (rows_path && ctc_split) {
+        if (rows_path) {
             asr_launch_armed(ctc_label_fix_kernel, dim3(g1), dim3(256), 0, st, (bf16_t*)dlogits, lp, alpha, beta, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, grad_scale_div);      // last kernel: may carry an armed completion event
-        } else if (rows_path) {
-#define K3(NV) ctc_grad_rows_kernel<NV><<<g1, 256, 0, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, grad_scale_div)
-            ROWS_DISPATCH(K3);
-#undef K3
         } else if (dtype == ASR_F32) ctc_grad_kernel<float><<<g3, 256, lds, st>>>((const float*)logits, (float*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
         else ctc_grad_kernel<bf16_t><<<g3, 256, lds, st>>>((const bf16_t*)logits, (bf16_t*)dlogits, lp, alpha, beta, lse, in_len, labels, lab_len, nll_raw, B, T, V, ld, Lmax, W, blank, grad_scale, asr_deterministic(), grad_scale_div);
     }

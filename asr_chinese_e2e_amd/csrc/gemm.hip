@@ -150,154 +150,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
 }
 
 
-// ------------------------------------------------------------------------- NT, LDS-DMA version
-// The projection GEMMs of this model are SHORT (K = 512 or 1024, M = 16000): one tile is a few
-// microseconds of MFMA work while a tile's fixed costs (launch, first-tile HBM latency, the store
-// tail) are of the same order, so the kernel is built to overlap them:
-//   * BM x 128 x 64 tiles (BM = 128 or 256), 4 waves (2 x 2), wave tile (BM/2) x 64 of MFMA 32x32x16;
-//   * operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging and no
-//     ds_write - the register-staged kernel above spends as many LDS cycles writing as the MFMAs
-//     take) in whole 128-byte lines (64-byte segments halve the request efficiency: measured),
-//     RING-stage ring, ONE raw s_barrier per k-step, a counted vmcnt keeps RING-2 tiles of DMA in
-//     flight across the barrier (RING = 2 relies on a second resident workgroup instead);
-//   * an LDS-DMA wave-instruction writes 1 KiB lane-linearly (8 rows of 128 B), so the bank
-//     swizzle goes on the per-lane SOURCE address (16-byte chunk c of row R lands in slot
-//     c ^ (R & 7)) and is undone on the fragment read (guide 5.4 rule 21);
-//   * fragments of k-step ks+1 are read from LDS while the MFMAs of ks issue (register double
-//     buffer: with one or two waves per SIMD nothing else hides the ds_read latency);
-//   * epilogue through LDS: bias / ReLU in registers, tile written as bf16 with a 272-byte row
-//     stride, then whole 256-byte rows stored 16 B per lane (the C^T accumulator stored straight
-//     from registers costs 32 scattered 8-byte stores per lane: more than the whole main loop);
-//   * XCD-aware tile order so the tiles that share an A row-panel run on one XCD's L2.
-// Rows past M / N are clamped on load (their results are never stored).
-constexpr int DBN = 128, DBK = 64;
-#ifndef SWZ_NEW
-#define SWZ_NEW 1
-#endif
-constexpr int DEPS = 272;                        // epilogue row stride (bytes)
+// ------------------------------------------------------------------------- NT: LDS-DMA building blocks
+// Operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging and no ds_write) in whole 128-byte lines; an LDS-DMA
+// wave-instruction writes 1 KiB lane-linearly (8 rows of 128 B), so the bank swizzle goes on the per-lane SOURCE address (16-byte chunk c of
+// row R lands in slot c ^ f(R)) and is undone on the fragment read.  Rows past M / N are clamped on load (their results are never stored).
+// (The non-persistent 128/256 x 128 kernels of rounds 1 - 2 that introduced this - two workgroups per CU, ring of 2 or 3 - are in the git
+// history: gemm_nt_dma_kernel; every shape they served runs on the persistent loader / consumer kernel below.)
+constexpr int DBK = 64;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
-template <int BM_, int RING_> struct DmaCfg {
-    static constexpr int STAGE = (BM_ + DBN) * 128;                       // bytes per ring stage
-    static constexpr int EPI = BM_ * DEPS;
-    static constexpr int LDS = RING_ * STAGE > EPI ? RING_ * STAGE : EPI;
-    static constexpr int GROUPS = (BM_ + DBN) / 8;                        // 1-KiB DMA pieces per stage
-    static constexpr int PER_WAVE = GROUPS / 4;
-};
 
-template <int ACT, int BM_, int RING_, int DBG = 0>   // DBG (timing experiments only): 1 = DMA without MFMA, 2 = MFMA without DMA refills
-__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-                                                          bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int tiles_n) {
-    using Cfg = DmaCfg<BM_, RING_>;
-    constexpr int MI = BM_ / 64;   // 32-row MFMA tiles per wave along M
-    constexpr int PW = Cfg::PER_WAVE;
-    extern __shared__ __attribute__((aligned(16))) char smem_dma[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;   // bijective XCD remap
-    const int tn = tile % tiles_n, tm = tile / tiles_n;
-    const int m0 = tm * BM_, n0 = tn * DBN;
-    const int wm = w >> 1, wn = w & 1;
-    const int r = lane & 31, hh = lane >> 5;
-    // staging: GROUPS pieces of 8 rows per stage (A rows first, then W rows), PW per wave
-    const int srow = lane >> 3;
-    const bf16_t* src[PW];
-#pragma unroll
-    for (int j = 0; j < PW; ++j) {
-        const int g = w * PW + j;
-        const int schunk = (lane & 7) ^ (SWZ_NEW ? (((g & 1) << 2) | (srow >> 1)) : srow);   // key = (row >> 1) & 7
-        src[j] = g < BM_ / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
-                             : W + (size_t)min(n0 + 8 * (g - BM_ / 8) + srow, N - 1) * ldb + schunk * 8;
-    }
-    auto stage = [&](int slot, int k0) {
-        char* base = smem_dma + slot * Cfg::STAGE + (w * PW) * 1024;
-#pragma unroll
-        for (int j = 0; j < PW; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + k0), (lds_void_t*)(base + j * 1024), 16, 0, 0);
-    };
-    f32x16 acc[2][MI];  // [ni][mi]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    const int sw = SWZ_NEW ? (r >> 1) & 7 : r & 7;
-    const int a_row = (wm * (BM_ / 2) + r) * 128;            // + mi*32*128
-    const int w_row = BM_ * 128 + (wn * 64 + r) * 128;       // + ni*32*128
-    const int nk = K / DBK;
-    stage(0, 0);
-    if (RING_ > 2 && nk > 1) stage(1, DBK);
-    int cur = 0;
-    bf16x8 af[2][MI], wf[2][2];
-    for (int kt = 0; kt < (DBG == 3 ? 1 : nk); ++kt) {
-        if (RING_ > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // every wave's part of tile kt landed; the slot refilled next is no longer read
-        if (DBG != 2 && kt + RING_ - 1 < nk) stage(cur >= 1 ? cur - 1 : RING_ - 1, (kt + RING_ - 1) * DBK);
-        const char* sb = smem_dma + cur * Cfg::STAGE;
-        cur = cur == RING_ - 1 ? 0 : cur + 1;
-        if (DBG == 1) continue;
-        auto load_frags = [&](int buf, int ks) {
-            const int coff = ((2 * ks + hh) ^ sw) << 4;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[buf][mi] = *(const bf16x8*)(sb + a_row + mi * 32 * 128 + coff);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
-        };
-        if (DBG != 4 || kt == 0) load_frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (DBG == 4) {
-                if (kt == 0 && ks == 0) load_frags(1, 1);
-            } else if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int nl = wn * 64 + ni * 32 + 8 * g4 + 4 * hh;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) b4[e] = (n0 + nl + e < N) ? bias[n0 + nl + e] : 0.f;
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int ml = wm * (BM_ / 2) + mi * 32 + r;
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[ni][mi][4 * g4 + e] + b4[e];
-                    if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
-                    o[e] = x;
-                }
-                store4<bf16_t>((bf16_t*)(smem_dma + ml * DEPS + nl * 2), o);
-            }
-        }
-    __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < BM_ / 16; ++it) {
-        const int row = it * 16 + (tid >> 4), ch = tid & 15;
-        const int m = m0 + row, n = n0 + ch * 8;
-        if (m >= M || n >= N) continue;
-        const u32x4 v = *(const u32x4*)(smem_dma + row * DEPS + ch * 16);
-        if (n + 7 < N) {
-            *(u32x4*)(C + (size_t)m * ldc + n) = v;
-        } else {
-            const bf16_t* pv = (const bf16_t*)&v;
-            for (int e = 0; e < 8 && n + e < N; ++e) C[(size_t)m * ldc + n + e] = pv[e];
-        }
-    }
-}
-
+// CUs the planners of the one-workgroup-per-CU kernels (persistent NT grid, weight-gradient M-splits) size their launches for: the
+// device's, or fewer under the tuning option "cu_limit" (> 0) - the engine sets it around the large launches it puts on the auxiliary /
+// weight-gradient streams BESIDE the decoder's chain of small kernels, whose workgroups need whole CUs too (132 - 148 KiB of LDS) and
+// otherwise wait for one of these launches to finish.
 static int cu_count() {
     static int n = 0;
     if (!n) {
@@ -308,23 +174,11 @@ static int cu_count() {
     return lim > 0 && lim < n ? (lim < 8 ? 8 : lim) : n;
 }
 
-template <int ACT, int BM_, int RING_, int DBG>
-static void launch_nt_dma(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st) {
-    using Cfg = DmaCfg<BM_, RING_>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<ACT, BM_, RING_, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-        attr = true;
-    }
-    const int t_n = ceil_div(N, DBN), t_m = ceil_div(M, BM_);
-    gemm_nt_dma_kernel<ACT, BM_, RING_, DBG><<<t_n * t_m, 256, Cfg::LDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n);
-}
-
-// ------------------------------------------------------------------------- NT, persistent version
-// Attribution of the kernel above on the config-2 shapes (tools/gemm_dbg_scan.sh): one k-step plus
-// the fixed per-tile costs (dispatch, first-tile latency, store tail) is HALF its time, and the
-// other half is DMA latency + MFMA in series (ring 2: one stage in flight per workgroup); LDS
-// fragment reads and bank conflicts are not on the critical path.  So this version
+// ------------------------------------------------------------------------- NT, persistent
+// Attribution of the non-persistent LDS-DMA kernel on the config-2 shapes (rounds 1 - 2): one k-step plus
+// the fixed per-tile costs (dispatch, first-tile latency, store tail) was HALF its time, and the
+// other half DMA latency + MFMA in series (ring 2: one stage in flight per workgroup); LDS
+// fragment reads and bank conflicts were not on the critical path.  So the persistent form
 //   * is PERSISTENT: one workgroup per CU walks a list of tiles, and the LDS-DMA ring runs across
 //     tile boundaries - the first stages of the next tile are in flight during the store tail;
 //   * uses 256 x 128 x 64 tiles (4 waves, wave tile 128 x 64 = 4 x 2 MFMA 32x32x16 tiles): 0.75 x
@@ -336,284 +190,16 @@ static void launch_nt_dma(const bf16_t* a, const bf16_t* w, const float* bias, b
 //     row-panels and W served by that XCD's L2).
 constexpr int PBM = 256, PBN = 128, PBK = 64, PRING = 3;
 constexpr int NT_ACT_ADD_RES = 3;      // kernel-internal: ASR_ACT_NONE with a residual operand (C = A W^T + bias + res; res may be C itself)
-// ReLU mask as ONE BIT per element (asr_gemm_nt_relu_bits_bf16; loader / consumer kernel only).  Forward: C = relu(A W^T + bias) and every
-// lane of a store round writes one dword = the "> 0" bits of its 32 output elements; backward: C = (A W^T) where the bit is set.  The bits
-// are private to the two launches (same M, N: same tiles; dword index ((tile * 4 + wave) * 4 + round) * 64 + lane) - 2 MB instead of the
-// 32-MB activation tensor that the ASR_ACT_RELU_MASK form re-reads, beside a weight-gradient GEMM that streams the same tensor.
-constexpr int NT_ACT_RELU_SAVE = 4, NT_ACT_MASK_BITS = 5;
 constexpr int PSTAGE = (PBM + PBN) * 128;          // 49152 B
 constexpr int PLDS = PRING * PSTAGE;               // 147456 B
-template <int NW> struct PCfg {                    // NW waves as (NW/2) x 2; wave tile (32*MI) x 64
-    static constexpr int MI = 8 / NW * 2;          // 4 waves: 4, 8 waves: 2
-    static constexpr int PPW = (PBM + PBN) / 8 / NW;   // DMA wave-instructions per wave per stage (12 / 6)
-    static constexpr int RM = NW == 4 ? 2 : 1;     // 32-row blocks per transpose round (staging must fit one ring slot)
-    static constexpr int PEPI = RM * 32 * 128;     // per-wave transpose buffer
-    static constexpr int PSTORES = 4 * MI;         // global stores per wave per tile (vmcnt accounting)
-};
-
-// KRAG: K is a multiple of 8 but not of 64 (the CTC head's input gradient reduces over V = 4232 columns): the 16-byte chunks of the
-// LAST k-step that lie past K are fetched from a zero page instead (per-lane select, on that one step only).
-template <int ACT, int NW, int DBG = 0, bool KRAG = false>
-__global__ __launch_bounds__(64 * NW, 1) void gemm_nt_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-                                                                     bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
-                                                                     int tiles_n, int ntiles, const bf16_t* __restrict__ mask,
-                                                                     const void* __restrict__ zero_page = nullptr, int st_mode = 0) {
-    using Cfg = PCfg<NW>;
-    constexpr int MI = Cfg::MI, PPW = Cfg::PPW, RM = Cfg::RM, PEPI = Cfg::PEPI, PSTORES = Cfg::PSTORES;
-    extern __shared__ __attribute__((aligned(16))) char smem_p[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // this workgroup's tiles: XCD x owns the contiguous range [lo, hi), its workgroups interleave inside it
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int nb_x = ((int)gridDim.x - xcd + 7) >> 3;
-    const int tq = ntiles >> 3, trem = ntiles & 7;          // XCD x owns tq + (x < trem) tiles: never fewer than its workgroups
-    const int lo = xcd * tq + min(xcd, trem), hi = lo + tq + (xcd < trem ? 1 : 0);
-    const int first = lo + idx;
-    if (first >= hi) return;
-    const int my_tiles = (hi - first + nb_x - 1) / nb_x;
-    const int nk = KRAG ? (K + PBK - 1) / PBK : K / PBK;
-    const int total = my_tiles * nk;
-    const int wm = w >> 1, wn = w & 1;
-    const int r = lane & 31, hh = lane >> 5;
-    const int srow = lane >> 3;
-
-    // ---- DMA issue cursor: runs PRING-1 k-steps ahead of the MFMAs, across tile boundaries
-    int it_tile = first, it_k = 0, it_slot = 0, issued = 0;
-    const bf16_t* src[PPW];   // this lane's source of each of the wave's one-KiB pieces, at k = 0 of the tile being staged
-    auto set_tile = [&](int tile) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int m0 = tm * PBM, n0 = tn * PBN;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int g = w * PPW + j;                       // 8-row group: 0..31 = A rows, 32..47 = W rows
-            const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));   // slot of chunk c in row R: c ^ ((R >> 1) & 7)
-            src[j] = g < PBM / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
-                                 : W + (size_t)min(n0 + 8 * (g - PBM / 8) + srow, N - 1) * ldb + schunk * 8;
-        }
-    };
-    auto dma = [&](int j) {
-        const bf16_t* p = src[j] + it_k * PBK;
-        if (KRAG && it_k == nk - 1) {      // wave-uniform: the ragged last k-step
-            const int g = w * PPW + j;
-            const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));
-            p = (it_k * PBK + schunk * 8 < K) ? p : (const bf16_t*)zero_page;
-        }
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)p, (lds_void_t*)(smem_p + it_slot * PSTAGE + (w * PPW + j) * 1024), 16, 0, 0);
-    };
-    auto advance = [&]() {
-        ++issued;
-        it_slot = it_slot == PRING - 1 ? 0 : it_slot + 1;
-        if (++it_k == nk) {
-            it_k = 0;
-            it_tile += nb_x;
-            if (issued < total) set_tile(it_tile);
-        }
-    };
-
-    const int sw = (r >> 1) & 7;
-    const int a_row = (wm * 32 * MI + r) * 128;              // + mi*32*128
-    const int w_row = PBM * 128 + (wn * 64 + r) * 128;       // + ni*32*128
-
-    unsigned long long* stamps = DBG == 5 ? (unsigned long long*)bias + (size_t)blockIdx.x * 16 : nullptr;
-    if (DBG == 5) { bias = nullptr; if (tid == 0) stamps[0] = __builtin_amdgcn_s_memrealtime(); }
-    set_tile(first);
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) dma(j);
-    advance();
-    if (total > 1) {
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) dma(j);
-        advance();
-    }
-    int c_slot = 0, i = 0;
-    bool prev_stores = false;   // the previous tile issued exactly PSTORES stores per wave (interior tile)
-    for (int c_tile = first; c_tile < hi; c_tile += nb_x) {
-        const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
-        const int m0 = tm * PBM + wm * 32 * MI, n0 = tn * PBN + wn * 64;
-        // The accumulators START at bias[n] (n = n0 + ni*32 + 8*g4 + 4*hh + e for register 4*g4 + e): one
-        // VALU op per element less in the store tail, where nothing overlaps it.  The address of each
-        // 8-float group is wave-uniform, so these are SCALAR loads (lgkmcnt): a vector load here would
-        // make the compiler wait for the prefetched DMA stages queued before it (vmcnt is in order).
-        // They live only inside this iteration: tile loop outside, k loop inside keeps them in AGPRs
-        // (one flat loop over (tile, k) made hipcc copy all of them in and out every k-step).
-        f32x16 acc[2][MI];  // [ni][mi]: C^T tiles (n in registers, m on the lane)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = min(n0 + ni * 32 + 8 * g4, N - 8);   // clamped groups are never stored
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
-                    const float bv = hh ? b_hi : b_lo;
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[ni][mi][4 * g4 + e] = bv;
-                }
-            }
-        // One k-step: 8*MI MFMAs per wave.  The DMA instructions of the stage two steps ahead are
-        // spread BETWEEN the MFMAs (three per 8 MFMAs): a wave issues in order and the texture path
-        // takes a 1-KiB DMA instruction every 16 cycles per CU, so a block of 48 of them in front
-        // of the MFMAs kept the matrix pipes idle for as long as the MFMAs themselves take (in-kernel
-        // stamps: 0.52 us DMA-only + 0.82 us MFMA-only = 1.28 us per k-step, i.e. no overlap at all).
-        // ACT_RELU_MASK: the activations whose sign gates this gradient, fetched at the start of the tile's LAST k-step
-        // so that their latency hides behind its MFMAs (loaded in the store tail they cost 8.8 us per launch, 36 %)
-        u32x4 hm[MI / RM][4 * RM];
-        auto load_masks = [&]() {
-#pragma unroll
-            for (int round = 0; round < MI / RM; ++round)
-#pragma unroll
-                for (int q = 0; q < 4 * RM; ++q) {
-                    const int row = q * 8 + srow, ch = lane & 7;
-                    const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
-                    const u32x4 z = {0u, 0u, 0u, 0u};
-                    hm[round][q] = (m < M && n + 8 <= N) ? *(const u32x4*)(mask + (size_t)m * ldc + n) : z;
-                }
-        };
-        auto k_step = [&](const bool more) {   // more (wave-uniform): a stage is left to be issued
-            const char* sb = smem_p + c_slot * PSTAGE;
-            c_slot = c_slot == PRING - 1 ? 0 : c_slot + 1;
-            bf16x8 af[2][MI], wf[2][2];
-            auto load_frags = [&](int buf, int ks) {
-                const int coff = ((2 * ks + hh) ^ sw) << 4;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) af[buf][mi] = *(const bf16x8*)(sb + a_row + mi * 32 * 128 + coff);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
-            };
-            load_frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
-#pragma unroll
-                for (int q = 0; q < 2 * MI; ++q) {
-                    const int ni = q / MI, mi = q % MI;
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
-                    const int g = ks * 2 * MI + q, g8 = g & 7;   // MFMA number in this step
-                    if (g8 == 1 || g8 == 4 || g8 == 6) {     // the MFMAs stay on ONE code path (two copies of this
-                        __builtin_amdgcn_sched_barrier(0);   // body made hipcc move the accumulators AGPR <-> VGPR every step)
-                        if (more) dma((g >> 3) * 3 + (g8 == 1 ? 0 : g8 == 4 ? 1 : 2));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            if (more) advance();
-        };
-        for (int c_k = 0; c_k < nk; ++c_k, ++i) {
-            // item i has landed when at most (the DMA of item i+1) + (the stores of a store tail in one
-            // of the last two iterations) are still outstanding; vmcnt retires in order.  Needs nk >= 2.
-            if (i + 1 < total) {
-                if (prev_stores && c_k < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + PSTORES) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();   // every wave's part of item i landed; nobody still reads the slot refilled during this step
-            if (DBG == 5 && tid == 0 && i < 12) stamps[1 + i] = __builtin_amdgcn_s_memrealtime();
-            if ((ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES) && c_k == nk - 1) load_masks();
-            k_step(issued < total);
-        }
-        // ---- store tail of tile c_tile: activation in registers, transpose through wave-private LDS
-        // buffers, 16-byte row stores.  Exactly PSTORES global stores per wave on an interior tile.
-        // Staging area: the ring slot the last k-step consumed.  It is free until the next step's
-        // DMA (issued after that step's barrier, which every wave reaches only after its LDS reads
-        // here); the barrier below makes sure the other waves have finished their fragment reads.
-        __builtin_amdgcn_s_barrier();
-        char* epi = smem_p + (c_slot == 0 ? PRING - 1 : c_slot - 1) * PSTAGE + w * PEPI;
-#pragma unroll
-        for (int round = 0; round < MI / RM; ++round) {
-#pragma unroll
-            for (int m2 = 0; m2 < RM; ++m2)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int mi = round * RM + m2;
-                        f32x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = acc[ni][mi][4 * g4 + e];
-                            if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
-                            o[e] = x;
-                        }
-                        // row m2*32 + r (= m), columns ni*32 + 8*g4 + 4*hh .. +3  ->  16-byte chunk ni*4 + g4, half hh
-                        store4<bf16_t>((bf16_t*)(epi + (m2 * 32 + r) * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
-                    }
-            __builtin_amdgcn_wave_barrier();
-            u32x4 v[4 * RM];   // all LDS reads first: with the read inside the bounds test each store waited for its own read
-#pragma unroll
-            for (int q = 0; q < 4 * RM; ++q) {
-                const int row = q * 8 + srow, ch = lane & 7;
-                v[q] = *(const u32x4*)(epi + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-            }
-            if (ACT == NT_ACT_ADD_RES) {      // C = A W^T + bias + res: the residual tile was fetched under the last k-step like the ReLU mask
-#pragma unroll
-                for (int q = 0; q < 4 * RM; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t a = v[q][e], r2 = hm[round][q][e];
-                        const bf16_t lo = (bf16_t)(__uint_as_float(a << 16) + __uint_as_float(r2 << 16));
-                        const bf16_t hi = (bf16_t)(__uint_as_float(a & 0xffff0000u) + __uint_as_float(r2 & 0xffff0000u));
-                        v[q][e] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
-                    }
-            }
-            if (ACT == ASR_ACT_RELU_MASK) {
-#pragma unroll
-                for (int q = 0; q < 4 * RM; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {   // bf16 pair: keep where the activation is > 0 (not zero, sign clear)
-                        const uint32_t h = hm[round][q][e];
-                        const uint32_t lo = ((h & 0x7fffu) != 0u && !(h & 0x8000u)) ? 0x0000ffffu : 0u;
-                        const uint32_t hi = ((h & 0x7fff0000u) != 0u && !(h & 0x80000000u)) ? 0xffff0000u : 0u;
-                        v[q][e] &= lo | hi;
-                    }
-            }
-#pragma unroll
-            for (int q = 0; q < 4 * RM; ++q) {
-                const int row = q * 8 + srow, ch = lane & 7;
-                const int m = m0 + round * RM * 32 + row, n = n0 + ch * 8;
-                if (m < M && n + 8 <= N) {
-                    u32x4* dst = (u32x4*)(C + (size_t)m * ldc + n);
-                    if (st_mode == 0) stream_store(v[q], dst);
-                    else if (st_mode == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v[q]) : "memory");
-                    else if (st_mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v[q]) : "memory");
-                    else *dst = v[q];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // an edge tile may skip whole store instructions: then the shorter wait (which also covers
-        // its stores) is the safe one
-        prev_stores = (tm * PBM + PBM <= M) && (tn * PBN + PBN <= N);
-        if (DBG == 5 && tid == 0 && c_tile == first) {
-            stamps[13] = __builtin_amdgcn_s_memrealtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamps[14] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-}
-
-template <int ACT, int NW, int DBG = 0, bool KRAG = false>
-static void launch_nt_persist(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st,
-                              const bf16_t* mask = nullptr, const void* zero_page = nullptr) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<ACT, NW, DBG, KRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
-        attr = true;
-    }
-    const int t_n = ceil_div(N, PBN), t_m = ceil_div(M, PBM), ntiles = t_n * t_m;
-    const int grid = ntiles < cu_count() ? ntiles : cu_count();
-    // store policy of the output tile: 0 = nt (default), 1 = sc1 (write-through), 2 = plain, 3 = sc0 sc1 - all correct, A/B switch
-    const int st_mode = asr_option(ASR_OPT_NT_STORE);
-    gemm_nt_persist_kernel<ACT, NW, DBG, KRAG><<<grid, 64 * NW, PLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask, zero_page, st_mode);
-}
-
 // ------------------------------------------------------------------------- NT, persistent, loader / consumer waves
-// In the kernel above every wave issues its share of the LDS-DMA between its own MFMAs, and a 1-KiB DMA instruction holds the issuing wave
-// for ~165 cycles (in-kernel stamps: 0.52 us of DMA issue + 0.82 us of MFMA per k-step overlap to 0.93 us, not to 0.82).  Here the two
+// In the round-2 form of this kernel (gemm_nt_persist_kernel, git history) every wave issued its share of the LDS-DMA between its own MFMAs,
+// and a 1-KiB DMA instruction holds the issuing wave for ~165 cycles (in-kernel stamps: 0.52 us of DMA issue + 0.82 us of MFMA per k-step
+// overlap to 0.93 us, not to 0.82).  Here the two
 // jobs belong to different waves of the same workgroup: waves 4..7 only LOAD (12 DMA instructions per k-step each, two k-steps ahead,
 // counted vmcnt), waves 0..3 only COMPUTE (wave tile 128 x 64 = 4 x 2 MFMA blocks, 32 back-to-back MFMAs per k-step, fragments read
 // one k-sub-step ahead) and store.  Same tile (256 x 128 x 64), same ring (3 x 48 KiB), same one s_barrier per k-step, same tile
-// order; a loader and a consumer share each SIMD, so DMA issue and matrix issue come from different instruction streams.  Every output
-// element sees the same k order as in the kernel above: identical bits.
+// order; a loader and a consumer share each SIMD, so DMA issue and matrix issue come from different instruction streams.
 typedef float f32x8u __attribute__((ext_vector_type(8), aligned(4)));      // eight floats at any 4-byte aligned address (scalar loads)
 
 template <int ACT, bool KRAG = false>
@@ -728,7 +314,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
         constexpr bool MASKED = ACT == ASR_ACT_RELU_MASK || ACT == NT_ACT_ADD_RES;
         constexpr int NPF = 2;      // rounds fetched under the k-loop (three: the kernel spills)
         u32x4 hmp[NPF][4];
-        uint32_t bitw[MI];      // NT_ACT_MASK_BITS: this lane's mask bits of the four store rounds
         const int pf_k = nk > 2 ? 2 : nk - 1;
         // A tile that lies wholly inside the matrix (all but the last row / column of tiles) loads and stores without predicates:
         // the compiler then counts the outstanding memory operations (vmcnt(N), N > 0) and a round never waits for the stores of
@@ -748,10 +333,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
         };
         for (int c_k = 0; c_k < nk; ++c_k) {
             __builtin_amdgcn_s_barrier();
-            if (ACT == NT_ACT_MASK_BITS && c_k == pf_k) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) bitw[mi] = ((const uint32_t*)mask)[((size_t)(c_tile * 4 + w) * 4 + mi) * 64 + lane];
-            }
             if (MASKED && c_k == pf_k) {
                 if (full) {
 #pragma unroll
@@ -802,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = acc[ni][mi][4 * g4 + e];
-                            if (ACT == ASR_ACT_RELU || ACT == NT_ACT_RELU_SAVE) x = fmaxf(x, 0.f);
+                            if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
                             o[e] = x;
                         }
                         store4<bf16_t>((bf16_t*)(epi + r * 128 + (((ni * 4 + g4) ^ sw) << 4) + hh * 8), o);
@@ -823,28 +404,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_spec_kernel(const bf16_t* __re
                             const bf16_t lo_ = (bf16_t)(__uint_as_float(a << 16) + __uint_as_float(r2 << 16));
                             const bf16_t hi_ = (bf16_t)(__uint_as_float(a & 0xffff0000u) + __uint_as_float(r2 & 0xffff0000u));
                             v[q][e] = (uint32_t)__builtin_bit_cast(unsigned short, lo_) | ((uint32_t)__builtin_bit_cast(unsigned short, hi_) << 16);
-                        }
-                }
-                if (ACT == NT_ACT_RELU_SAVE) {      // bit 8 q + 2 e (+ 1): element 2 e (+ 1) of piece q is > 0 (the values are relu outputs: >= 0)
-                    uint32_t bits = 0u;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            bits |= ((v[q][e] & 0x7fffu) != 0u ? 1u : 0u) << (8 * q + 2 * e);
-                            bits |= ((v[q][e] & 0x7fff0000u) != 0u ? 1u : 0u) << (8 * q + 2 * e + 1);
-                        }
-                    ((uint32_t*)mask)[((size_t)(c_tile * 4 + w) * 4 + mi) * 64 + lane] = bits;
-                }
-                if (ACT == NT_ACT_MASK_BITS) {
-                    const int bw = (int)bitw[mi];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uint32_t lo_ = (uint32_t)__builtin_amdgcn_sbfe(bw, 8 * q + 2 * e, 1);          // 0 or all ones
-                            const uint32_t hi_ = (uint32_t)__builtin_amdgcn_sbfe(bw, 8 * q + 2 * e + 1, 1);
-                            v[q][e] &= (lo_ & 0x0000ffffu) | (hi_ & 0xffff0000u);
                         }
                 }
                 if (ACT == ASR_ACT_RELU_MASK) {
@@ -885,186 +444,6 @@ static void launch_nt_spec(const bf16_t* a, const bf16_t* w, const float* bias, 
     const int t_n = ceil_div(N, PBN), t_m = ceil_div(M, PBM), ntiles = t_n * t_m;
     const int grid = ntiles < cu_count() ? ntiles : cu_count();
     asr_launch_armed(gemm_nt_spec_kernel<ACT, KRAG>, dim3(grid), dim3(512), PLDS, st, a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles, mask, zero_page);
-}
-
-// ------------------------------------------------------------------------- NT, persistent, 256 x 256 tiles
-// What bounds the 256 x 128 kernel above (in-kernel stamps, round 3): a k-step takes 0.93 us where its 32 MFMAs per SIMD need
-// 0.54 us - the step is paced by the L2 -> LDS stream (48 KiB per k-step and CU at the ~70 GB/s a CU draws from L2 with every CU
-// pulling), not by the matrix pipe.  A 256 x 256 tile moves 64 KiB per 8.4 MFLOP instead of 48 KiB per 4.2: two thirds of the
-// bytes per FLOP, so the k-step becomes matrix-bound (64 MFMAs per SIMD ~ 1.1 us at the ~1.9 GHz held under load).  The price:
-// a stage is 64 KiB, so the ring has TWO slots (128 KiB) and the DMA of step i + 1 has exactly step i to land; and a GEMM needs
-// N >= 1024 with about one tile per CU or many (w_1 forward and w_2 input gradient: 63 x 4 = 252 tiles; CTC head: 63 x 17).
-//   * 8 waves as 4 (rows) x 2 (columns), wave tile 64 x 128 = 2 x 4 MFMA 32x32x16 blocks (128 accumulator registers),
-//     6 fragment reads per 8 MFMAs (the kernel above: 4 per 4);
-//   * the 8 DMA instructions of a wave for step i + 1 go out behind every second MFMA of the FIRST half of step i;
-//   * store tail: per wave two rounds of 32 rows x 128 columns through a wave-private 8-KiB buffer in the slot consumed last
-//     (256-byte rows, 16-byte chunk c of row r at c ^ (r & 15)), 16 lanes per row = whole 256-byte segments per store.
-constexpr int WBM = 256, WBN = 256, WBK = 64;
-constexpr int WSTAGE = (WBM + WBN) * 128;          // 65536 B
-constexpr int WLDS = 2 * WSTAGE;                   // 131072 B
-constexpr int WPPW = (WBM + WBN) / 8 / 8;          // 8 one-KiB DMA pieces per wave per stage
-constexpr int WSTORES = 16;                        // global stores per wave per interior tile
-
-template <int ACT>
-__global__ __launch_bounds__(512, 1) void gemm_nt_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-                                                              bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int tiles_n, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int nb_x = ((int)gridDim.x - xcd + 7) >> 3;
-    const int tq = ntiles >> 3, trem = ntiles & 7;
-    const int lo = xcd * tq + min(xcd, trem), hi = lo + tq + (xcd < trem ? 1 : 0);
-    const int first = lo + idx;
-    if (first >= hi) return;
-    const int my_tiles = (hi - first + nb_x - 1) / nb_x;
-    const int nk = K / WBK;
-    const int total = my_tiles * nk;
-    const int wm = w >> 1, wn = w & 1;
-    const int r = lane & 31, hh = lane >> 5, srow = lane >> 3;
-
-    // DMA cursor: ONE k-step ahead of the MFMAs, across tile boundaries
-    int it_tile = first, it_k = 0, it_slot = 0, issued = 0;
-    const bf16_t* src[WPPW];
-    auto set_tile = [&](int tile) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int m0 = tm * WBM, n0 = tn * WBN;
-#pragma unroll
-        for (int j = 0; j < WPPW; ++j) {
-            const int g = w * WPPW + j;                       // 8-row group: 0..31 = A rows, 32..63 = W rows
-            const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));
-            src[j] = g < WBM / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
-                                 : W + (size_t)min(n0 + 8 * (g - WBM / 8) + srow, N - 1) * ldb + schunk * 8;
-        }
-    };
-    auto dma = [&](int j) {
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + it_k * WBK), (lds_void_t*)(smem_w + it_slot * WSTAGE + (w * WPPW + j) * 1024), 16, 0, 0);
-    };
-    auto advance = [&]() {
-        ++issued;
-        it_slot ^= 1;
-        if (++it_k == nk) {
-            it_k = 0;
-            it_tile += nb_x;
-            if (issued < total) set_tile(it_tile);
-        }
-    };
-    const int sw = (r >> 1) & 7;
-    const int a_row = (wm * 64 + r) * 128;                   // + mi * 32 * 128
-    const int w_row = WBM * 128 + (wn * 128 + r) * 128;      // + ni * 32 * 128
-    set_tile(first);
-#pragma unroll
-    for (int j = 0; j < WPPW; ++j) dma(j);
-    advance();
-    int c_slot = 0, i = 0;
-    bool prev_stores = false;
-    for (int c_tile = first; c_tile < hi; c_tile += nb_x) {
-        const int tm = c_tile / tiles_n, tn = c_tile - tm * tiles_n;
-        const int m0 = tm * WBM + wm * 64, n0 = tn * WBN + wn * 128;
-        f32x16 acc[4][2];  // [ni][mi]: C^T blocks (n in registers, m on the lane), starting at the bias (scalar loads)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int nb = min(n0 + ni * 32 + 8 * g4, N - 8);   // clamped groups are never stored
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
-                    const float bv = hh ? b_hi : b_lo;
-                    acc[ni][0][4 * g4 + e] = bv;
-                    acc[ni][1][4 * g4 + e] = bv;
-                }
-            }
-        for (int c_k = 0; c_k < nk; ++c_k, ++i) {
-            // item i has landed when only the stores of the previous tile's tail (issued after its DMA) are outstanding
-            if (prev_stores && c_k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WSTORES) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // every wave's part of item i landed; nobody still reads the other slot (item i - 1)
-            const bool more = issued < total;
-            const char* sb = smem_w + c_slot * WSTAGE;
-            c_slot ^= 1;
-            bf16x8 af[2][2], wf[2][4];
-            auto load_frags = [&](int buf, int ks) {
-                const int coff = ((2 * ks + hh) ^ sw) << 4;
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) af[buf][mi] = *(const bf16x8*)(sb + a_row + mi * 32 * 128 + coff);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
-            };
-            load_frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int ni = q >> 1, mi = q & 1;
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1][mi], acc[ni][mi], 0, 0, 0);
-                    const int g = ks * 8 + q;                    // MFMA number in this step: DMA piece g / 2 behind every odd one of the first 16
-                    if (g < 2 * WPPW && (g & 1)) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more) dma(g >> 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            if (more) advance();
-        }
-        // ---- store tail
-        __builtin_amdgcn_s_barrier();      // the other waves have finished their fragment reads of the slot that becomes the staging area
-        char* epi = smem_w + (c_slot ^ 1) * WSTAGE + w * 8192;
-        const int erow = lane >> 4, ech = lane & 15;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[ni][mi][4 * g4 + e];
-                        if (ACT == ASR_ACT_RELU) x = fmaxf(x, 0.f);
-                        o[e] = x;
-                    }
-                    // row r (= m), columns ni*32 + 8*g4 + 4*hh .. +3  ->  16-byte chunk ni*4 + g4 (of 16 per 256-byte row), half hh
-                    store4<bf16_t>((bf16_t*)(epi + r * 256 + (((ni * 4 + g4) ^ (r & 15)) << 4) + hh * 8), o);
-                }
-            __builtin_amdgcn_wave_barrier();
-            u32x4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = q * 4 + erow;
-                v[q] = *(const u32x4*)(epi + row * 256 + ((ech ^ (row & 15)) << 4));
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = q * 4 + erow;
-                const int m = m0 + mi * 32 + row, n = n0 + ech * 8;
-                if (m < M && n + 8 <= N) stream_store(v[q], (u32x4*)(C + (size_t)m * ldc + n));
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        prev_stores = (tm * WBM + WBM <= M) && (tn * WBN + WBN <= N);
-    }
-}
-
-template <int ACT>
-static void launch_nt_wide(const bf16_t* a, const bf16_t* w, const float* bias, bf16_t* c, int M, int N, int K, int lda, int ldb, int ldc, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS);
-        attr = true;
-    }
-    const int t_n = ceil_div(N, WBN), t_m = ceil_div(M, WBM), ntiles = t_n * t_m;
-    const int grid = ntiles < cu_count() ? ntiles : cu_count();
-    gemm_nt_wide_kernel<ACT><<<grid, 512, WLDS, st>>>(a, w, bias, c, M, N, K, lda, ldb, ldc, t_n, ntiles);
-}
-// Tile choice: the wide tile pays when the GEMM has enough 256 x 256 tiles to fill the chip about once (>= 90 % of the CUs in the
-// last round) - w_1 / w_2-dgrad (252 tiles), the CTC head (1071); N = 1536 (378 tiles = 1.48 rounds) stays on 256 x 128.
-static bool nt_wide_pays(int M, int N, int K) {
-    if (N < 1024 || K % WBK || K < 2 * WBK) return false;
-    const int tiles = ceil_div(N, WBN) * ceil_div(M, WBM), cus = cu_count();
-    const int rounds = ceil_div(tiles, cus);
-    return tiles * 10 >= rounds * cus * 8;      // at least 80 % of the tile slots of the rounds it takes are used
 }
 
 // ------------------------------------------------------------------------- small-M projections (decoder)
@@ -1215,260 +594,8 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const bf16_t* __restric
     }
 }
 
-// ------------------------------------------------------------------------- NT + residual + LayerNorm
-// out-projection / second feed-forward projection with their post-LN in the store tail (attention.py:59-60, module.py:72-75,
-// transformer_official.py:208, 211): y = LN(A W^T + bias + res) gamma + beta, rows t >= lens[b] zeroed, xhat and rstd kept for
-// the backward pass.  N = 512 is one whole row, so a workgroup owns 64 rows x 512 columns (250 workgroups at M = 16000) and
-// the row statistics never leave it: the separate add-LN launch and one write + read of the (M, 512) projection output disappear.
-//   * 8 waves as 2 (rows) x 4 (columns): wave tile 32 x 128 = 4 MFMA 32x32x16 blocks, accumulators start at the bias;
-//   * stage = [A 64 x 64 | W 512 x 64] bf16 = 72 KiB by LDS-DMA (whole 128-byte lines, swizzle on the source address as in
-//     the kernels above), ring of 2: the DMA instructions of k-step kt + 1 are issued between the MFMAs of kt;
-//   * store tail: C^T accumulators -> bf16 row-major tile in LDS (the ring is free by then), then 8 threads per row add the
-//     residual (16-byte coalesced loads), reduce mean / variance with three shuffles, normalise and store y and xhat
-//     with 16-byte row stores (the arithmetic of add_ln_fwd_kernel; the projection output is rounded to bf16 before the
-//     statistics exactly as the two-kernel path stores it).
-constexpr int LBM = 64, LBN = 512, LBK = 64;
-constexpr int LSTAGE = (LBM + LBN) * 128;      // 73728 B
-constexpr int LZS = 1040;                      // row stride (bytes) of the store-tail tile: 16-byte aligned, 260 dwords
-constexpr int LLDS = 2 * LSTAGE;               // 147456 B (store tail: 64 x 1040 = 66560 B + gamma / beta 4 KiB inside it)
-constexpr int LPPW = (LBM + LBN) / 8 / 8;      // 9 one-KiB DMA pieces per wave per stage
-
-__global__ __launch_bounds__(512, 2) void gemm_nt_ln_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-                                                            const bf16_t* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const int32_t* __restrict__ lens, bf16_t* __restrict__ Y, bf16_t* __restrict__ XH,
-                                                            float* __restrict__ rstd_out, int M, int K, int lda, int ldb, int T_) {
-    extern __shared__ __attribute__((aligned(16))) char smem_l[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * LBM;
-    const int wm = w >> 2, wn = w & 3;
-    const int r = lane & 31, hh = lane >> 5, srow = lane >> 3;
-    // DMA sources at k = 0: piece g = 9 w + j: 8-row group g of the stage (0..7 = A rows, 8..71 = W rows)
-    const bf16_t* src[LPPW];
-#pragma unroll
-    for (int j = 0; j < LPPW; ++j) {
-        const int g = w * LPPW + j;
-        const int schunk = (lane & 7) ^ (((g & 1) << 2) | (srow >> 1));      // slot of chunk c in row R: c ^ ((R >> 1) & 7)
-        src[j] = g < LBM / 8 ? A + (size_t)min(m0 + 8 * g + srow, M - 1) * lda + schunk * 8
-                             : W + (size_t)(8 * (g - LBM / 8) + srow) * ldb + schunk * 8;
-    }
-    auto dma = [&](int j, int slot, int k0) {
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[j] + k0), (lds_void_t*)(smem_l + slot * LSTAGE + (w * LPPW + j) * 1024), 16, 0, 0);
-    };
-    f32x16 acc[4];   // [ni]: C^T blocks (n in registers, m on the lane), starting at the bias
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int nb = wn * 128 + ni * 32 + 8 * g4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float b_lo = bias ? bias[nb + e] : 0.f, b_hi = bias ? bias[nb + 4 + e] : 0.f;
-                acc[ni][4 * g4 + e] = hh ? b_hi : b_lo;
-            }
-        }
-    const int sw = (r >> 1) & 7;
-    const int a_row = (wm * 32 + r) * 128;
-    const int w_row = LBM * 128 + (wn * 128 + r) * 128;      // + ni * 32 * 128
-    const int nk = K / LBK;
-#pragma unroll
-    for (int j = 0; j < LPPW; ++j) dma(j, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // stage kt landed in every wave; nobody still reads the slot refilled during this step
-        const bool more = kt + 1 < nk;
-        const int nslot = (kt + 1) & 1, nk0 = (kt + 1) * LBK;
-        const char* sb = smem_l + (kt & 1) * LSTAGE;
-        bf16x8 af[2], wf[2][4];
-        auto load_frags = [&](int buf, int ks) {
-            const int coff = ((2 * ks + hh) ^ sw) << 4;
-            af[buf] = *(const bf16x8*)(sb + a_row + coff);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[buf][ni] = *(const bf16x8*)(sb + w_row + ni * 32 * 128 + coff);
-        };
-        static_assert(LPPW == 9, "issue schedule below");
-        load_frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][ni], af[ks & 1], acc[ni], 0, 0, 0);
-                // ring of 2: the next stage must land within THIS step, so its 9 DMA instructions go out early - one behind
-                // each of the first 9 MFMAs (spread over all 16 their latency was exposed at the next barrier: 25.0 -> ? us)
-                const int g = ks * 4 + ni;
-                if (g < LPPW) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) dma(g, nslot, nk0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-    __syncthreads();      // every wave has finished its fragment reads: the ring becomes the store-tail tile
-    float* gb = (float*)(smem_l + LBM * LZS);      // gamma (512) | beta (512)
-    for (int c = tid; c < 2 * LBN; c += 512) gb[c] = c < LBN ? gamma[c] : beta[c - LBN];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int nl = wn * 128 + ni * 32 + 8 * g4 + 4 * hh;
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = acc[ni][4 * g4 + e];
-            store4<bf16_t>((bf16_t*)(smem_l + (wm * 32 + r) * LZS + nl * 2), o);
-        }
-    __syncthreads();
-    // 8 threads per row, thread (row, seg) owns the 16-byte chunks p * 8 + seg, p = 0..7
-    const int row = tid >> 3, seg = tid & 7;
-    const int m = m0 + row;
-    const bool in_range = m < M;
-    const size_t grow = (size_t)(in_range ? m : M - 1) * LBN;
-    float z[64];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int ch = p * 8 + seg;
-        float a8[8], r8[8];
-        load8<bf16_t>((const bf16_t*)(smem_l + row * LZS + ch * 16), a8);
-        load8<bf16_t>(res + grow + ch * 8, r8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[p * 8 + e] = a8[e] + r8[e];
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) s += z[i];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    const float mean = s * (1.f / LBN);
-    float qv = 0.f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) { z[i] -= mean; qv += z[i] * z[i]; }
-    qv += __shfl_xor(qv, 1, 64);
-    qv += __shfl_xor(qv, 2, 64);
-    qv += __shfl_xor(qv, 4, 64);
-    const float rstd = rsqrtf(qv * (1.f / LBN) + 1e-5f);
-    bool keep = true;
-    if (lens) {
-        const int mm = in_range ? m : M - 1, b = mm / T_, t = mm - b * T_;
-        keep = t < lens[b];
-    }
-    if (in_range) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int ch = p * 8 + seg;
-            float xh[8], out[8];
-            const f32x4 g0 = *(const f32x4*)(gb + ch * 8), g1 = *(const f32x4*)(gb + ch * 8 + 4);
-            const f32x4 b0 = *(const f32x4*)(gb + LBN + ch * 8), b1 = *(const f32x4*)(gb + LBN + ch * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xh[e] = z[p * 8 + e] * rstd;
-                const float gg = e < 4 ? g0[e] : g1[e - 4], bb = e < 4 ? b0[e] : b1[e - 4];
-                out[e] = keep ? xh[e] * gg + bb : 0.f;
-            }
-            store8<bf16_t>(XH + grow + ch * 8, xh);
-            store8<bf16_t>(Y + grow + ch * 8, out);
-        }
-        if (seg == 0) rstd_out[m] = rstd;
-    }
-}
-
 // ---------------------------------------------------------------------------------------- TN
-constexpr int TM = 64;     // reduction rows per LDS tile
-constexpr int TSW = 160;   // LDS row stride in elements (320 B == 64 mod 256: tr reads conflict-free)
-
-__device__ __forceinline__ void tn_load(Stage4& st, const bf16_t* __restrict__ base, size_t ld, int row0, int row_end, int c0, int cols, int tid) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int id = tid + 256 * c, row = id >> 4, ch = id & 15;
-        const int gr = row0 + row, gc = c0 + ch * 8;
-        u32x4 z = {0u, 0u, 0u, 0u};
-        st.v[c] = (gr < row_end && gc < cols) ? *(const u32x4*)(base + (size_t)gr * ld + gc) : z;
-    }
-}
-__device__ __forceinline__ void tn_store(const Stage4& st, bf16_t* tile, int tid) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int id = tid + 256 * c, row = id >> 4, ch = id & 15;
-        *(u32x4*)(tile + row * TSW + ch * 8) = st.v[c];
-    }
-}
-// lane (r, hh), j = 0..7  ->  tile[16*s + 8*(j>>2) + 4*hh + (j&3)][col0 + r]
-__device__ __forceinline__ bf16x8 tn_frag(const bf16_t* tile, int col0, int s, int lane) {
-    const int G = lane >> 4, i = lane & 15;
-    const bf16_t* p = tile + (16 * s + 4 * (G >> 1) + (i >> 2)) * TSW + col0 + 16 * (G & 1) + 4 * (i & 3);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 8 * TSW));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N, int K,
-                                                      int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split, int use_atomic, size_t split_stride) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TM * TSW];
-    bf16_t* Ys = smem;
-    bf16_t* Xs = smem + TM * TSW;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // 1-D grid, XCD-aware: all output tiles of one M-split read the same dY / X rows, so a split's
-    // tiles get consecutive virtual ids (one XCD's L2 then serves the re-reads)
-    const int ntiles = tiles_k * tiles_n;
-    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
-    const int split = vid / ntiles, tile = vid - split * ntiles;
-    const int tk = tile % tiles_k, tn = tile / tiles_k;
-    const int n0 = tn * 128, k0 = tk * 128;
-    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
-    dW += (size_t)split * split_stride;     // deterministic mode: every split owns a slab (summed by tn_slab_reduce_kernel)
-    const int wn = w >> 1, wk = w & 1;
-    f32x16 acc[2][2];  // [ni][ki]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    Stage4 sy, sx;
-    if (mbeg < mend) {
-        tn_load(sy, dY, ldy, mbeg, mend, n0, N, tid);
-        tn_load(sx, X, ldx, mbeg, mend, k0, K, tid);
-    }
-    for (int m0 = mbeg; m0 < mend; m0 += TM) {
-        __syncthreads();
-        tn_store(sy, Ys, tid);
-        tn_store(sx, Xs, tid);
-        __syncthreads();
-        if (m0 + TM < mend) {
-            tn_load(sy, dY, ldy, m0 + TM, mend, n0, N, tid);
-            tn_load(sx, X, ldx, m0 + TM, mend, k0, K, tid);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 yf[2], xf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                yf[i] = tn_frag(Ys, wn * 64 + i * 32, s, lane);
-                xf[i] = tn_frag(Xs, wk * 64 + i * 32, s, lane);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int ki = 0; ki < 2; ++ki) acc[ni][ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[ni], xf[ki], acc[ni][ki], 0, 0, 0);
-        }
-    }
-    // accumulator: row = n (registers), col = k (lane): 32 consecutive k per register -> 128-B segments
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
-            const int kc = k0 + wk * 64 + ki * 32 + (lane & 31);
-            if (kc >= K) continue;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = n0 + wn * 64 + ni * 32 + acc_row(i, lane);
-                if (n >= N) continue;
-                float* dst = dW + (size_t)n * ldw + kc;
-                if (use_atomic) atomicAdd(dst, acc[ni][ki][i]);
-                else *dst = acc[ni][ki][i];
-            }
-        }
-}
+constexpr int TM = 64;     // reduction rows per LDS stage
 
 // ------------------------------------------------------------------------- TN, LDS-DMA version
 // Same pipeline as the persistent NT kernel, applied to the weight gradient: a 4-stage ring of
@@ -1508,13 +635,10 @@ __device__ __forceinline__ bf16x8 tn_frag_swz(unsigned addr) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// TRING ring slots; G wave groups of four waves.  G = 2 is an intra-workgroup split of the reduction:
-// a ring slot then holds 128 rows, group 0 multiplies rows 0..63 and group 1 rows 64..127 into its
-// own accumulators, which are added through LDS at the end - two waves per SIMD hide each other's
-// barrier, LDS and DMA-issue latencies like two co-resident workgroups would, but the tile is
-// added to memory once.  Forms used: <2, 2> (one 8-wave workgroup per CU), <2, 1> (two per CU).
-template <int TRING, int G>
-__global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
+// TRING ring slots of 64 rows; four waves (2 x 2 over the 128 x 128 tile).  (An 8-wave form with an intra-workgroup split of the
+// reduction - two wave groups per ring slot - is in the git history: faster alone, slower beside the main stream.)
+template <int TRING>
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
                                                              int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
                                                              int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias, size_t split_stride,
                                                              int bias_split_stride, int skew = 0) {
@@ -1528,13 +652,12 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
     // skew > 0 (the default; tuning option "tn_cfg" = 3 switches it off): split s reduces rows_per_split + skew * s rows, so the splits - which all add their tile
     // to memory with fp32 atomics when they finish - finish one after the other instead of together
     const int mbeg = split * rows_per_split + skew * (split * (split - 1) / 2), mend = min(M, mbeg + rows_per_split + skew * split);
-    constexpr int SR = TM * G;                 // rows per ring slot
-    constexpr int SBYTES = TSTAGE * G;         // bytes per ring slot: [dY SR x 256 B | X SR x 256 B]
+    constexpr int SR = TM;                     // rows per ring slot
+    constexpr int SBYTES = TSTAGE;             // bytes per ring slot: [dY 64 x 256 B | X 64 x 256 B]
     const int nsteps = (mend - mbeg + SR - 1) / SR;
     if (nsteps <= 0) return;
     dW += (size_t)split * split_stride;     // deterministic mode: every split owns a slab (summed by tn_slab_reduce_kernel)
-    const int grp = w >> 2, wl = w & 3;
-    const int wn = wl >> 1, wk = wl & 1;
+    const int wn = w >> 1, wk = w & 1;
 
     // this lane's part of each of the wave's 8 one-KiB pieces: the first half of the waves stages dY
     // (rows 4g.. of piece g), the second half X.  Running pointers, advanced by one uniform add per stage: the
@@ -1544,12 +667,12 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
     // columns that are never stored.  Rows past the end of the range must read zeros: only the last
     // stage of a range can be partial, and only there the per-lane select runs.
     const int lrow = lane >> 4, slot = lane & 15;
-    const bool is_y = w < 2 * G;
+    const bool is_y = w < 2;
     const bf16_t* cur[8];
     int prow[8];   // row inside the stage
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int gg = (w % (2 * G)) * 8 + j;
+        const int gg = (w & 1) * 8 + j;
         const int row = 4 * gg + lrow;
         const int col = (slot ^ (4 * (row & 3))) * 8;
         prow[j] = row;
@@ -1586,10 +709,10 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_t;
-    const unsigned y_off[2] = {grp * TM * 256 + tn_frag_off(wn * 64, lane), grp * TM * 256 + tn_frag_off(wn * 64 + 32, lane)};
-    const unsigned x_off[2] = {(SR + grp * TM) * 256 + tn_frag_off(wk * 64, lane), (SR + grp * TM) * 256 + tn_frag_off(wk * 64 + 32, lane)};
+    const unsigned y_off[2] = {tn_frag_off(wn * 64, lane), tn_frag_off(wn * 64 + 32, lane)};
+    const unsigned x_off[2] = {SR * 256 + tn_frag_off(wk * 64, lane), SR * 256 + tn_frag_off(wk * 64 + 32, lane)};
     // Bias gradient (column sums of dY) from the dY stages already in LDS, by the workgroups of the
-    // first k-tile: thread (chunk = tid & 15, phase = tid >> 4) adds rows phase, phase + 16 G, ... of
+    // first k-tile: thread (chunk = tid & 15, phase = tid >> 4) adds rows phase, phase + 16, ... of
     // its 8 columns; rows with equal (r & 3) keep a chunk in the same swizzled slot.  Replaces a
     // separate pass over dY (colsum + finalize launches) per projection.
     const bool do_bias = dbias != nullptr && tk == 0;
@@ -1637,7 +760,7 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
         if (do_bias) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const u32x4 c8 = *(const u32x4*)(smem_t + (sbase - lds_base) + b_off + qq * 16 * G * 256);
+                const u32x4 c8 = *(const u32x4*)(smem_t + (sbase - lds_base) + b_off + qq * 16 * 256);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bsum[2 * e] += __uint_as_float(c8[e] << 16);
@@ -1666,29 +789,8 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
 #undef TN_MMA
         if (more) advance();
     }
-    if (G > 1) {   // group 1 hands its accumulators to group 0 through the (now idle) ring memory
-        __syncthreads();
-        float* xch = (float*)smem_t + (size_t)wl * 64 * 64;
-        if (grp == 1) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int ki = 0; ki < 2; ++ki)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) xch[((ni * 2 + ki) * 16 + e) * 64 + lane] = acc[ni][ki][e];
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int ki = 0; ki < 2; ++ki)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[ni][ki][e] += xch[((ni * 2 + ki) * 16 + e) * 64 + lane];
-        }
-    }
     // accumulator: row = n (registers), col = k (lane): 32 consecutive k per register -> 128-B segments
-    if (grp == 0) {
+    {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -1705,7 +807,7 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
             }
         }
     }
-    if (do_bias) {   // 16 G row phases -> one sum per column, through the (now idle) ring memory
+    if (do_bias) {   // 16 row phases -> one sum per column, through the (now idle) ring memory
         __syncthreads();
         float* red = (float*)smem_t;
 #pragma unroll
@@ -1714,179 +816,8 @@ __global__ __launch_bounds__(256 * G) void gemm_tn_dma_kernel(const bf16_t* __re
         if (tid < 128 && n0 + tid < N) {
             float t = 0.f;
 #pragma unroll
-            for (int ph = 0; ph < 16 * G; ++ph) t += red[ph * 128 + tid];
-            if (bias_split_stride) dbias[(size_t)split * bias_split_stride + n0 + tid] = t;   // deterministic mode: slab per split
-            else atomicAdd(dbias + n0 + tid, t);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------- TN, loader / consumer waves
-// The weight-gradient kernel above is balanced on paper - a 64-row stage of a 128 x 128 tile is 32 one-KiB DMA instructions (512
-// cycles of the CU's vector-memory issue) against 16 MFMAs per SIMD (512 cycles) - but each wave issues its 8 DMA instructions
-// between its own MFMAs and runs ~730 cycles per stage.  Same split as gemm_nt_spec_kernel: waves 4..7 only load (8 pieces per
-// stage each, TRING - 1 stages ahead, counted vmcnt, zero-page redirection of a ragged last stage), waves 0..3 only compute
-// (unchanged 64 x 64 wave tiles, transposed fragment reads with hand-counted lgkmcnt) and add the tile to memory.  Same stages,
-// same ring, same split of the M range, same accumulation order per element.
-template <int TRING>
-__global__ __launch_bounds__(512) void gemm_tn_spec_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N, int K,
-                                                           int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split, int use_atomic,
-                                                           const void* __restrict__ zero_page, float* __restrict__ dbias, size_t split_stride,
-                                                           int bias_split_stride) {
-    extern __shared__ __attribute__((aligned(16))) char smem_ts[];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = tiles_k * tiles_n;
-    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
-    const int split = vid / ntiles, tile = vid - split * ntiles;
-    const int tk = tile % tiles_k, tn = tile / tiles_k;
-    const int n0 = tn * 128, k0 = tk * 128;
-    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
-    constexpr int SR = TM;                     // rows per ring slot
-    constexpr int SBYTES = TSTAGE;             // bytes per ring slot: [dY 64 x 256 B | X 64 x 256 B]
-    const int nsteps = (mend - mbeg + SR - 1) / SR;
-    if (nsteps <= 0) return;
-    if (w >= 4) {
-        // ================================================================ loader waves: lw 0, 1 stage dY, lw 2, 3 stage X
-        const int lw = w - 4;
-        const int lrow = lane >> 4, slot = lane & 15;
-        const bool is_y = lw < 2;
-        const bf16_t* cur[8];
-        int prow[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int gg = (lw & 1) * 8 + j;
-            const int row = 4 * gg + lrow;
-            const int col = (slot ^ (4 * (row & 3))) * 8;
-            prow[j] = row;
-            cur[j] = is_y ? dY + (size_t)(mbeg + row) * ldy + min(n0 + col, N - 8) : X + (size_t)(mbeg + row) * ldx + min(k0 + col, K - 8);
-        }
-        const size_t stage_step = (size_t)SR * (is_y ? ldy : ldx);
-        const bool ragged = ((mend - mbeg) % SR) != 0;
-        int it = 0, it_slot = 0;
-        auto fix_last = [&]() {
-            if (ragged && it == nsteps - 1) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) cur[j] = (mbeg + it * SR + prow[j] < mend) ? cur[j] : (const bf16_t*)zero_page;
-            }
-        };
-        auto issue_stage = [&]() {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)cur[j], (lds_void_t*)(smem_ts + it_slot * SBYTES + (lw * 8 + j) * 1024), 16, 0, 0);
-            ++it;
-            it_slot = it_slot == TRING - 1 ? 0 : it_slot + 1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cur[j] += stage_step;
-            fix_last();
-        };
-        fix_last();
-        for (int p = 0; p < TRING - 1 && p < nsteps; ++p) issue_stage();
-        for (int i = 0; i < nsteps; ++i) {
-            const int younger = min(TRING - 2, nsteps - 1 - i);      // stages issued after stage i that may still be in flight
-            if (TRING >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (TRING >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // stage i is complete for the consumers; they have finished stage i - 1, whose slot is refilled now
-            if (it < nsteps) issue_stage();
-        }
-        __builtin_amdgcn_s_barrier();          // the consumers' barrier(s) of the bias reduction / end
-        if (dbias != nullptr && tk == 0) __builtin_amdgcn_s_barrier();
-        return;
-    }
-    // ==================================================================== consumer waves
-    dW += (size_t)split * split_stride;
-    const int wn = w >> 1, wk = w & 1;
-    f32x16 acc[2][2];  // [ni][ki]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_ts;
-    const unsigned y_off[2] = {tn_frag_off(wn * 64, lane), tn_frag_off(wn * 64 + 32, lane)};
-    const unsigned x_off[2] = {SR * 256 + tn_frag_off(wk * 64, lane), SR * 256 + tn_frag_off(wk * 64 + 32, lane)};
-    const bool do_bias = dbias != nullptr && tk == 0;
-    float bsum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-    const unsigned b_off = (unsigned)((tid >> 4) * 256 + (((tid & 15) ^ (4 * ((tid >> 4) & 3))) << 4));
-    int c_slot = 0;
-    for (int i = 0; i < nsteps; ++i) {
-        __builtin_amdgcn_s_barrier();
-        const unsigned sbase = lds_base + c_slot * SBYTES;
-        c_slot = c_slot == TRING - 1 ? 0 : c_slot + 1;
-        bf16x8 yf[2][2], xf[2][2];
-#define TNS_LOAD(BUF, S)                                             \
-    do {                                                             \
-        yf[BUF][0] = tn_frag_swz<S>(sbase + y_off[0]);               \
-        yf[BUF][1] = tn_frag_swz<S>(sbase + y_off[1]);               \
-        xf[BUF][0] = tn_frag_swz<S>(sbase + x_off[0]);               \
-        xf[BUF][1] = tn_frag_swz<S>(sbase + x_off[1]);               \
-    } while (0)
-#define TNS_MMA(BUF)                                                                                                          \
-    do {                                                                                                                      \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                       \
-            const int ni = q >> 1, ki = q & 1;                                                                                \
-            acc[ni][ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[BUF][ni], xf[BUF][ki], acc[ni][ki], 0, 0, 0);            \
-        }                                                                                                                     \
-    } while (0)
-        if (do_bias) {
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const u32x4 c8 = *(const u32x4*)(smem_ts + (sbase - lds_base) + b_off + qq * 16 * 256);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bsum[2 * e] += __uint_as_float(c8[e] << 16);
-                    bsum[2 * e + 1] += __uint_as_float(c8[e] & 0xffff0000u);
-                }
-            }
-        }
-        TNS_LOAD(0, 0);
-        TNS_LOAD(1, 1);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TNS_MMA(0);
-        TNS_LOAD(0, 2);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TNS_MMA(1);
-        TNS_LOAD(1, 3);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TNS_MMA(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        TNS_MMA(1);
-#undef TNS_LOAD
-#undef TNS_MMA
-    }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int ki = 0; ki < 2; ++ki) {
-            const int kc = k0 + wk * 64 + ki * 32 + (lane & 31);
-            if (kc >= K) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = n0 + wn * 64 + ni * 32 + acc_row(e, lane);
-                if (n >= N) continue;
-                float* dst = dW + (size_t)n * ldw + kc;
-                if (use_atomic) atomicAdd(dst, acc[ni][ki][e]);
-                else *dst = acc[ni][ki][e];
-            }
-        }
-    __builtin_amdgcn_s_barrier();      // every consumer has finished its LDS reads of the ring (pairs with the loaders' barrier)
-    if (do_bias) {   // 16 row phases -> one sum per column, through the (now idle) ring memory
-        float* red = (float*)smem_ts;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
-        __builtin_amdgcn_s_barrier();
-        if (tid < 128 && n0 + tid < N) {
-            float t = 0.f;
-#pragma unroll
             for (int ph = 0; ph < 16; ++ph) t += red[ph * 128 + tid];
-            if (bias_split_stride) dbias[(size_t)split * bias_split_stride + n0 + tid] = t;
+            if (bias_split_stride) dbias[(size_t)split * bias_split_stride + n0 + tid] = t;   // deterministic mode: slab per split
             else atomicAdd(dbias + n0 + tid, t);
         }
     }
@@ -2219,80 +1150,34 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     if ((((uintptr_t)A | (uintptr_t)W) % 16) || ((uintptr_t)C % 8) || (res && (uintptr_t)res % 8) || (bias && (uintptr_t)bias % 16)) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     if (act != ASR_ACT_RELU && act != ASR_ACT_NONE && act != ASR_ACT_RELU_MASK) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
-    const bool spec = asr_option(ASR_OPT_NT_TILE) != 1;      // loader / consumer form of the persistent kernel (gemm_nt_spec_kernel): the default since round 3
-    if (act == ASR_ACT_RELU_MASK) {   // C = (A W^T + bias) where res > 0, else 0: persistent kernel only
-        if (!res || (uintptr_t)res % 16 || K % DBK || K < 2 * PBK || N % 8 || ldc % 8 || ((uintptr_t)C % 16))
+    // every projection / input gradient of the training step takes the persistent loader / consumer kernel (gemm_nt_spec_kernel: >= 2 k-steps,
+    // N % 8 == 0, 16-byte aligned rows); what is left (K < 128, odd leading dimensions) goes to the register-staged 128 x 128 kernel below
+    const bool rows16 = N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0;
+    if (act == ASR_ACT_RELU_MASK) {   // C = (A W^T) where res > 0, else 0 (the input gradient through a ReLU; no bias: gradients have none)
+        if (!res || (uintptr_t)res % 16 || K % DBK || K < 2 * PBK || !rows16)
             ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: ASR_ACT_RELU_MASK needs the mask in `res`, K %% 64 == 0, K >= 128, N, ldc %% 8 == 0 and 16-byte aligned pointers");
-        if (spec && !bias) launch_nt_spec<ASR_ACT_RELU_MASK>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
-        else
-        launch_nt_persist<ASR_ACT_RELU_MASK, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+        if (bias) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: ASR_ACT_RELU_MASK takes no bias");
+        launch_nt_spec<ASR_ACT_RELU_MASK>((const bf16_t*)A, (const bf16_t*)W, nullptr, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }
-    if (res && act == ASR_ACT_NONE && K % DBK == 0 && K >= 2 * PBK && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)res % 16) == 0) {
-        // residual add in the persistent kernel's store tail (res = C accumulates in place: every element is read and written by one lane)
-        if (spec && !bias) launch_nt_spec<NT_ACT_ADD_RES>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
-        else
-        launch_nt_persist<NT_ACT_ADD_RES, 8>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
+    if (res && act == ASR_ACT_NONE && !bias && K % DBK == 0 && K >= 2 * PBK && rows16 && ((uintptr_t)res % 16) == 0) {
+        // residual add in the store tail (res = C accumulates in place: every element is read and written by one lane)
+        launch_nt_spec<NT_ACT_ADD_RES>((const bf16_t*)A, (const bf16_t*)W, nullptr, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)res);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }
-    if (K % DBK != 0 && K > PBK && !res && act == ASR_ACT_NONE && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {      // >= 2 k-steps, the last one ragged (also linear_in: K = 80)
-        // ragged reduction length (K % 8 == 0 was checked above): persistent kernel, last k-step padded from the zero page
+    if (K % DBK != 0 && K > PBK && !res && act == ASR_ACT_NONE && rows16) {      // >= 2 k-steps, the last one ragged (linear_in: K = 80; the CTC head's input gradient: K = 4232)
         static void* zero_page = nullptr;
         if (!zero_page && (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page))
             ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: zero page symbol not found");
-        if (spec) launch_nt_spec<ASR_ACT_NONE, true>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, nullptr, zero_page);
-        else
-        launch_nt_persist<ASR_ACT_NONE, 8, 0, true>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, nullptr, zero_page);
+        launch_nt_spec<ASR_ACT_NONE, true>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, nullptr, zero_page);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }
-    if (K % DBK == 0 && !res && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0) {   // LDS-DMA kernel: whole 64-wide k-tiles, 16-B row stores
-        static const int dbg = unsafe_debug_env("ASR_GEMM_DBG");      // timing experiments (wrong results): debug builds only
-        static const int cfg = getenv("ASR_GEMM_CFG") ? atoi(getenv("ASR_GEMM_CFG")) : 0;   // tuning experiments
-        const bf16_t *a = (const bf16_t*)A, *wp = (const bf16_t*)W;
-        bf16_t* c = (bf16_t*)C;
-#define NT_DMA(BM_, RING_)                                                                                                  \
-    do {                                                                                                                     \
-        if (dbg == 1) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 1>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);                \
-        else if (dbg == 2) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 2>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);           \
-        else if (dbg == 3) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 3>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);           \
-        else if (dbg == 4) launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 4>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);           \
-        else if (act == ASR_ACT_RELU) launch_nt_dma<ASR_ACT_RELU, BM_, RING_, 0>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st); \
-        else launch_nt_dma<ASR_ACT_NONE, BM_, RING_, 0>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);                         \
-    } while (0)
-        // (of the non-persistent variants 128 x 128, ring 2, two workgroups per CU was the fastest;
-        // they stay selectable through ASR_GEMM_CFG for A/B runs)
-        // default: the persistent 8-wave kernel (tools/gemm_bench.py on the config-2 shapes, us:
-        // 38.4 / 17.4 / 27.0 / 23.8 / 116.8 vs 46.2 / 19.4 / 32.1 / 27.1 / 130.0 for 128 x 128 ring 2)
-        // tuning option "nt_tile": 0 = 256 x 128 tiles, loader / consumer waves (default); 1 = 256 x 128, every wave loads and computes (the
-        // round-2 kernel); 2 = 256 x 256 whenever the shape allows; 3 = 256 x 256 where nt_wide_pays().
-        // Measured (round 3): the wide tile is no faster alone (w_1: 26.3 vs 27.0 us; CTC head 111 vs 117) - its ring of two leaves the
-        // L2 -> LDS stream idle between a step's last landing and the next step's first issue - and SLOWER beside other streams (the joint
-        // model's K|V projections: 41 vs 26 us), step 3.416 vs 3.423 ms: kept as an option, not the default.
-        const int tile_opt = asr_option(ASR_OPT_NT_TILE);
-        if (cfg == 0 && dbg == 0 && N % 8 == 0 && (tile_opt == 2 || tile_opt == 3) && (tile_opt == 2 ? (K % WBK == 0 && K >= 2 * WBK && N >= 256) : nt_wide_pays(M, N, K))) {
-            if (act == ASR_ACT_RELU) launch_nt_wide<ASR_ACT_RELU>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-            else launch_nt_wide<ASR_ACT_NONE>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-        } else
-        if (spec && cfg == 0 && dbg == 0 && K >= 2 * PBK && N % 8 == 0) {
-            if (act == ASR_ACT_RELU) launch_nt_spec<ASR_ACT_RELU>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-            else launch_nt_spec<ASR_ACT_NONE>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-        } else
-        if ((cfg == 0 || cfg == 8) && K >= 2 * PBK && N % 8 == 0) {
-            if (dbg == 5) launch_nt_persist<ASR_ACT_NONE, 8, 5>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-            else if (act == ASR_ACT_RELU) launch_nt_persist<ASR_ACT_RELU, 8>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-            else launch_nt_persist<ASR_ACT_NONE, 8>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-        } else if (cfg == 4 && K >= 2 * PBK && N % 8 == 0) {
-            if (dbg == 5) launch_nt_persist<ASR_ACT_NONE, 4, 5>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-            else if (act == ASR_ACT_RELU) launch_nt_persist<ASR_ACT_RELU, 4>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-            else launch_nt_persist<ASR_ACT_NONE, 4>(a, wp, bias, c, M, N, K, lda, ldb, ldc, st);
-        } else if (cfg == 1) NT_DMA(256, 3);
-        else if (cfg == 2) NT_DMA(128, 3);
-        else if (cfg == 3) NT_DMA(256, 2);
-        else NT_DMA(128, 2);
-#undef NT_DMA
+    if (K % DBK == 0 && K >= 2 * PBK && !res && rows16) {
+        if (act == ASR_ACT_RELU) launch_nt_spec<ASR_ACT_RELU>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st);
+        else launch_nt_spec<ASR_ACT_NONE>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st);
         ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
         return ASR_OK;
     }
@@ -2304,32 +1189,6 @@ extern "C" int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias,
     else
         ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_bf16: unknown activation %d", act);
     ASR_CHECK_LAUNCH("asr_gemm_nt_bf16");
-    return ASR_OK;
-}
-
-// ReLU mask as bits (see NT_ACT_RELU_SAVE above).  0 bytes = no bit-mask form for this shape / these options: use ASR_ACT_RELU + ASR_ACT_RELU_MASK.
-extern "C" size_t asr_gemm_nt_relu_bits_bytes(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0 || N % 8 || K % DBK || K < 2 * PBK) return 0;
-    const int tile_opt = asr_option(ASR_OPT_NT_TILE);
-    if (tile_opt != 0) return 0;      // the loader / consumer kernel only
-    static const int cfg = getenv("ASR_GEMM_CFG") ? atoi(getenv("ASR_GEMM_CFG")) : 0;
-    if (cfg != 0) return 0;
-    return (size_t)ceil_div(N, PBN) * ceil_div(M, PBM) * 4096;
-}
-
-extern "C" int asr_gemm_nt_relu_bits_bf16(const void* A, const void* W, const float* bias, void* bits, size_t bits_bytes, void* C, int M, int N, int K, int lda,
-                                          int ldb, int ldc, int backward, void* stream) {
-    if (!A || !W || !C || !bits) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: null pointer");
-    const size_t need = asr_gemm_nt_relu_bits_bytes(M, N, K);
-    if (!need) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: no bit-mask form for M=%d N=%d K=%d with the current options (asr_gemm_nt_relu_bits_bytes = 0)", M, N, K);
-    if (bits_bytes < need || ((uintptr_t)bits % 4)) ASR_FAIL(ASR_EWORKSPACE, "asr_gemm_nt_relu_bits_bf16: bit buffer %zu < %zu bytes (or misaligned)", bits_bytes, need);
-    if (lda % 8 || ldb % 8 || ldc % 8 || lda < K || ldb < K || ldc < N) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: lda, ldb, ldc must be multiples of 8 (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
-    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16) || (bias && (uintptr_t)bias % 16)) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: misaligned pointer");
-    if (backward && bias) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_relu_bits_bf16: the backward form takes no bias");
-    hipStream_t st = (hipStream_t)stream;
-    if (backward) launch_nt_spec<NT_ACT_MASK_BITS>((const bf16_t*)A, (const bf16_t*)W, nullptr, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)bits);
-    else launch_nt_spec<NT_ACT_RELU_SAVE>((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldb, ldc, st, (const bf16_t*)bits);
-    ASR_CHECK_LAUNCH("asr_gemm_nt_relu_bits_bf16");
     return ASR_OK;
 }
 
@@ -2368,26 +1227,6 @@ extern "C" int asr_gemm_small_bf16(const void* A, const void* Bm, const float* b
     }
 #undef SMALL
     ASR_CHECK_LAUNCH("asr_gemm_small_bf16");
-    return ASR_OK;
-}
-
-extern "C" int asr_gemm_nt_add_ln_bf16(const void* A, const void* W, const float* bias, const void* res, const float* gamma, const float* beta,
-                                       const int32_t* lens, void* y, void* xhat, float* rstd, int B, int T, int N, int K, int lda, int ldb, void* stream) {
-    if (!A || !W || !res || !gamma || !beta || !y || !xhat || !rstd) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: null pointer");
-    if (B <= 0 || T <= 0 || K <= 0) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: bad shape B=%d T=%d K=%d", B, T, K);
-    if (N != LBN) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: the fused kernel is built for rows of %d columns (got %d): use asr_gemm_nt_bf16 + asr_add_ln_fwd", LBN, N);
-    if (K % LBK || lda % 8 || ldb % 8 || lda < K || ldb < K) ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: K must be a multiple of 64, lda / ldb multiples of 8 (K=%d lda=%d ldb=%d)", K, lda, ldb);
-    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)res | (uintptr_t)y | (uintptr_t)xhat) % 16) || (bias && (uintptr_t)bias % 16) || (((uintptr_t)gamma | (uintptr_t)beta) % 16))
-        ASR_FAIL(ASR_EINVAL, "asr_gemm_nt_add_ln_bf16: misaligned pointer");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LLDS);
-        attr = true;
-    }
-    const int M = B * T;
-    gemm_nt_ln_kernel<<<ceil_div(M, LBM), 512, LLDS, (hipStream_t)stream>>>((const bf16_t*)A, (const bf16_t*)W, bias, (const bf16_t*)res, gamma, beta, lens, (bf16_t*)y,
-                                                                            (bf16_t*)xhat, rstd, M, K, lda, ldb, T);
-    ASR_CHECK_LAUNCH("asr_gemm_nt_add_ln_bf16");
     return ASR_OK;
 }
 
@@ -2446,7 +1285,6 @@ extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, 
         ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: zero page symbol not found");
     // stage rows x ring: 64 x 3 = 144 KiB is the fastest alone (0.67 PFLOP/s on a config-2 layer), but this GEMM runs
     // beside the main stream, whose attention / LayerNorm workgroups need the rest of the CU's LDS
-    static const int cfg = getenv("ASR_GEMM_TNG_CFG") ? atoi(getenv("ASR_GEMM_TNG_CFG")) : 324;
     static const int dbg = unsafe_debug_env("ASR_GEMM_TNG_DBG");
 #define TNG_LAUNCH(ROWS_, RING_, DBG_)                                                                                                   \
     do {                                                                                                                                   \
@@ -2455,52 +1293,31 @@ extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, 
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<ROWS_, RING_, DBG_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
         gemm_tn_grouped_kernel<ROWS_, RING_, DBG_><<<begin, 256, lds, st>>>(g, accumulate, tn_noatomic, zero_page);                        \
     } while (0)
-    if (dbg == 1) TNG_LAUNCH(64, 3, 1);
-    else if (dbg == 2) TNG_LAUNCH(64, 3, 2);
-    else if (dbg == 3) TNG_LAUNCH(64, 3, 3);
-    else if (cfg == 643) TNG_LAUNCH(64, 3, 0);
-    else if (cfg == 325) TNG_LAUNCH(32, 5, 0);
-    else if (cfg == 323) TNG_LAUNCH(32, 3, 0);
-    else TNG_LAUNCH(32, 4, 0);
+    (void)dbg;
+    TNG_LAUNCH(32, 4, 0);      // 32-row stages x 4 = 96 KiB (64 x 3 = 144 KiB is the fastest alone, 0.67 PFLOP/s on a config-2 layer, but excludes the main stream from the CU)
 #undef TNG_LAUNCH
     ASR_CHECK_LAUNCH("asr_gemm_tn_grouped_bf16");
     return ASR_OK;
 }
 
 namespace {
-struct TnPlan { int tn_cfg, ring, rows_per_split, nsplit; bool eight; };
-// M-splits: every split adds N*K*4 bytes of atomics, every workgroup beyond what is resident at
-// once adds a whole second round.  The DMA kernel holds one 8-wave workgroup per CU (two wave
-// groups splitting each 128-row ring slot); if that leaves more than ~20 % of the CUs idle it
-// runs two 4-wave workgroups per CU instead.
+struct TnPlan { int ring, rows_per_split, nsplit; };
+// M-splits: every split adds N*K*4 bytes of atomics, every workgroup beyond what is resident at once adds a whole second round.  One 4-wave
+// workgroup per CU with a 3-stage ring (96 KiB) when the tiles x splits fill >= 80 % of the CUs that way, else two per CU with 2-stage rings.
+// (Tried and in the git history: an 8-wave form - 12 % faster alone, step 2 % slower: its waves take issue slots from the main stream's kernels
+// beside it; loader / consumer waves - same result; a 4-stage ring of 128 KiB - 1-5 % faster alone, step 1.4 % slower; fewer / more splits.)
 static TnPlan tn_plan(int M, int N, int K) {
-    static const int tn_cfg = getenv("ASR_GEMM_TN_CFG") ? atoi(getenv("ASR_GEMM_TN_CFG")) : 0;   // 1 = register-staged kernel (A/B runs)
     const int tiles = ceil_div(N, 128) * ceil_div(K, 128);
     const int cus = cu_count();
     const int max_s = ceil_div(M, 4 * TM);   // at least 4 reduction stages per workgroup
-    int splits = tn_splits(M, N, K), ring = 0;
-    if (tn_cfg != 1) {
-        const int s_floor = cus / tiles > 0 ? cus / tiles : 1;
-        if (tiles * s_floor * 5 >= cus * 4) { splits = s_floor; ring = 4; }   // "4" = the one-per-CU form <2, 2>
-        else { splits = ceil_div(2 * cus, tiles) > 1 ? (2 * cus) / tiles : 1; ring = 2; }
-        static const int split_env = getenv("ASR_GEMM_TN_SPLIT_PCT") ? atoi(getenv("ASR_GEMM_TN_SPLIT_PCT")) : 100;   // tuning: fewer, longer workgroups
-        const int split_opt = asr_option(ASR_OPT_TN_SPLIT);      // run-time form (tuning option "tn_split", percent; 0 = unset)
-        splits = splits * (split_opt > 0 ? split_opt : split_env) / 100;
-        if (splits > max_s) splits = max_s;
-        if (splits < 1) splits = 1;
-    }
-    // One workgroup per CU comes in two forms: four waves with a 4-stage ring (default), or eight waves
-    // = two wave groups splitting 128-row slots (ASR_GEMM_TN_CFG=8).  Stand-alone the 8-wave form is
-    // ~12 % faster (46 / 24 / 33 / 33 us vs 53 / 27 / 37 / 37 on the config-2 shapes), but this GEMM
-    // runs on the side stream BESIDE the dgrad / attention / LayerNorm chain, and two of its waves per
-    // SIMD take issue slots from that chain: the whole step is 2 % slower with it (A/B in one process:
-    // 8.10 vs 8.28 k utterances/s).  The step time decides.
     TnPlan pl;
-    pl.tn_cfg = tn_cfg;
-    pl.ring = ring;
-    pl.eight = ring == 4 && tn_cfg == 8;
-    const int gran = pl.eight ? 2 * TM : TM;          // rows per ring slot
-    pl.rows_per_split = ceil_div(ceil_div(M, splits), gran) * gran;
+    int splits;
+    const int s_floor = cus / tiles > 0 ? cus / tiles : 1;
+    if (tiles * s_floor * 5 >= cus * 4) { splits = s_floor; pl.ring = 3; }
+    else { splits = ceil_div(2 * cus, tiles) > 1 ? (2 * cus) / tiles : 1; pl.ring = 2; }
+    if (splits > max_s) splits = max_s;
+    if (splits < 1) splits = 1;
+    pl.rows_per_split = ceil_div(ceil_div(M, splits), TM) * TM;
     pl.nsplit = ceil_div(M, pl.rows_per_split);
     return pl;
 }
@@ -2532,8 +1349,7 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
     const int tiles_n = ceil_div(N, 128), tiles_k = ceil_div(K, 128), tiles = tiles_n * tiles_k;
     static const int tn_noatomic = unsafe_debug_env("ASR_GEMM_TN_NOATOMIC");   // timing experiments only (wrong results): debug builds only
     const TnPlan pl = tn_plan(M, N, K);
-    const int tn_cfg = pl.tn_cfg, ring = pl.ring, rows_per_split = pl.rows_per_split, nsplit = pl.nsplit;
-    const bool eight = pl.eight;
+    const int ring = pl.ring, rows_per_split = pl.rows_per_split, nsplit = pl.nsplit;
     // Deterministic mode: no atomics - each split stores its partial tile into its own slab of the workspace and
     // tn_slab_reduce_kernel adds the slabs in split order (also for a single split when accumulating into dW).
     const bool det = asr_deterministic() != 0;
@@ -2556,53 +1372,29 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
         zero_f32_kernel<<<g < 1024 ? g : 1024, 256, 0, st>>>(dW, N, K, ldw);
     }
     const int grid = tiles * nsplit;
-    // Staggered M-splits (default since round 3; tuning option "tn_cfg" = 3: equal splits): lengths r0 + skew * s, s = 0 .. nsplit - 1, from
-    // ~0.75 to ~1.25 of the mean (the spread, in percent of the mean, is the tuning option "spare", default 50), all multiples of the 64-row
-    // stage, covering M.  Every split ends by adding its 128 x 128 tile to memory with fp32 atomics (256 workgroups x 64 KiB = 16 MB per
-    // launch at the chip's 1.3 TB/s atomic rate): splits that finish one after the other put that traffic under the others' compute.
+    // Staggered M-splits: lengths r0 + skew * s, s = 0 .. nsplit - 1, from ~0.75 to ~1.25 of the mean, all multiples of the 64-row stage,
+    // covering M.  Every split ends by adding its 128 x 128 tile to memory with fp32 atomics (256 workgroups x 64 KiB = 16 MB per launch at
+    // the chip's 1.3 TB/s atomic rate): splits that finish one after the other put that traffic under the others' compute (step 3.326 ->
+    // 3.314 ms; a spread of 30 / 80 / 120 % of the mean: 3.328 / 3.376 / 3.459 against 3.305 at 50 %).
     int sk_r0 = rows_per_split, sk_skew = 0;
-    if (asr_option(ASR_OPT_TN_CFG) != 3 && nsplit >= 3 && !eight) {
-        const int spread = asr_option(ASR_OPT_SPARE) > 0 ? asr_option(ASR_OPT_SPARE) : 50;
-        sk_skew = (int)((long long)rows_per_split * spread / 100 / (nsplit - 1)) / TM * TM;
+    if (nsplit >= 3) {
+        sk_skew = (int)((long long)rows_per_split * 50 / 100 / (nsplit - 1)) / TM * TM;
         const int tri = nsplit * (nsplit - 1) / 2;
         sk_r0 = ceil_div(ceil_div(M - sk_skew * tri > 0 ? M - sk_skew * tri : M, nsplit), TM) * TM;
         if (sk_skew <= 0 || sk_r0 < 4 * TM || sk_r0 * (nsplit - 1) + sk_skew * ((nsplit - 1) * (nsplit - 2) / 2) >= M) { sk_r0 = rows_per_split; sk_skew = 0; }      // the last split must start inside the range
     }
-    if (tn_cfg == 1) {
-        if (dbias) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bias_bf16: the register-staged kernel (ASR_GEMM_TN_CFG=1) has no bias path");
-        gemm_tn_kernel<<<grid, 256, 0, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, split_stride);
-    } else {
-        static void* zero_page = nullptr;
-        if (!zero_page) {
-            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
-            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);
-            (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE);
-            if (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: zero page symbol not found");
-        }
-        // LDS footprint experiments: a 16-KiB pad (144 KiB) costs the training step 6 %, 30 KiB 12 % - the
-        // main stream's attention / LayerNorm workgroups no longer fit beside this kernel on a CU
-        static const int lds_pad = getenv("ASR_TN_LDS_PAD") ? atoi(getenv("ASR_TN_LDS_PAD")) : 0;
-        if (lds_pad && ring == 4 && !eight) {
-            static bool once = false;
-            if (!once) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSTAGE + lds_pad); once = true; }
-            gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE + lds_pad, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
-        } else if (tn_cfg == 2 && ring == 4) {   // 2-stage ring, 64 KiB, still one workgroup per CU
-            gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
-        } else if (tn_cfg != 4 && ring == 4 && !eight && asr_option(ASR_OPT_TN_CFG) == 1) {   // tuning option "tn_cfg" = 1: loader / consumer waves, 3-stage ring
-            static bool once_s = false;
-            if (!once_s) { (void)hipFuncSetAttribute((const void*)gemm_tn_spec_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); once_s = true; }
-            gemm_tn_spec_kernel<3><<<grid, 512, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
-        } else if (tn_cfg != 4 && ring == 4 && !eight) {   // default: 3-stage ring, 96 KiB (step 3.74 vs 3.79 ms with 4 stages = 128 KiB, although the kernel alone is 1-5 % slower)
-            static bool once3 = false;
-            if (!once3) { (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); once3 = true; }
-            int r0 = rows_per_split, skew = 0;
-            r0 = sk_r0; skew = sk_skew;
-            gemm_tn_dma_kernel<3, 1><<<grid, 256, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, r0, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride, skew);
-        } else
-        if (ring == 4 && !eight) gemm_tn_dma_kernel<4, 1><<<grid, 256, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
-        else if (ring == 4) gemm_tn_dma_kernel<2, 2><<<grid, 512, 4 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, rows_per_split, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride);
-        else gemm_tn_dma_kernel<2, 1><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, sk_r0, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride, sk_skew);
+    static void* zero_page = nullptr;
+    if (!zero_page) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE);
+        if (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_bf16: zero page symbol not found");
     }
+    // the ring is 3 stages = 96 KiB (one workgroup per CU) or 2 stages (two per CU): this kernel runs BESIDE the main stream, whose attention /
+    // LayerNorm workgroups need the rest of the CU's LDS (a 16-KiB pad on top of 128 KiB cost the training step 6 %, 30 KiB 12 %)
+    if (ring == 3)
+        gemm_tn_dma_kernel<3><<<grid, 256, 3 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, sk_r0, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride, sk_skew);
+    else
+        gemm_tn_dma_kernel<2><<<grid, 256, 2 * TSTAGE, st>>>((const bf16_t*)dY, (const bf16_t*)X, dW_k, M, N, K, ldy, ldx, ldw_k, tiles_k, tiles_n, sk_r0, use_atomic, zero_page, dbias_k, split_stride, bias_split_stride, sk_skew);
     if (det) {
         const size_t total4 = (size_t)N * K / 4;
         int g = (int)((total4 + 255) / 256);

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(LN_WAVES* WAVE) void add_ln_bwd_kernel(
 // forward: 1024 workgroups measured best (5.15 TB/s vs 3.9 at 512); backward: its grid is also the
 // number of partial rows the finalize pass has to sum
 static int ln_grid_fwd(int rows) {
-    static const int cap = getenv("ASR_LN_GRID_FWD") ? atoi(getenv("ASR_LN_GRID_FWD")) : 1024;
+    const int cap = 1024;
     int g = ceil_div(rows, LN_WAVES);
     return g < cap ? g : cap;
 }
@@ -311,7 +311,7 @@ static int ln_grid(int rows) {
     // round 1 (one row per wave and trip), stand-alone: 256 -> 29.7, 512 -> 21.3, 1024 -> 19.4, 2048 -> 23.5 us.  With two rows per
     // trip the step decides (tools/env_sweep.sh, ms per step): 256 -> 3.49, 384 -> 3.39, 512 -> 3.35, 1024 -> 3.38, 2048 -> 3.54
     // (half the partial sums to write and to reduce, and the kernel holds fewer CUs beside the weight-gradient stream)
-    static const int cap = getenv("ASR_LN_GRID") ? atoi(getenv("ASR_LN_GRID")) : 512;
+    const int cap = 512;
     int g = ceil_div(rows, LN_WAVES);
     return g < cap ? g : cap;
 }
@@ -421,7 +421,7 @@ extern "C" int asr_add_ln_bwd(const void* dy, const void* dy2, const void* xhat,
     const int ncols = dbias ? 3 * d : 2 * d;
     if (dgamma) {   // dgamma == dbeta == NULL: the partial sums stay in ws for asr_add_ln_bwd_reduce_batched
         // the partial rows are split between 4 workgroups per column group (atomic adds): 3.806 vs 3.830 ms per step
-        static const int fsplit = getenv("ASR_LN_FSPLIT") ? atoi(getenv("ASR_LN_FSPLIT")) : 4;
+        const int fsplit = 4;
         colsum_finalize_kernel<<<dim3(ceil_div(ncols, 32), (P >= 256 * fsplit && !asr_deterministic()) ? fsplit : 1), 1024, 0, st>>>((const float*)ws, P, (size_t)3 * d, ncols, d, dgamma, dbeta, dbias, 1);
     }
     ASR_CHECK_LAUNCH("asr_add_ln_bwd");

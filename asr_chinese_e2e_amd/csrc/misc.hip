@@ -34,25 +34,11 @@ extern "C" int asr_set_deterministic(int on) {
     return old;
 }
 
-// ---- tuning options: process-wide integer switches that select between CORRECT variants of a kernel (store policy, tile shape ...),
-// settable at run time so that two variants can be timed alternately inside one process (box-to-box noise is ~2 %).
-// Initial value: environment variable ASR_OPT_<NAME upper case>, else the built-in default.
-static const char* const g_opt_names[ASR_OPT_COUNT] = {"nt_store", "nt_tile", "tn_split", "sdpa_store", "tn_cfg", "spare", "cu_limit"};
-static int g_opt_val[ASR_OPT_COUNT];
-static bool g_opt_init = false;
-static void opt_init() {
-    if (g_opt_init) return;
-    static const int defaults[ASR_OPT_COUNT] = {ASR_OPT_NT_STORE_DEFAULT, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < ASR_OPT_COUNT; ++i) {
-        char env[64] = "ASR_OPT_";
-        size_t k = strlen(env);
-        for (const char* c = g_opt_names[i]; *c && k + 1 < sizeof(env); ++c) env[k++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
-        env[k] = 0;
-        const char* e = getenv(env);
-        g_opt_val[i] = e ? atoi(e) : defaults[i];
-    }
-    g_opt_init = true;
-}
+// ---- tuning options: process-wide integer switches under which every value gives correct results (asr_set_option).  ABI 8 keeps one,
+// "cu_limit" (gemm.hip: cu_count); the kernel-variant switches of rounds 2 - 3 left with the variants.
+static const char* const g_opt_names[ASR_OPT_COUNT] = {"cu_limit"};
+static int g_opt_val[ASR_OPT_COUNT] = {0};
+static void opt_init() {}
 int asr_option(int key) {
     opt_init();
     return (key >= 0 && key < ASR_OPT_COUNT) ? g_opt_val[key] : 0;
@@ -92,11 +78,8 @@ extern "C" int asr_last_error(char* buf, size_t n) {
 // Events that only order streams of THIS device: a device-scope release when the event is recorded / when the kernel it is bound to
 // completes (hipEventReleaseToDevice).  The default is a system-scope release - the L2 written back so that the host or another device
 // could look at the data - and the main queue started its next kernel ~5 us late after every kernel that carried such an event
-// (step timeline, round 3).  ASR_EVENT_SCOPE=system restores the default (A/B runs).
-static unsigned fork_event_flags() {
-    const char* e = getenv("ASR_EVENT_SCOPE");
-    return hipEventDisableTiming | ((e && !strcmp(e, "system")) ? 0u : hipEventReleaseToDevice);
-}
+// (step timeline, round 3).
+static unsigned fork_event_flags() { return hipEventDisableTiming | hipEventReleaseToDevice; }
 static hipEvent_t g_fork_events[256];
 static unsigned g_fork_next = 0;
 static bool g_fork_init = false;

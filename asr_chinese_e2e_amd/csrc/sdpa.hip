@@ -528,15 +528,11 @@ __device__ __forceinline__ void ff_wait_tiles(int younger) {      // at most `yo
     }
 }
 
-// BITS (with DROP): the keep decisions of every (key, 32-query block) also leave as one 32-bit word (bit = query inside the block) in
-// drop_bits[((b H + h) * ceil(Tq / 32) + block) * 512 + key] - the layout the fused backward kernel wants (key on the lane, queries in
-// registers), so that it reads one word per key and tile instead of hashing again (asr_sdpa_drop_bits).  The word of a key is the lane
-// mask of the compare this kernel makes anyway; v_writelane moves the 64 masks of a tile onto the 64 lanes for one coalesced store.
-template <bool DROP, bool MASKED, bool BITS = false>
+template <bool DROP, bool MASKED>
 __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                          bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
                                                                          int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
-                                                                         uint32_t dseed, uint32_t dthr, float dscale, uint32_t* __restrict__ drop_bits = nullptr) {
+                                                                         uint32_t dseed, uint32_t dthr, float dscale) {
     extern __shared__ __attribute__((aligned(1024))) char smem_ff[];
     const char* Kimg = smem_ff;
     const char* Vimg = smem_ff + FF_IMG;
@@ -736,7 +732,6 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
                 if constexpr (DROP) {
                     l += ps0 + ps1;      // the sum is over the un-dropped P: VALU adds here
                     const uint32_t rowbase = (((uint32_t)(b * H + h)) * Tq + min(qi, Tq - 1)) * ((Tk + 1) & ~1);
-                    int vword = 0;      // BITS: lane = key of the tile, bit = query of this 32-query block
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -745,18 +740,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
                             const bool ka = drop_keep(hsh, 0, dthr), kb = drop_keep(hsh, 1, dthr);
                             st[sub][i] = ka ? st[sub][i] * dscale : 0.f;
                             st[sub][i + 1] = kb ? st[sub][i + 1] * dscale : 0.f;
-                            if constexpr (BITS) {      // lanes 0..31 hold key (i & 3) + 8 (i >> 2) of the sub-block, lanes 32..63 that key + 4
-                                // (s_nop 1: on gfx950 a vector instruction may read an SGPR / VCC that a vector compare wrote only two
-                                // wait states later, and the compiler's hazard pass cannot see into the asm)
-                                const unsigned long long ba = __ballot(ka), bb = __ballot(kb);
-                                const int key = 32 * sub + (i & 3) + 8 * (i >> 2);
-                                asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(vword) : "s"((uint32_t)ba), "n"(key));
-                                asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(vword) : "s"((uint32_t)(ba >> 32)), "n"(key + 4));
-                                asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(vword) : "s"((uint32_t)bb), "n"(key + 1));
-                                asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(vword) : "s"((uint32_t)(bb >> 32)), "n"(key + 5));
-                            }
                         }
-                    if constexpr (BITS) drop_bits[((size_t)bh * ((Tq + 31) >> 5) + (q0 >> 5)) * FF_KEYS + k0 + lane] = (uint32_t)vword;
                 }
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -862,14 +846,13 @@ __device__ __forceinline__ uint32_t scale_bf16_pair(uint32_t x, float f) {
     return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
 }
 
-template <bool DROP, bool MASKED, bool BAND = false, bool BITS = false>
+template <bool DROP, bool MASKED, bool BAND = false>
 __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                          const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const float* __restrict__ lse,
                                                                          bf16_t* __restrict__ dq, bf16_t* __restrict__ dk_, bf16_t* __restrict__ dv,
                                                                          const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                                                                          int causal, int window, float scale, uint32_t dseed, uint32_t dthr, float dscale,
-                                                                         float* __restrict__ halo = nullptr, int halo_slots = 0,
-                                                                         const uint32_t* __restrict__ drop_bits = nullptr) {
+                                                                         float* __restrict__ halo = nullptr, int halo_slots = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_fb[];
     // BAND (self-attention inside a +-window band over MORE keys than one workgroup holds: the long-form configuration, T = 2000):
     // blockIdx.y = key block of FB_KEYS keys.  The workgroup owns the dK / dV of its keys and walks only the query tiles whose band
@@ -1006,8 +989,6 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         for (int kbk = 0; kbk < 2; ++kbk) {
             const int key0 = kk0 + 32 * kbk, kj = key0 + kjl;
             const float* s_lk = kj < klen ? s_l : s_neg;      // padded keys: p = 0 without a test per element
-            uint32_t kbits = 0u;
-            if constexpr (DROP && BITS) kbits = drop_bits[((size_t)bh * ((Tq + 31) >> 5) + t) * FB_KEYS + kj] >> (4 * hh);      // this lane's queries: acc_row = .. + 4 hh
             f32x16 st, dp;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -1041,7 +1022,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                 // neighbouring lanes here - each lane hashes for one of two consecutive queries and takes the other from its
                 // neighbour (8 hashes + 8 lane swaps per 16 elements instead of 16 hashes: 3 integer multiplies each)
                 uint32_t hsh[4] = {0u, 0u, 0u, 0u};
-                if (DROP && !BITS) {
+                if (DROP) {
                     const uint32_t kcl = (uint32_t)min(kblk0 + kj, Tkg - 1), tkp = (uint32_t)((Tkg + 1) & ~1), bhq = ((uint32_t)(b * H + h)) * Tq;
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
@@ -1058,8 +1039,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                     const int i = 4 * g4 + e;
                     const float p = __builtin_amdgcn_exp2f(st[i]);
                     if (DROP) {
-                        // BITS: the forward kernel's decision, bit (query inside the tile) of this key's word
-                        const float keepf = (BITS ? ((kbits >> ((i & 3) + 8 * (i >> 2))) & 1u) != 0u : drop_keep(hsh[e], min(kblk0 + kj, Tkg - 1) & 1, dthr)) ? dscale : 0.f;
+                        const float keepf = drop_keep(hsh[e], min(kblk0 + kj, Tkg - 1) & 1, dthr) ? dscale : 0.f;
                         dp[i] = p * (dp[i] * keepf + d4[e]);     // dS / scale (d4 = -delta)
                         st[i] = p * keepf;                       // dropped probabilities feed dV
                     } else {
@@ -1372,39 +1352,6 @@ static int check_common(const char* name, int B, int H, int Tq, int Tk, int dk, 
 
 }  // namespace
 
-// Keep mask of the attention dropout handed from the forward to the backward kernel as bits (asr_sdpa_drop_bits): the buffer given here
-// is used by the NEXT asr_sdpa_fwd (written) or asr_sdpa_bwd (read) call and then forgotten.
-static void* g_drop_bits = nullptr;
-static size_t g_drop_bits_bytes = 0;
-extern "C" size_t asr_sdpa_drop_bits_bytes(int B, int H, int Tq, int Tk, int dk, int dtype) {
-    if (dtype != ASR_BF16 || dk != DK || Tk > FF_KEYS || Tk > FB_KEYS || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;      // both fused kernels must take the shape
-    static const int fwd_tiled = getenv("ASR_SDPA_FWD_TILED") ? atoi(getenv("ASR_SDPA_FWD_TILED")) : 0;
-    static const int bwd_split = getenv("ASR_SDPA_BWD_SPLIT") ? atoi(getenv("ASR_SDPA_BWD_SPLIT")) : 0;
-    if (fwd_tiled || bwd_split) return 0;
-    return (size_t)B * H * ((Tq + 31) / 32) * FF_KEYS * sizeof(uint32_t);
-}
-extern "C" int asr_sdpa_drop_bits(void* bits, size_t bytes) {
-    if (bits && ((uintptr_t)bits % 4)) ASR_FAIL(ASR_EINVAL, "asr_sdpa_drop_bits: misaligned buffer");
-    g_drop_bits = bits;
-    g_drop_bits_bytes = bits ? bytes : 0;
-    return ASR_OK;
-}
-static uint32_t* take_drop_bits(const char* who, int B, int H, int Tq, int Tk, int dk, int dtype, bool fused, uint32_t dthr, int* rc) {
-    void* p = g_drop_bits;
-    const size_t n = g_drop_bits_bytes;
-    g_drop_bits = nullptr;
-    g_drop_bits_bytes = 0;
-    *rc = ASR_OK;
-    if (!p || !dthr) return nullptr;      // no buffer, or no dropout: nothing to hand over
-    const size_t need = asr_sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, dtype);
-    if (!fused || !need || n < need) {
-        asr_set_error("%s: a dropout bit buffer was given (asr_sdpa_drop_bits, %zu bytes) but this call cannot use it (needs the fused kernel and %zu bytes)", who, n, need);
-        *rc = ASR_EINVAL;
-        return nullptr;
-    }
-    return (uint32_t*)p;
-}
-
 extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* k_len, int B, int H, int Tq, int Tk, int dk,
                             int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale, float drop_p, uint32_t dseed, int dtype,
                             void* stream) {
@@ -1415,16 +1362,10 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
     const uint32_t dthr = drop_thr16(drop_p);
     const float dscale = 1.f / (1.f - drop_p);
     hipStream_t st = (hipStream_t)stream;
-    static const int fwd_tiled = getenv("ASR_SDPA_FWD_TILED") ? atoi(getenv("ASR_SDPA_FWD_TILED")) : 0;   // 1: the register-staged tile kernel for every shape (A/B runs)
-    const bool ff_fused = dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o) && Tk <= FF_KEYS && !fwd_tiled;
-    int rc_bits;
-    uint32_t* bits = take_drop_bits("asr_sdpa_fwd", B, H, Tq, Tk, dk, dtype, ff_fused, dthr, &rc_bits);
-    if (rc_bits) return rc_bits;
+    const bool ff_fused = dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o) && Tk <= FF_KEYS;      // else (more keys than LDS holds): the tiled kernel of round 1
     if (ff_fused) {   // K and V of a head fit LDS: one workgroup per (b, h)
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
-            (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
@@ -1433,9 +1374,7 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
         }
 #define FF_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
         const bool masked = causal || window >= 0;
-        if (bits && masked) sdpa_fwd_fused_bf16_kernel<true, true, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS, bits);
-        else if (bits) sdpa_fwd_fused_bf16_kernel<true, false, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS, bits);
-        else if (dthr && masked) sdpa_fwd_fused_bf16_kernel<true, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
+        if (dthr && masked) sdpa_fwd_fused_bf16_kernel<true, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (dthr) sdpa_fwd_fused_bf16_kernel<true, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (masked) sdpa_fwd_fused_bf16_kernel<false, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else sdpa_fwd_fused_bf16_kernel<false, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
@@ -1490,16 +1429,10 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         if (dtype == ASR_F32) sdpa_delta_kernel<float><<<ceil_div(ngroups, 32), 256, 0, st>>>((const float*)o, (const float*)d_o, delta, B, H, Tq, dk, ldo);
         else sdpa_delta_kernel<bf16_t><<<ceil_div(ngroups, 32), 256, 0, st>>>((const bf16_t*)o, (const bf16_t*)d_o, delta, B, H, Tq, dk, ldo);
     }
-    static const int bwd_split = getenv("ASR_SDPA_BWD_SPLIT") ? atoi(getenv("ASR_SDPA_BWD_SPLIT")) : 0;   // 1: the dQ + dK/dV kernel pair for every shape (A/B runs)
-    const bool fb_fused = mfma && Tk <= FB_KEYS && !bwd_split;
-    int rc_bits;
-    const uint32_t* bits = take_drop_bits("asr_sdpa_bwd", B, H, Tq, Tk, dk, dtype, fb_fused, dthr, &rc_bits);
-    if (rc_bits) return rc_bits;
+    const bool fb_fused = mfma && Tk <= FB_KEYS;      // else: the band kernel (windowed attention over many keys) or the dQ + dK/dV pair of round 1
     if (fb_fused) {   // every key of a head fits one workgroup: single-pass backward
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
-            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
@@ -1509,15 +1442,12 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
 #define FB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
         const bool masked = causal || window >= 0;
         // the only kernel of this path: it may carry an armed completion event (asr_stream_arm)
-        const uint32_t* nobits = nullptr;
-        if (bits && masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, true, false, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0, bits);
-        else if (bits) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, false, false, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0, bits);
-        else if (dthr && masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0, nobits);
-        else if (dthr) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0, nobits);
-        else if (masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0, nobits);
-        else asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0, nobits);
+        if (dthr && masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
+        else if (dthr) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
+        else if (masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
+        else asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
 #undef FB_ARGS
-    } else if (mfma && !bwd_split && sdpa_band_shape(Tq, Tk, dk, causal, window, dtype) && delta_bytes >= asr_sdpa_bwd_workspace_bytes(B, H, Tq, Tk, dk, causal, window, dtype)
+    } else if (mfma && sdpa_band_shape(Tq, Tk, dk, causal, window, dtype) && delta_bytes >= asr_sdpa_bwd_workspace_bytes(B, H, Tq, Tk, dk, causal, window, dtype)
                && ((uintptr_t)delta % 16) == 0) {
         // long-form band: one workgroup per (b, h, 512-key block), single pass; dQ of the tiles on a block boundary through fp32 slabs
         static bool attr_b = false;

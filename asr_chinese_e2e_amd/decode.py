@@ -19,6 +19,10 @@ import torch
 
 from . import kernels as K
 
+# cross attention of the beam search on the training attention kernel (all beams of an utterance as Tq = beam queries against the same K / V:
+# 11 us) instead of the single-query decode kernel (one wave per (hypothesis, head): ~220 us per layer and step); False: the latter (tests)
+USE_SDPA = True
+
 SOS_ID, EOS_ID = 2, 3   # transformer_official.py:53-54
 BLANK_ID = 0            # CTC blank = <pad>, as in the training loss
 
@@ -68,7 +72,7 @@ def _search(model, eng, input, beam, nbest, decode_max_len, check_every):
     row_bytes = 2 * hd * caches[0].element_size()
     cur = 0
     steps_done = 0
-    use_sdpa = dk == 64 and eng.dtype == torch.bfloat16 and os.environ.get("ASR_DECODE_SDPA", "1") == "1"
+    use_sdpa = dk == 64 and eng.dtype == torch.bfloat16 and USE_SDPA
     o_buf = torch.empty(R, hd, dtype=eng.dtype, device=dev) if use_sdpa else None
     lse_buf = None
     for i in range(Lcap):

@@ -90,8 +90,7 @@ class GradBucketer:
         self.cuda = flat_g.is_cuda
         # NORMAL priority: a high-priority HIP stream (priority=-1) next to the two compute streams
         # doubled the step time on MI355X / ROCm 7 (11.0 vs 5.2 ms, measured with one rank)
-        prio = int(os.environ.get("ASR_COMM_PRIORITY", "0"))
-        self.comm_stream = torch.cuda.Stream(priority=prio) if self.cuda else None
+        self.comm_stream = torch.cuda.Stream() if self.cuda else None
         self.wire = None
         if wire_dtype is not None and wire_dtype != flat_g.dtype:
             if not self.cuda:

@@ -133,7 +133,7 @@ class Linear:
         return sub
 
     # ---- forward
-    SMALL_M = int(os.environ.get("ASR_SMALL_M", "1024"))      # rows up to which the 64 x 64-tile kernel serves a projection (the decoder's B*To)
+    SMALL_M = 1024      # rows up to which the 64 x 64-tile kernel serves a projection (the decoder's B*To)
     SMALL_REDUCE = 8192      # longest reduction it takes (the tied output projection's input gradient reduces over V = 4232)
 
     def small(self, x, reduce_len):
@@ -276,20 +276,18 @@ def _shared_stream(device, kind):
     their steps one after the other, so sharing costs nothing."""
     key = (torch.device(device).index, kind)
     if key not in _STREAMS:
-        # "aux" (the CTC branch / cross-attention K|V work beside the decoder): ASR_AUX_PRIORITY=low puts it at the lowest priority too
-        low = kind == "wgrad" or os.environ.get("ASR_AUX_PRIORITY", "normal") == "low"
-        _STREAMS[key] = _side_stream(device) if low else torch.cuda.Stream(device=device)
+        # "wgrad": lowest priority (off the critical path); "aux" (the CTC branch / cross-attention K|V work beside the decoder): normal
+        # (at the lowest priority too: 5.49 vs 5.48 ms, nothing)
+        _STREAMS[key] = _side_stream(device) if kind == "wgrad" else torch.cuda.Stream(device=device)
     return _STREAMS[key]
 
 
 def _side_stream(device):
-    """The weight-gradient stream.  ASR_SIDE_PRIORITY=low (default) creates it at the LOWEST HIP stream priority: its
+    """The weight-gradient stream, at the LOWEST HIP stream priority: its
     GEMMs are off the critical path, and at equal priority they take CUs from the dgrad / attention / LayerNorm chain
     whenever both have workgroups pending (the LayerNorm backward ran 30 us beside them against 14 us alone).
     torch.cuda.Stream only offers normal / high, so the stream comes from asr_stream_create (the HIP runtime the library and
     torch share) and is wrapped as an ExternalStream (host plumbing; it lives as long as the process)."""
-    if os.environ.get("ASR_SIDE_PRIORITY", "low") != "low":
-        return torch.cuda.Stream(device=device)
     import ctypes
     from . import _lib
     with torch.cuda.device(device):
@@ -302,6 +300,7 @@ def _side_stream(device):
 
 class Engine:
     """Forward + backward of encoder (+ decoder) (+ CTC head) for one minibatch on one GPU."""
+    PAD_HEAD_ROWS = True      # rows of the CTC head's logits / gradient on whole 128-byte lines (see self.ld_v)
 
     def __init__(self, flat, cfg, vocab_size, use_decoder, use_ctc, pe):
         self.flat, self.cfg = flat, cfg
@@ -330,9 +329,9 @@ class Engine:
         # row stride of the CTC head's logits / gradient rows in the training step: whole 128-byte lines (bf16: multiples of 64
         # elements; V = 4232 -> 4288).  With dense rows of 8464 B every row of a GEMM tile straddles one line more and shares
         # its first and last line with the neighbouring tiles: head GEMM 110 -> 94 us, its input gradient 87 -> 76 us
-        # (tools/gemm_bench.py pad).  ASR_PAD_LOGITS=0: dense rows.
+        # (tools/gemm_bench.py pad).  Engine.PAD_HEAD_ROWS = False: dense rows (tests).
         self.ld_v = vocab_size
-        if self.dtype == torch.bfloat16 and vocab_size % 8 == 0 and os.environ.get("ASR_PAD_LOGITS", "1") != "0":
+        if self.dtype == torch.bfloat16 and vocab_size % 8 == 0 and self.PAD_HEAD_ROWS:
             self.ld_v = (vocab_size + 63) // 64 * 64
         self.grad_ready = None  # callback(offset): gradients at flat offsets >= offset are final
         # Input gradients dX = dY W of the encoder projections run on the own persistent NT kernel, as NT products with
@@ -376,12 +375,12 @@ class Engine:
         # off in deterministic mode (the weight gradients then share one scratch buffer on whatever stream is current)
         self.ctc_stream = _shared_stream(flat.device, "aux")
         self.ws_ctc = K.Workspace(flat.device)
-        self.overlap_ctc = os.environ.get("ASR_CTC_OVERLAP", "1") == "1"
-        self.aux_overlap = os.environ.get("ASR_AUX_OVERLAP", "1") == "1" and not K.deterministic()   # cross-attention K|V work on that stream too
         self.side = _shared_stream(flat.device, "wgrad")
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
-        self.overlap_wgrad = os.environ.get("ASR_WGRAD_OVERLAP", "1") == "1"      # 0: weight gradients on the main stream (A/B runs)
+        # ---- environment switches of the engine (all read here, when the engine is built; the complete list is in README.md):
+        # ASR_WGRAD_OVERLAP=0: ONE stream - weight gradients, the CTC branch and the cross-attention K|V work stay on the main stream
+        self.overlap_wgrad = os.environ.get("ASR_WGRAD_OVERLAP", "1") == "1"
         # Deterministic mode (kernels.set_deterministic / ASR_DETERMINISTIC=1, read when the engine is built): every
         # gradient reduction runs in a fixed order.  The weight gradients then stay on the main stream (the tied
         # embedding / projection weight is updated by plain read-modify-writes of two kernels, which must not overlap),
@@ -389,11 +388,15 @@ class Engine:
         self.deterministic = K.deterministic()
         if self.deterministic:
             self.overlap_wgrad = False
+        # the CTC branch of the joint model beside the decoder's forward pass (ctc_branch_async), and the cross-attention K|V projections /
+        # their input gradients, on the auxiliary stream: with the weight-gradient overlap (off in deterministic mode: the weight gradients
+        # then share one scratch buffer on whatever stream is current)
+        self.overlap_ctc = self.aux_overlap = self.overlap_wgrad
         # ASR_WGRAD_GROUP: "decoder" (default): the seven weight gradients of a DECODER layer (self-attention, cross
         # attention incl. the K|V projection of all encoder frames, feed-forward) go out as ONE grouped GEMM
         # (asr_gemm_tn_grouped_bf16) - the decoder's main stream is a chain of small launches (B*To rows) that
         # leaves the GPU to the side stream: joint config 6.19 -> 6.02 ms; the ENCODER keeps one launch per
-        # projection, as soon as its dY exists.  "0": never group; "layer" / "block" / "hybrid": group everywhere,
+        # projection, as soon as its dY exists.  "0": never group; "layer" / "block": group everywhere,
         # per layer / per attention or feed-forward block.  The grouped kernel is 1.6x faster alone (98 vs 160 us
         # per config-2 layer) but one 100-us launch filling every CU overlaps worse with the main stream than
         # four short ones spread over the layer: step 3.84 (layer) / 3.96 (block) vs 3.79 ms, joint 6.27 vs 6.16.
@@ -409,7 +412,6 @@ class Engine:
         # within 1 % of each other; 0 = the whole device).  The head's weight gradient queued BEHIND its input gradient on the auxiliary stream
         # instead of beside it on the weight-gradient stream: 4.880 vs 4.853 ms - not kept.
         self.dec_cu_limit = int(os.environ.get("ASR_DEC_CU_LIMIT", "192"))
-        self.kv_first = os.environ.get("ASR_KV_FIRST", "1") == "1"      # cross-attention K|V projections ahead of the CTC branch (decoder_kv_async)
         self._kv_ahead = None
         self._pending = []
         self._deferred = []
@@ -421,23 +423,11 @@ class Engine:
         # than under 30).  Holding references costs nothing (the blocks are the step's own) and makes the allocation sequence
         # of every step identical from the second step on.
         self._keep = []
+        # ASR_WGRAD_DEFER (default "fc"): projections whose weight gradient is held back until the layer's attention backward is launched (_wgrad)
         self.defer_wgrad = tuple(t for t in os.environ.get("ASR_WGRAD_DEFER", "fc").split(",") if t)
-        self._defer_point = os.environ.get("ASR_WGRAD_DEFER_POINT", "before")      # release before / after the attention backward launch
-        self.fuse_relu_bwd = os.environ.get("ASR_FUSE_RELU_BWD", "1") == "1"
-        self.armed_fork = os.environ.get("ASR_ARMED_FORK", "1") == "1"      # see _arm
-        # attention dropout: keep mask handed to the backward kernel as bits (asr_sdpa_drop_bits) instead of hashed again there.  Opt-in:
-        # the backward gains 10 us (104 -> 94 stand-alone) but the forward pays 4.5 (48.2 -> 52.7: 64 v_writelane per tile move the
-        # compares' lane masks onto the lanes) and is not overlapped with anything: step 3.521 vs 3.504 ms at dropout 0.1
-        self.drop_bits = os.environ.get("ASR_DROP_BITS", "0") == "1"
+        self.armed_fork = os.environ.get("ASR_ARMED_FORK", "1") == "1"      # hand-overs by the producer kernel's own completion event (_arm)
         self._armed = False
         self._arm_covers_pending = False      # set by _dec_exec_bwd while it collects a layer's weight gradients behind its armed last kernel
-        # ReLU mask of the encoder FFN as one bit per element (see _relu_bits): opt-in.  The w_2 input gradient then reads 2 MB instead of
-        # the 32-MB activation tensor, but the step is 1 % SLOWER (3.128 vs 3.097 ms, joint 5.150 vs 5.110; A/B in one process): the
-        # weight-gradient GEMM on the side stream streams the same tensor at the same time, so the second reader was nearly free, and
-        # the bit packing costs the forward's store tail more than the backward saves
-        self.relu_bits = os.environ.get("ASR_RELU_BITS", "0") == "1"
-        self.batch_ln_reduce = os.environ.get("ASR_LN_BATCH", "1") == "1"
-        self.fuse_ln = os.environ.get("ASR_FUSE_LN", "0") == "1"   # measured: no gain inside the step (see _fuse_ln), so off by default
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
         self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
@@ -455,17 +445,6 @@ class Engine:
         if not self.training or self.drop_p <= 0.0:
             return 0.0, 0
         return self.drop_p, (self.step_seed * 0x9E3779B1 + site * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF
-
-    def _fuse_ln(self, lin, a, res, drop_p):
-        """Projection + residual + LayerNorm as ONE kernel (asr_gemm_nt_add_ln_bf16): bf16, d_model = 512, no dropout at the site,
-        enough rows to fill the GPU with 64-row workgroups.  At config 2 the fused kernel takes 24.4 us against 15.2 + 12.1 us for
-        the out-projection (33.0 against 22.2 + 12.1 for w_2): it saves the write + read of the projection output (32 MB of the
-        96 MB the pair moves); the rest of the LayerNorm traffic (residual in, y and xhat out) is inherent, and a 64 x 512 tile
-        streams the whole weight matrix per 64 rows (1.5 x the L2 -> LDS traffic of the 256 x 128 tiling, which runs at the
-        ~67 GB/s per CU the L2 delivers).  Inside the training step the gain vanishes (3.360 vs 3.350 ms, two A/B pairs on one
-        box), so the two-kernel path stays the default; ASR_FUSE_LN=1 selects the fused kernel."""
-        return (self.fuse_ln and drop_p <= 0.0 and lin.wlp is not None and lin.N == 512 and a.shape[0] >= 4096 and res.dtype == torch.bfloat16
-                and K.gemm_nt_add_ln_supported(a, lin.wlp, res))
 
     def _ready(self, name):
         """Gradients at flat offsets >= this tensor's offset are final once the work queued so far
@@ -485,8 +464,6 @@ class Engine:
         launched per site: the partial sums go to a buffer owned by the site and ONE batched launch reduces all
         pending sites (flush_ln_reduce: per layer when gradients are all-reduced as they become final, otherwise once
         at the end of backward) - each of the 13 small launches cost ~5 us of dispatch and drain."""
-        if not self.batch_ln_reduce:
-            return K.add_ln_bwd(dy, dy2, xhat, rstd, ln.g, lens, ln.gg, ln.gb, dbias, B, T, self.ws, **kw)
         d = xhat.shape[-1]
         need = K.add_ln_bwd_workspace_bytes(B * T, d)
         part = self._ln_part.get(id(ln))
@@ -574,9 +551,10 @@ class Engine:
         self.flat.lpT_version = self.flat.version
 
     def wait_transposes(self):
+        """The current stream waits for this step's transposed weight copies (every stream that multiplies by them calls it: the main
+        stream in front of the backward pass, the auxiliary stream in front of the CTC head's input gradient)."""
         if self._tr_tiles is not None and self._tr_pending:
             torch.cuda.current_stream().wait_event(self._tr_event)
-            self._tr_pending = False
 
     def join_side(self):
         """Main stream waits for every weight-gradient kernel issued so far."""
@@ -680,18 +658,9 @@ class Engine:
             c["q"], c["kv"] = q, kv
         pa, sa = self._drop(site)          # attention probabilities (attention.py:83)
         pf, sf = self._drop(site + 1)      # after fc, before residual + LN (attention.py:59)
-        dbits = None
-        if pa > 0.0 and self.drop_bits:      # the keep mask goes to the backward kernel as bits (it then does not hash again)
-            nb = K.sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, q.dtype)
-            if nb and q.shape[0] * H >= 4096:      # encoder-sized attention only: for the decoder's few rows the hash is cheaper than 8 MB of words
-                dbits = torch.empty(nb, dtype=torch.uint8, device=q.device)
-        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa, drop_bits=dbits)
-        c["drop_bits"] = dbits
-        if self._fuse_ln(m.fc, ctx, x, pf):      # out-projection + residual + LayerNorm in one kernel
-            y, xhat, rstd = K.gemm_nt_add_ln(ctx, m.fc.wlp, m.fc.b32, x, m.ln.g, m.ln.b, q_lens, B, Tq)
-        else:
-            a = m.fc.fwd(ctx)
-            y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)
+        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa)
+        a = m.fc.fwd(ctx)
+        y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)
         c.update(x=x, kv_src=kv_src, ctx=ctx, lse=lse, xhat=xhat, rstd=rstd, k_len=k_len, q_lens=q_lens, dims=(B, Tq, Tk), causal=causal,
                  window=window, cross=cross, drop=(pa, sa, pf, sf))
         return y, c
@@ -708,20 +677,17 @@ class Engine:
             self._arm()
         dz, dxg = self._ln_bwd(m.ln, m.fc.gb, dy, dy2, c["xhat"], c["rstd"], c["q_lens"], B, Tq, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(m.fc, dxg, c["ctx"])
-        if fc_deferred and not c["cross"] and self._defer_point != "after" and m.fc.own_dgrad(dxg):
+        if fc_deferred and not c["cross"] and m.fc.own_dgrad(dxg):
             self._arm()      # the held-back weight gradient is released right behind this input-gradient GEMM: its completion is the hand-over
         dctx = m.fc.dgrad(dxg)
         if not c["cross"]:
             qkv = c["qkv"]
             dqkv = torch.empty_like(qkv)
-            if self._defer_point != "after":
-                self._release_deferred()
+            self._release_deferred()      # before the attention launch (after it: 3.59 vs 3.50 ms)
             self._disarm()      # nothing was released: the arm must not leak into the attention kernel's launch
             self._arm()
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
-                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa, drop_bits=c.get("drop_bits"))
-            if self._defer_point == "after":
-                self._release_deferred()
+                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa)
             self._wgrad(m.qkv, dqkv, c["x"], bias_from=dqkv)
             dx = m.qkv.dgrad(dqkv)
         else:
@@ -729,7 +695,7 @@ class Engine:
             dq = torch.empty_like(q)
             dkv = torch.empty_like(kv)
             K.sdpa_bwd(q, kv[:, :hd], kv[:, hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk, dq, dkv[:, :hd], dkv[:, hd:],
-                       c["causal"], c["window"], drop_p=pa, drop_seed=sa, drop_bits=c.get("drop_bits"))
+                       c["causal"], c["window"], drop_p=pa, drop_seed=sa)
             self._wgrad(m.q, dq, c["x"], bias_from=dq)
             self._wgrad(m.kv, dkv, c["kv_src"], bias_from=dkv)
             dx = m.q.dgrad(dq)
@@ -747,31 +713,12 @@ class Engine:
             self.flush_wgrads()
         return dx, dz
 
-    def _relu_bits(self, f, x):
-        """Byte size of the ReLU bit mask when the feed-forward pair can keep it as bits (asr_gemm_nt_relu_bits_bf16: the loader /
-        consumer NT kernel on both sides - many rows, bf16, aligned operands, transposed copy of w_2 present), else 0."""
-        if not (self.relu_bits and self.fuse_relu_bwd and x.dtype == torch.bfloat16 and x.shape[0] >= 4096 and f.w2.wlpT is not None
-                and not f.w1.small(x, f.w1.K) and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
-            return 0
-        M = x.shape[0]
-        n = K.relu_bits_bytes(M, f.w1.N, f.w1.K)
-        return n if n and n == K.relu_bits_bytes(M, f.w1.N, f.w2.N) else 0      # forward reduces over d, backward over w_2's outputs: both must have the form
-
     def _ffn_block_fwd(self, f, x, B, T, lens, site):
-        nbits = self._relu_bits(f, x)
-        bits = None
-        if nbits:      # ReLU mask as one bit per element, written by the w_1 GEMM's store tail (2 MB instead of re-reading h in the backward pass)
-            bits = torch.empty(nbits, dtype=torch.uint8, device=x.device)
-            h = K.gemm_nt_relu_bits(x, f.w1.wlp, f.w1.b32, bits, torch.empty(x.shape[0], f.w1.N, dtype=x.dtype, device=x.device))
-        else:
-            h = f.w1.fwd(x, act=ACT_RELU)
+        h = f.w1.fwd(x, act=ACT_RELU)
         pf, sf = self._drop(site)          # after w_2, before residual + LN (module.py:73)
-        if self._fuse_ln(f.w2, h, x, pf):
-            y, xhat, rstd = K.gemm_nt_add_ln(h, f.w2.wlp, f.w2.b32, x, f.ln.g, f.ln.b, lens, B, T)
-        else:
-            o = f.w2.fwd(h)
-            y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o, drop_p=pf, drop_seed=sf, drop_mode=1)
-        return y, dict(x=x, h=h, bits=bits, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T), drop=(pf, sf))
+        o = f.w2.fwd(h)
+        y, xhat, rstd = K.add_ln_fwd(o, x, f.ln.g, f.ln.b, None, lens, B, T, xhat=o, drop_p=pf, drop_seed=sf, drop_mode=1)
+        return y, dict(x=x, h=h, xhat=xhat, rstd=rstd, lens=lens, dims=(B, T), drop=(pf, sf))
 
     def _ffn_block_bwd(self, f, c, dy, dy2):
         B, T = c["dims"]
@@ -779,15 +726,11 @@ class Engine:
         self._arm()
         dz, dxg = self._ln_bwd(f.ln, f.w2.gb, dy, dy2, c["xhat"], c["rstd"], c["lens"], B, T, drop_p=pf, drop_seed=sf, drop_mode=1)
         self._wgrad(f.w2, dxg, c["h"])
-        fused_relu = self.fuse_relu_bwd and (f.w2.own_dgrad(dxg) or f.w2.small(dxg, f.w2.N) or dxg.dtype == torch.float32) and c["h"].is_contiguous() \
-            and c["h"].data_ptr() % 16 == 0
+        # ReLU backward in the store tail of the input-gradient GEMM (every kernel that takes the shape has that tail; else a masking pass)
+        fused_relu = (f.w2.own_dgrad(dxg) or f.w2.small(dxg, f.w2.N) or dxg.dtype == torch.float32) and c["h"].is_contiguous() and c["h"].data_ptr() % 16 == 0
         if fused_relu and f.w2.own_dgrad(dxg):      # dh then comes out of ONE launch of the NT kernel
             self._arm()
-        if c.get("bits") is not None and fused_relu and f.w2.own_dgrad(dxg):
-            f.w2._fresh_transpose()
-            dh = K.gemm_nt_relu_bits(dxg, f.w2.wlpT, None, c["bits"], torch.empty(dxg.shape[0], f.w2.K, dtype=dxg.dtype, device=dxg.device), backward=True)
-        else:
-            dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)     # ReLU backward in the GEMM's store tail
+        dh = f.w2.dgrad(dxg, relu_mask=c["h"] if fused_relu else None)
         fused = f.w1.fused_bias_wgrad(dh, c["x"])      # then the w_1 bias gradient comes out of its weight-gradient GEMM
         if not fused_relu:
             self._disarm()      # dh is finished by the masking kernel below, not by the (possibly armed) GEMM above
@@ -827,8 +770,6 @@ class Engine:
         for i in reversed(range(self.L)):
             mha, ffn = self.enc[i]
             c1, c2 = cache["layers"][i]
-            if i == 0 and self.group_wgrad == "hybrid":      # nothing left to hide a whole layer's launch behind
-                self._block_flush = True
             dx, dz = self._ffn_block_bwd(ffn, c2, dy, dy2)
             if i == 0:      # finer mark inside the last layer: its feed-forward gradients can leave while attention runs
                 self._ready(self.tail_mark_name())
@@ -874,16 +815,18 @@ class Engine:
     def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None, ws=None):
         """Returns (nll (B,), d_enc contribution or None)."""
         buf = torch.empty(B * T, self.ld_v, dtype=enc.dtype, device=enc.device)      # rows padded to whole lines (see self.ld_v)
+        ws = ws if ws is not None else self.ws
         logits = self.ctc_lo.fwd(enc, out=buf[:, :self.V])
         frames = buf.view(B, T, self.ld_v)[:, :, :self.V]
         if want_grad:
             self._arm()      # the head's weight gradient follows the loss kernels directly
-        nll, dl = K.ctc_fwd_bwd(frames, wave_len, labels32, lab_len, ws if ws is not None else self.ws, blank=0, grad_scale=grad_scale,
+        nll, dl = K.ctc_fwd_bwd(frames, wave_len, labels32, lab_len, ws, blank=0, grad_scale=grad_scale,
                                 dlogits=frames if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div)
         if not want_grad:
             return nll, None
         dl = logits      # the gradient was written in place
         self._wgrad(self.ctc_lo, dl, enc, bias_from=dl)
+        self.wait_transposes()      # this step's transposed copy of the head (made on the weight-gradient stream at the start of the step)
         d_enc = self.ctc_lo.dgrad(dl)
         # "ready(o)" means every gradient at flat offsets >= o is final.  ctc_lo sits BELOW the decoder
         # block in the flat buffer and the joint model runs the CTC backward BEFORE the decoder
@@ -980,7 +923,7 @@ class Engine:
         trace, round 4: the chain stood still for ~240 us).  The CTC results are needed only when the decoder's backward pass starts."""
         self._kv_ahead = None
         To = prep[0].shape[1]
-        if not (self.aux_overlap and self.kv_first and not torch.cuda.is_current_stream_capturing() and self._dec_exec_ok(B, To, T)):
+        if not (self.aux_overlap and not torch.cuda.is_current_stream_capturing() and self._dec_exec_ok(B, To, T)):
             return
         bufs = self._dec_bufs(B, To, T, self.training and self.drop_p > 0.0)
         self._kv_exec_async(bufs, enc)

@@ -228,18 +228,8 @@ def _strided_rows(t, H, dk):
     return t.stride(0)
 
 
-def sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, dtype):
-    """Size of the buffer that carries the attention dropout's keep mask from sdpa_fwd to sdpa_bwd as bits (0: this shape has no such
-    hand-over - the backward regenerates the mask from the counter hash)."""
-    return int(lib.asr_sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, _dt(torch.empty(0, dtype=dtype))))
-
-
-def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None, drop_p=0.0, drop_seed=0, drop_bits=None):
-    """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer).
-    drop_bits (uint8 tensor of sdpa_drop_bits_bytes, with drop_p > 0): receives the keep mask for sdpa_bwd(drop_bits=...)."""
-    if drop_bits is not None and drop_p > 0.0:
-        assert drop_bits.dtype == torch.uint8 and drop_bits.is_contiguous()
-        check(lib.asr_sdpa_drop_bits(_p(drop_bits), drop_bits.numel()), "asr_sdpa_drop_bits")
+def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None, drop_p=0.0, drop_seed=0):
+    """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer)."""
     ldq, ldk, ldv = _strided_rows(q, H, dk), _strided_rows(k, H, dk), _strided_rows(v, H, dk)
     assert q.shape[0] == B * Tq and k.shape[0] == B * Tk and v.shape[0] == B * Tk
     assert q.dtype == k.dtype == v.dtype
@@ -258,10 +248,7 @@ def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=No
 
 
 def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=False, window=-1, scale=None, delta=None,
-             drop_p=0.0, drop_seed=0, drop_bits=None):
-    if drop_bits is not None and drop_p > 0.0:      # the keep mask the forward call wrote (same shape, seed and drop_p)
-        assert drop_bits.dtype == torch.uint8 and drop_bits.is_contiguous()
-        check(lib.asr_sdpa_drop_bits(_p(drop_bits), drop_bits.numel()), "asr_sdpa_drop_bits")
+             drop_p=0.0, drop_seed=0):
     ldq, ldk, ldv, ldo = (_strided_rows(t, H, dk) for t in (q, k, v, o))
     assert _strided_rows(do, H, dk) == ldo and _strided_rows(dq, H, dk) == ldq
     assert _strided_rows(dk_, H, dk) == ldk and _strided_rows(dv, H, dk) == ldv
@@ -562,8 +549,7 @@ def transpose_batched(src, dst, tiles):
 
 def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None, family="gemm_nt"):
     """out (M,N) = act(a (M,K) @ w (N,K)^T + bias) (+ res); bf16 operands, MFMA kernel.
-    act = ACT_RELU_MASK: out = (a @ w^T + bias) where res > 0 else 0 (res = the activations of a ReLU whose backward
-    this is)."""
+    act = ACT_RELU_MASK: out = (a @ w^T) where res > 0 else 0 (res = the activations of a ReLU whose backward this is; no bias)."""
     assert a.dtype == w.dtype == out.dtype == torch.bfloat16
     M, K = a.shape
     N = w.shape[0]
@@ -575,33 +561,6 @@ def gemm_nt(a, w, bias, out, act=ACT_NONE, res=None, family="gemm_nt"):
         lib.asr_gemm_nt_bf16(_p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0), int(act),
                              _stream()), "asr_gemm_nt_bf16"))
     return out
-
-
-def relu_bits_bytes(M, N, K):
-    """Size of the bit-mask buffer of gemm_nt_relu_bits for an (M, N) output and reduction length K, 0 = no such form (asr_hip.h)."""
-    return int(lib.asr_gemm_nt_relu_bits_bytes(M, N, K))
-
-
-def gemm_nt_relu_bits(a, w, bias, bits, out, backward=False, family="gemm_nt"):
-    """backward = False: out = relu(a @ w^T + bias), `bits` (uint8) receives one "> 0" bit per element;
-    backward = True: out = (a @ w^T) where the bit is set, else 0 (the input gradient through the ReLU).  include/asr_hip.h:
-    asr_gemm_nt_relu_bits_bf16."""
-    assert a.dtype == w.dtype == out.dtype == torch.bfloat16 and bits.dtype == torch.uint8 and bits.is_contiguous()
-    M, K = a.shape
-    N = w.shape[0]
-    assert w.shape[1] == K and out.shape == (M, N) and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
-    _chk_f32(bias)
-    timed(family, 2.0 * M * N * K, lambda: check(
-        lib.asr_gemm_nt_relu_bits_bf16(_p(a), _p(w), _p(bias), _p(bits), bits.numel(), _p(out), M, N, K, a.stride(0), w.stride(0), out.stride(0),
-                                       int(bool(backward)), _stream()), "asr_gemm_nt_relu_bits_bf16"))
-    return out
-
-
-def set_option(name, value):
-    """Process-wide tuning switch between correct kernel variants (include/asr_hip.h: asr_set_option); returns the previous value."""
-    prev = ctypes.c_int(0)
-    check(_lib.lib.asr_set_option(name.encode(), int(value), ctypes.byref(prev)), "asr_set_option")
-    return prev.value
 
 
 _CU_LIMIT_NAME = ctypes.create_string_buffer(b"cu_limit")
@@ -652,31 +611,6 @@ def gemm_small(a, bm, bias, out, trans_b=False, act=ACT_NONE, mask=None):
         lib.asr_gemm_small_bf16(_p(a), _p(bm), _p(bias), _p(mask), _p(out), M, N, K, a.stride(0), bm.stride(0), out.stride(0), int(trans_b), int(act),
                                 _stream()), "asr_gemm_small_bf16"))
     return out
-
-
-def gemm_nt_add_ln_supported(a, w, res):
-    return (a.dtype == torch.bfloat16 and w.shape[0] == 512 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
-            and res.is_contiguous() and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
-
-
-def gemm_nt_add_ln(a, w, bias, res, gamma, beta, lens, B, T, y=None, xhat=None, rstd=None):
-    """y = LN(a @ w^T + bias + res) * gamma + beta with rows t >= lens[b] zeroed, in one kernel (N = 512).  Returns (y, xhat, rstd)."""
-    assert a.dtype == w.dtype == res.dtype == torch.bfloat16
-    M, K = a.shape
-    N = w.shape[0]
-    assert M == B * T and w.shape[1] == K and res.shape == (M, N) and res.is_contiguous() and a.stride(1) == 1 and w.stride(1) == 1
-    _chk_f32(bias, gamma, beta)
-    _chk_i32(lens)
-    assert gamma.numel() == N and beta.numel() == N and (bias is None or bias.numel() == N) and (lens is None or lens.numel() == B)
-    y = torch.empty_like(res) if y is None else y
-    xhat = torch.empty_like(res) if xhat is None else xhat
-    rstd = torch.empty(M, dtype=torch.float32, device=a.device) if rstd is None else rstd
-    assert y.is_contiguous() and xhat.is_contiguous() and y.shape == res.shape == xhat.shape
-    nb = 3.0 * res.numel() * 2 + a.numel() * 2            # A, res read; y, xhat written
-    timed("gemm_nt_ln", 2.0 * M * N * K, lambda: check(
-        lib.asr_gemm_nt_add_ln_bf16(_p(a), _p(w), _p(bias), _p(res), _p(gamma), _p(beta), _p(lens), _p(y), _p(xhat), _p(rstd), B, T, N, K,
-                                    a.stride(0), w.stride(0), _stream()), "asr_gemm_nt_add_ln_bf16"), nb)
-    return y, xhat, rstd
 
 
 def gemm_tn(dy, x, dw, accumulate=True, dbias=None, ws=None):

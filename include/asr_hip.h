@@ -46,7 +46,7 @@ typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
 #define ASR_ACT_NONE 0
 #define ASR_ACT_RELU 1
-#define ASR_ACT_RELU_MASK 2 /* asr_gemm_nt_bf16 only: C = (A W^T + bias) where res > 0, else 0 - the ReLU backward of
+#define ASR_ACT_RELU_MASK 2 /* C = (A W^T) where res > 0, else 0 (no bias: gradients have none) - the ReLU backward of
                                module.py:70-71 applied in the store tail of the input-gradient GEMM (res = the activations) */
 
 int asr_abi_version(void);
@@ -77,11 +77,12 @@ int asr_stream_arm_pending(void);
  * offers (weight-gradient stream: off the critical path of the step), 0 = default, > 0 = the highest.  Lives as long as the
  * process.  (The reference has one stream, trainer11.py:73-74; torch.cuda.Stream offers no low priority.) */
 int asr_stream_create(int priority, void** out_stream);
-/* Tuning options: process-wide integer switches between CORRECT variants of a kernel (every value gives correct results), settable at
- * run time so that two variants can be timed alternately inside one process.  Names: "nt_store" (store policy of the NT GEMM's output tile:
- * 0 nt, 1 sc1 write-through, 2 plain, 3 sc0 sc1), "nt_tile" (0: 256 x 128 tiles with loader / consumer waves, 1: 256 x 128 with every wave loading and computing, 2: 256 x 256 wherever the shape allows, 3: by shape), "tn_cfg" (weight-gradient kernel: 0 four waves with staggered M-splits, 1 loader / consumer waves, 3 equal M-splits), "spare" (spread of the
- * staggered splits in percent of their mean length), "tn_split" (M-splits of the weight-gradient kernel in percent of the plan's), "sdpa_store" (reserved), "cu_limit" (> 0: the one-workgroup-per-CU kernels - persistent NT GEMM, weight-gradient M-splits - size their launches for this many CUs instead of the device's; the engine sets it around the large launches that run beside the decoder's small kernels).  Initial values: ASR_OPT_<NAME>
- * in the environment, else the defaults.  previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
+/* Tuning options: process-wide integer switches under which every value gives correct results, settable at run time.  ABI 8 keeps one:
+ * "cu_limit" (> 0: the one-workgroup-per-CU kernels - persistent NT GEMM grid, weight-gradient M-splits - size their launches for this
+ * many CUs instead of the device's; the engine sets it around the large launches that run beside the decoder's chain of small kernels;
+ * 0 = the whole device).  (Rounds 2 - 3 carried switches between kernel variants here - store policy, tile shape, split plans; the variants
+ * that lost their A/B left the library, see DESIGN.md section 4 "Tried".)  Initial value 0.
+ * previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
 int asr_set_option(const char* name, int value, int* previous);
 int asr_get_deterministic(void);
 int asr_set_deterministic(int on);
@@ -157,14 +158,6 @@ int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* ls
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
                  int ldv, int ldo, int causal, int window, float scale, float drop_p,
                  uint32_t drop_seed, int dtype, void* stream);
-
-/* Hand-over of the attention dropout's keep mask from the forward to the backward call as bits (ABI 7), for the shapes both fused
- * kernels take (bf16, dk = 64, Tk <= 512): asr_sdpa_drop_bits(bits, bytes) gives the buffer to the NEXT asr_sdpa_fwd (which writes
- * it: one 32-bit word per key and 32-query block) or asr_sdpa_bwd (which reads it instead of hashing again - the backward's loop is
- * where the hash hurts: 97 vs 65 us at config 2); the call after that has no buffer again.  Same mask as without the buffer.
- * asr_sdpa_drop_bits_bytes: size needed, 0 = no hand-over for this shape (a buffer given anyway makes the call fail). */
-size_t asr_sdpa_drop_bits_bytes(int B, int H, int Tq, int Tk, int dk, int dtype);
-int asr_sdpa_drop_bits(void* bits, size_t bytes);
 
 /* Backward: given do (same layout as o) computes dq, dk, dv (layouts/strides of q, k, v).
  * delta: f32 scratch of delta_bytes >= asr_sdpa_bwd_workspace_bytes(...) bytes, written by the call: (B, H, Tq) row sums
@@ -385,17 +378,6 @@ int asr_loss_combine(const float* row_nll, int M, const float* n_valid, const fl
  */
 int asr_gemm_nt_bf16(const void* A, const void* W, const float* bias, const void* res, void* C,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, void* stream);
-/* The feed-forward pair with the ReLU mask kept as ONE BIT per element (ABI 7): `PositionwiseFeedForwardUseConv` (module.py:68-75:
- * w_2(relu(w_1(x)))) and autograd's ReLU backward through it.
- *   backward = 0:  C (M, N) = relu(A (M, K) W (N, K)^T + bias), and `bits` receives the "> 0" bit of every element of C;
- *   backward = 1:  C (M, N) = (A W^T) where the element's bit is set, else 0  - the w_2 input gradient (A = dY, W = W_2^T), no bias.
- * The bit layout is private to the pair (both calls must see the same M and N; the K of the two calls differ): the backward reads 2 MB
- * instead of the 32-MB activation tensor (ASR_ACT_RELU_MASK of asr_gemm_nt_bf16), which the weight-gradient GEMM on the side stream is
- * streaming at the same time.  asr_gemm_nt_relu_bits_bytes = size of `bits` for (M, N) and a reduction length K, or 0 when this form
- * does not exist for the shape or the current tuning options (then use ASR_ACT_RELU / ASR_ACT_RELU_MASK). */
-size_t asr_gemm_nt_relu_bits_bytes(int M, int N, int K);
-int asr_gemm_nt_relu_bits_bf16(const void* A, const void* W, const float* bias, void* bits, size_t bits_bytes, void* C,
-                               int M, int N, int K, int lda, int ldb, int ldc, int backward, void* stream);
 /* Small-M form of the projections (the decoder's B*To ~ 550 rows; transformer_official.py:446-458 through attention.py:43-59 and
  * module.py:70-71): 64 x 64 tiles, many short workgroups instead of a dozen long ones.
  *   trans_b = 0: C (M, N) = act(A (M, K) * Bm (N, K)^T + bias)        forward, Bm = the weight as stored
@@ -414,16 +396,6 @@ int asr_gemm_small_bf16(const void* A, const void* Bm, const float* bias, const 
  * The reduction is never split across workgroups: results are deterministic (same bits every run) in either mode. */
 int asr_gemm_f32(const float* A, const float* B, const float* bias, const float* mask, float* C, int M, int N, int K,
                  int lda, int ldb, int ldc, int trans_a, int trans_b, int act, int accumulate, void* stream);
-/* Projection + residual + LayerNorm in ONE kernel (N must be 512 = d_model: a workgroup owns whole rows):
- *   y = LN(A W^T + bias + res) * gamma + beta, rows t >= lens[b] zeroed (lens may be NULL); xhat, rstd as asr_add_ln_fwd.
- * Replaces:  fc -> (dropout) -> layer_norm(out + residual) -> *= non_pad_mask      attention.py:59-60, transformer_official.py:208
- *            w_2 -> (dropout) -> layer_norm(out + residual) -> *= non_pad_mask     module.py:71-75, transformer_official.py:211
- * i.e. asr_gemm_nt_bf16 followed by asr_add_ln_fwd without the round trip of the (B*T, 512) projection output through HBM.
- * A: (B*T, K) lda bf16; W: (512, K) ldb bf16; bias (512) f32 or NULL; res, y, xhat: (B*T, 512) bf16 contiguous; gamma, beta: (512) f32;
- * rstd: (B*T) f32.  No dropout form (dropout > 0: use the two-kernel path). */
-int asr_gemm_nt_add_ln_bf16(const void* A, const void* W, const float* bias, const void* res, const float* gamma,
-                            const float* beta, const int32_t* lens, void* y, void* xhat, float* rstd, int B, int T,
-                            int N, int K, int lda, int ldb, void* stream);
 /* Weight gradient  dW (N, K) f32 (+)= dY^T (M, N)^T * X (M, K)   ("TN": reduction over rows).
  * ws: NULL / 0 in the default mode; in deterministic mode a 16-byte aligned buffer of
  * asr_gemm_tn_workspace_bytes(M, N, K) bytes (partial slabs, one per M-split). */

@@ -536,42 +536,14 @@ def test_gemm_nt(K, M, N, K_, act, use_bias, use_res):
     close(out, ref, rtol=1e-2, atol=1e-2, what="gemm_nt")
 
 
-@pytest.mark.parametrize("M,N,K_,act,use_bias", [(256, 256, 128, 0, True), (1000, 1024, 512, 1, True), (300, 4232, 512, 0, True), (777, 520, 192, 0, False),
-                                                 (16000, 1024, 512, 1, True), (16000, 4232, 512, 0, True)])
-def test_gemm_nt_wide_tiles(K, M, N, K_, act, use_bias):
-    """The 256 x 256-tile form of the persistent NT GEMM (gemm_nt_wide_kernel; chosen by shape for w_1, the w_2 input gradient and the
-    CTC head through the tuning option "nt_tile", forced here): edge tiles in M and N, ragged N = 4232, bias, ReLU - against the fp64 product
-    and, element for element, against the 256 x 128 form (same k order, same accumulation: identical bits)."""
-    torch.manual_seed(M + N + K_)
-    a = torch.randn(M, K_, device=DEV).bfloat16()
-    w = (torch.randn(N, K_, device=DEV) * 0.1).bfloat16()
-    bias = torch.randn(N, device=DEV) if use_bias else None
-    outs = {}
-    for tile in (2, 0):
-        prev = K.set_option("nt_tile", tile)
-        try:
-            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-            K.gemm_nt(a, w, bias, out, act)
-            outs[tile] = out
-        finally:
-            K.set_option("nt_tile", prev)
-    rows = slice(None) if M <= 2000 else torch.cat([torch.arange(0, 700), torch.arange(M - 700, M)]).to(DEV)      # fp64 check on the first / last rows of the big cases
-    ref = a[rows].double() @ w.double().t()
-    if use_bias:
-        ref = ref + bias.double()
-    if act:
-        ref = torch.relu(ref)
-    close(outs[2][rows], ref, rtol=1e-2, atol=1e-2, what="gemm_nt wide")
-    assert torch.equal(outs[2], outs[0]), float((outs[2].float() - outs[0].float()).abs().max())
-
-
 @pytest.mark.parametrize("M,N,K_,mode", [(16000, 512, 512, "none"), (16000, 1536, 512, "none"), (16000, 1024, 512, "relu"), (16000, 1024, 512, "mask"),
                                             (16000, 512, 1024, "res"), (1000, 512, 4232, "none"), (777, 520, 192, "none"), (300, 4232, 512, "relu"),
                                             (16000, 512, 80, "none")])
-def test_gemm_nt_loader_consumer_form(K, M, N, K_, mode):
-    """The loader / consumer form of the persistent NT GEMM (gemm_nt_spec_kernel: four waves only issue the LDS-DMA, four only compute;
-    the default form; tuning option nt_tile = 1 selects the all-in-one round-2 kernel) against that kernel: every store-tail variant (bias, ReLU, ReLU mask, residual add), the ragged
-    last k-step, edge tiles - identical bits (same tile, same k order)."""
+def test_gemm_nt_full_size_store_tails(K, M, N, K_, mode):
+    """The persistent loader / consumer NT GEMM (gemm_nt_spec_kernel: four waves only issue the LDS-DMA, four only compute) at the sizes of
+    the training step, every store-tail variant (bias, ReLU, ReLU mask, residual add), the ragged last k-step, edge tiles - against the
+    fp32 product of the same bf16 operands.  (Rounds 2 - 3 compared it bit for bit with the all-in-one kernel it replaced; that kernel
+    is in the git history.)"""
     from asr_chinese_e2e_amd._lib import ACT_RELU_MASK
     torch.manual_seed(M + N + K_)
     a = torch.randn(M, K_, device=DEV).bfloat16()
@@ -579,17 +551,21 @@ def test_gemm_nt_loader_consumer_form(K, M, N, K_, mode):
     bias = torch.randn(N, device=DEV) if mode in ("none", "relu") and K_ % 64 == 0 else None
     res = torch.relu(torch.randn(M, N, device=DEV)).bfloat16() if mode in ("mask", "res") else None
     act = {"none": 0, "relu": 1, "mask": ACT_RELU_MASK, "res": 0}[mode]
-    outs = {}
-    for tile in (0, 1):      # 0 = loader / consumer form (the default), 1 = every wave loads and computes (the round-2 kernel)
-        prev = K.set_option("nt_tile", tile)
-        try:
-            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-            K.gemm_nt(a, w, bias, out, act, res)
-            outs[tile] = out
-        finally:
-            K.set_option("nt_tile", prev)
-    assert not bool(torch.isnan(outs[0].float()).any())
-    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    K.gemm_nt(a, w, bias, out, act, res)
+    ref = a.float() @ w.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if mode == "relu":
+        ref = torch.relu(ref)
+    if mode == "mask":
+        ref = torch.where(res.float() > 0, ref, torch.zeros_like(ref))
+    if mode == "res":
+        ref = ref + res.float()
+    assert not bool(torch.isnan(out.float()).any())
+    close(out, ref, rtol=1e-2, atol=1e-2 * max(1.0, (K_ / 512) ** 0.5), what=f"gemm_nt {mode}")
+    if mode == "mask":      # masked elements are exact zeros
+        assert bool((out[res.float() <= 0] == 0).all())
 
 
 def test_armed_hand_over_orders_the_other_stream(K):
@@ -620,37 +596,6 @@ def test_armed_hand_over_orders_the_other_stream(K):
     K.cast(ref, torch.empty_like(ref))         # not an armed-capable entry point
     assert K.stream_arm_pending() and not K.stream_arm_pending()
     torch.cuda.synchronize()
-
-
-@pytest.mark.parametrize("M,N,K1,K2", [(16000, 1024, 512, 512), (4500, 1024, 512, 512), (5000, 1000, 256, 512), (300, 256, 128, 192)])
-def test_gemm_nt_relu_mask_as_bits(K, M, N, K1, K2):
-    """The feed-forward pair with the ReLU mask kept as one bit per element (asr_gemm_nt_relu_bits_bf16): the forward writes the same
-    activations as ASR_ACT_RELU, the backward the same masked input gradient as ASR_ACT_RELU_MASK reading those activations - identical
-    bits, edge tiles (rows and columns past a whole tile) included; a short bit buffer is refused."""
-    from asr_chinese_e2e_amd._lib import ACT_RELU, ACT_RELU_MASK
-    torch.manual_seed(M + N)
-    x = torch.randn(M, K1, device=DEV).bfloat16()
-    w1 = (torch.randn(N, K1, device=DEV) * 0.1).bfloat16()
-    b1 = torch.randn(N, device=DEV) * 0.2
-    dy = torch.randn(M, K2, device=DEV).bfloat16()
-    w2t = (torch.randn(N, K2, device=DEV) * 0.1).bfloat16()      # W_2^T: (ff, d) - the NT operand of the input gradient
-    nb = K.relu_bits_bytes(M, N, K1)
-    assert nb == K.relu_bits_bytes(M, N, K2) and nb == ((M + 255) // 256) * ((N + 127) // 128) * 4096
-    h_ref = K.gemm_nt(x, w1, b1, torch.empty(M, N, dtype=torch.bfloat16, device=DEV), ACT_RELU)
-    dh_ref = K.gemm_nt(dy, w2t, None, torch.empty(M, N, dtype=torch.bfloat16, device=DEV), ACT_RELU_MASK, h_ref)
-    bits = torch.zeros(nb, dtype=torch.uint8, device=DEV)
-    h = K.gemm_nt_relu_bits(x, w1, b1, bits, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV))
-    dh = K.gemm_nt_relu_bits(dy, w2t, None, bits, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV), backward=True)
-    assert torch.equal(h, h_ref) and torch.equal(dh, dh_ref), float((dh.float() - dh_ref.float()).abs().max())
-    frac = float((h_ref > 0).float().mean())
-    assert 0.2 < frac < 0.8      # the mask is not trivial
-    with pytest.raises(RuntimeError, match="bit buffer"):
-        K.gemm_nt_relu_bits(x, w1, b1, bits[: nb - 4096], torch.empty(M, N, dtype=torch.bfloat16, device=DEV))
-    prev = K.set_option("nt_tile", 1)      # the all-in-one kernel has no bit form: the size query says so
-    try:
-        assert K.relu_bits_bytes(M, N, K1) == 0
-    finally:
-        K.set_option("nt_tile", prev)
 
 
 @pytest.mark.parametrize("M,N,K_,ta,tb,act,acc,bias", [
@@ -733,48 +678,6 @@ def test_gemm_small(K, M, N, K_, trans_b, act):
         K.gemm_small(a.to(DEV)[:, :12], bm.to(DEV)[:12] if trans_b else bm.to(DEV)[:, :12], None, out, trans_b=trans_b)      # K not a multiple of 8
 
 
-@pytest.mark.parametrize("B,T,K_,use_bias,use_len", [(32, 500, 512, True, True), (32, 500, 1024, True, True), (3, 70, 64, False, False), (2, 333, 512, True, True)])
-def test_gemm_nt_add_ln_fused(K, B, T, K_, use_bias, use_len):
-    """Projection + residual + LayerNorm in one kernel (fc / w_2 with their post-LN, attention.py:59-60, module.py:72-75) ==
-    the fp64 formula, and == the two-kernel path (asr_gemm_nt_bf16 -> asr_add_ln_fwd) to bf16 rounding; padded rows are exact zeros."""
-    torch.manual_seed(B * T + K_)
-    M, N = B * T, 512
-    a = (torch.randn(M, K_) * 0.7).bfloat16()
-    w = (torch.randn(N, K_) * K_ ** -0.5).bfloat16()
-    bias = torch.randn(N) * 0.1 if use_bias else None
-    res = torch.randn(M, N).bfloat16()
-    gamma, beta = 1 + 0.1 * torch.randn(N), 0.05 * torch.randn(N)
-    lens = torch.randint(T // 2, T + 1, (B,), dtype=torch.int32) if use_len else None
-    if lens is not None:
-        lens[0] = T
-    ad, wd, rd = a.to(DEV), w.to(DEV), res.to(DEV)
-    bd = bias.to(DEV) if use_bias else None
-    ld = lens.to(DEV) if use_len else None
-    y, xhat, rstd = K.gemm_nt_add_ln(ad, wd, bd, rd, gamma.to(DEV), beta.to(DEV), ld, B, T)
-    # two-kernel path on the same inputs
-    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    K.gemm_nt(ad, wd, bd, c)
-    y2, xhat2, rstd2 = K.add_ln_fwd(c.clone(), rd, gamma.to(DEV), beta.to(DEV), None, ld, B, T)
-    close(y, y2.float(), rtol=2e-2, atol=2e-2, what="fused vs two kernels: y")
-    close(xhat, xhat2.float(), rtol=2e-2, atol=2e-2, what="fused vs two kernels: xhat")
-    close(rstd, rstd2, rtol=5e-3, atol=1e-5, what="fused vs two kernels: rstd")
-    # fp64 formula (projection rounded to bf16 before the statistics, as both paths store it)
-    proj = (a.double() @ w.double().t() + (bias.double() if use_bias else 0)).bfloat16().double()
-    z = proj + res.double()
-    mean, var = z.mean(-1, keepdim=True), z.var(-1, unbiased=False, keepdim=True)
-    xr = (z - mean) / torch.sqrt(var + 1e-5)
-    yr = xr * gamma.double() + beta.double()
-    if use_len:
-        keep = (torch.arange(T).view(1, T) < lens.view(B, 1)).reshape(M, 1)
-        yr = yr * keep
-        assert float(y.float().cpu()[~keep.squeeze(1)].abs().max() if (~keep).any() else 0.0) == 0.0
-    close(xhat, xr, rtol=1.6e-2, atol=2.5e-2, what="fused xhat vs fp64")      # one bf16 ulp of the projection moves xhat by ~2^-9 |proj| rstd
-    close(y, yr, rtol=1.6e-2, atol=3e-2, what="fused y vs fp64")
-    close(rstd, (1 / torch.sqrt(var + 1e-5)).squeeze(1), rtol=5e-3, atol=1e-5, what="fused rstd vs fp64")
-    with pytest.raises(RuntimeError):
-        K.gemm_nt_add_ln(ad, wd[:256], bd[:256] if use_bias else None, rd[:, :256].contiguous(), gamma[:256].to(DEV), beta[:256].to(DEV), ld, B, T)
-
-
 @pytest.mark.parametrize("M,N,K_", [(16000, 1024, 512), (777, 264, 128), (4100, 512, 1536)])
 def test_gemm_nt_relu_mask_epilogue(K, M, N, K_):
     """ACT_RELU_MASK: C = (A W^T) where the mask tensor is > 0, else exactly 0 (the ReLU backward folded into the
@@ -791,29 +694,6 @@ def test_gemm_nt_relu_mask_epilogue(K, M, N, K_):
     ref = (a.float() @ w.float().t()) * (h.float() > 0)
     close(out, ref, rtol=1e-2, atol=1e-2, what="relu-mask epilogue")
     assert bool((out[h.float() <= 0] == 0).all())
-
-
-def test_gemm_tn_eight_wave_form():
-    """The 8-wave (intra-workgroup split) form of the wgrad kernel, selected by ASR_GEMM_TN_CFG=8 in a
-    child process (the library reads the variable once): same results as the fp32 GEMM on the GPU."""
-    import subprocess, sys
-    code = """
-import math, sys, torch
-sys.path.insert(0, %r)
-from asr_chinese_e2e_amd import kernels as K
-torch.manual_seed(1)
-for M, N, Kd in ((16000, 1536, 512), (8197, 512, 512), (300, 128, 128)):
-    dy = (torch.randn(M, N, device="cuda") * 0.5 + 0.1).bfloat16(); x = torch.randn(M, Kd, device="cuda").bfloat16()
-    dw = torch.zeros(N, Kd, device="cuda"); db = torch.zeros(N, device="cuda")
-    K.gemm_tn(dy, x, dw, accumulate=True, dbias=db)
-    ref = dy.float().t() @ x.float()
-    assert float((dw - ref).abs().max()) <= 2e-3 * math.sqrt(M) + 2e-3 * float(ref.abs().max()), (M, N, Kd)
-    assert float((db - dy.float().sum(0)).abs().max()) <= 1e-3 * math.sqrt(M) + 1e-4 * float(dy.float().sum(0).abs().max())
-print("eight ok")
-""" % ROOT
-    import os
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ASR_GEMM_TN_CFG="8"), capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0 and "eight ok" in p.stdout, p.stdout + p.stderr
 
 
 def test_gemm_nt_integer_exact(K):
@@ -866,30 +746,6 @@ def test_gemm_tn(K, M, N, K_):
     db = torch.full((N,), 2.0, device=DEV)        # bias gradient from the same kernel (ragged M, clamped edge columns)
     K.gemm_tn(dy.to(DEV), x.to(DEV), dw2, accumulate=True, dbias=db)
     close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn bias gradient")
-
-
-@pytest.mark.parametrize("cfg", [1, 3])
-@pytest.mark.parametrize("M,N,K_", [(16000, 1536, 512), (16000, 512, 512), (16000, 512, 1024), (8197, 512, 512), (4000, 1536, 512), (300, 128, 128), (16000, 1024, 512)])
-def test_gemm_tn_loader_consumer_form(K, M, N, K_, cfg):
-    """The optional forms of the weight-gradient kernel (tuning option tn_cfg): 1 = loader / consumer waves (gemm_tn_spec_kernel), 3 = M-splits
-    of equal length (the default staggers them: they finish - and add their tiles with atomics - one after the other).  Same values as the fp64 product, weight
-    gradient and fused bias gradient, accumulate and overwrite, ragged M (zero-page redirection of the last stage)."""
-    torch.manual_seed(M + K_)
-    dy = (torch.randn(M, N) * 0.5 + 0.05).bfloat16().to(DEV)
-    x = torch.randn(M, K_).bfloat16().to(DEV)
-    ref = dy.double().cpu().t() @ x.double().cpu()
-    prev = K.set_option("tn_cfg", cfg)
-    try:
-        dw = torch.ones(N, K_, device=DEV)
-        db = torch.full((N,), 2.0, device=DEV)
-        K.gemm_tn(dy, x, dw, accumulate=True, dbias=db)
-        dw2 = torch.full((N, K_), float("nan"), device=DEV)
-        K.gemm_tn(dy, x, dw2, accumulate=False)
-    finally:
-        K.set_option("tn_cfg", prev)
-    close(dw - 1, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="gemm_tn loader/consumer accumulate")
-    close(db - 2, dy.double().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what="gemm_tn loader/consumer bias gradient")
-    close(dw2, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what="gemm_tn loader/consumer overwrite")
 
 
 @pytest.mark.parametrize("M,N,K_", [(16000, 512, 512), (16000, 4232, 512), (1000, 1536, 512), (8197, 264, 72)])
@@ -1177,42 +1033,6 @@ def test_sdpa_dropout(K, dtype, B, H, Tq, Tk, dk, causal):
     close(dq.reshape(B, Tq, H, dk), qr.grad, **gt, what="sdpa dropout dq")
     close(dg[:, :d].reshape(B, Tk, H, dk), kr.grad, **gt, what="sdpa dropout dk")
     close(dg[:, d:].reshape(B, Tk, H, dk), vr.grad, **gt, what="sdpa dropout dv")
-
-
-@pytest.mark.parametrize("B,H,Tq,Tk,causal", [(2, 8, 500, 500, False), (2, 4, 130, 130, True), (1, 8, 70, 500, False), (3, 2, 33, 512, False)])
-def test_sdpa_dropout_keep_mask_as_bits(K, B, H, Tq, Tk, causal):
-    """The fused kernels hand the dropout keep mask from the forward to the backward call as bits (asr_sdpa_drop_bits: one word per key
-    and 32-query block, written from the lane masks of the forward's compares) instead of hashing again: outputs and gradients are
-    bit-identical to the regenerating path; a buffer that the call cannot use is refused."""
-    torch.manual_seed(Tq + Tk)
-    dk, p, seed = 64, 0.15, 4242
-    d = H * dk
-    qkv = torch.randn(B * max(Tq, Tk), 3 * d, device=DEV).bfloat16()
-    q, k, v = qkv[: B * Tq, :d], qkv[: B * Tk, d:2 * d], qkv[: B * Tk, 2 * d:]
-    klen = torch.tensor([Tk, max(Tk - 37, 1), max(Tk // 2, 1)][:B], dtype=torch.int32, device=DEV)
-    do = torch.randn(B * Tq, d, device=DEV).bfloat16()
-    nb = K.sdpa_drop_bits_bytes(B, H, Tq, Tk, dk, torch.bfloat16)
-    assert nb == B * H * ((Tq + 31) // 32) * 512 * 4
-    res = {}
-    for use_bits in (False, True):
-        bits = torch.zeros(nb, dtype=torch.uint8, device=DEV) if use_bits else None
-        o, lse = K.sdpa_fwd(q, k, v, klen, B, H, Tq, Tk, dk, causal, -1, drop_p=p, drop_seed=seed, drop_bits=bits)
-        dqkv = torch.zeros_like(qkv)      # gradients in the layout of their operands
-        K.sdpa_bwd(q, k, v, o, do, lse, klen, B, H, Tq, Tk, dk, dqkv[: B * Tq, :d], dqkv[: B * Tk, d:2 * d], dqkv[: B * Tk, 2 * d:], causal, -1,
-                   drop_p=p, drop_seed=seed, drop_bits=bits)
-        res[use_bits] = (o, lse, dqkv)
-        if use_bits:      # the words really carry the mask: their density is the keep probability
-            words = bits.view(torch.int32).view(B * H, (Tq + 31) // 32, 512)[:, 0, : min(Tk, 64)]
-            ones = sum(int(((words >> b) & 1).sum()) for b in range(min(32, Tq)))
-            frac = ones / (words.numel() * min(32, Tq))
-            assert abs(frac - (1 - p)) < 0.03, frac
-    for a, b_, name in zip(res[False], res[True], ("o", "lse", "dqkv")):
-        assert torch.equal(a, b_), (name, float((a.float() - b_.float()).abs().max()))
-    # Tk = 600 takes the tiled kernels: no hand-over, and a buffer given anyway is an error
-    assert K.sdpa_drop_bits_bytes(1, 2, 600, 600, dk, torch.bfloat16) == 0
-    big = torch.randn(600, 3 * 2 * dk, device=DEV).bfloat16()
-    with pytest.raises(RuntimeError, match="cannot use it"):
-        K.sdpa_fwd(big[:, :128], big[:, 128:256], big[:, 256:], None, 1, 2, 600, 600, dk, drop_p=p, drop_seed=1, drop_bits=torch.zeros(64, dtype=torch.uint8, device=DEV))
 
 
 def test_embed_dropout(K):

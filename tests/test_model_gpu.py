@@ -16,6 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_model as R  # noqa: E402
+from asr_chinese_e2e_amd import engine as E  # noqa: E402
 from tests.helpers import golden_model_case, mfma_golden_case  # noqa: E402
 
 DEV = "cuda"
@@ -827,7 +828,7 @@ def test_edge_batches_match_oracle(which):
 @pytest.mark.parametrize("T", [70, 600])
 def test_beam_search_cross_attention_kernels_agree(T, monkeypatch):
     """The beam search's cross attention on the training attention kernel (all beams of an utterance as Tq = beam queries; the LDS-
-    resident kernel at T <= 512, the tiled one beyond) gives the hypotheses of the single-query decode kernel (ASR_DECODE_SDPA=0):
+    resident kernel at T <= 512, the tiled one beyond) gives the hypotheses of the single-query decode kernel (decode.USE_SDPA = False):
     same token sequences; scores within bf16 noise (the two kernels round differently)."""
     over = dict(d_model=64, hidden_size=64, num_head=2, ff_size=128, layer_num=2)
     cfg, sd, batch = oracle_case(3, T, 16, 24, 5, over, seed=13)
@@ -838,9 +839,10 @@ def test_beam_search_cross_attention_kernels_agree(T, monkeypatch):
     model.load_state_dict({k: v for k, v in sd.items()})
     model.eval()
     pack = to_pack(batch)
-    monkeypatch.setenv("ASR_DECODE_SDPA", "1")
+    from asr_chinese_e2e_amd import decode
+    monkeypatch.setattr(decode, "USE_SDPA", True)
     a = model.beam_search(pack, 4, 2, 10)
-    monkeypatch.setenv("ASR_DECODE_SDPA", "0")
+    monkeypatch.setattr(decode, "USE_SDPA", False)
     b = model.beam_search(pack, 4, 2, 10)
     for ha, hb in zip(a, b):
         assert len(ha) == len(hb)
@@ -884,7 +886,7 @@ def test_decoder_sequencer_matches_per_kernel_path(dropout, monkeypatch):
 def test_padded_head_rows_match_dense_rows(name, monkeypatch):
     """The training step keeps the CTC head's logits / gradient rows 64-element aligned (V = 56 -> 64, like 4232 -> 4288 at full size;
     the W^T copy of the head is padded the same way).  Same kernels, same tiles: in deterministic mode the loss and every gradient are
-    bit-identical to the dense layout's (ASR_PAD_LOGITS=0)."""
+    bit-identical to the dense layout's (Engine.PAD_HEAD_ROWS = False)."""
     from asr_chinese_e2e_amd import kernels as K
     over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=1, ctc_weight=0.3)
     if name == "TransformerCTC":
@@ -895,7 +897,7 @@ def test_padded_head_rows_match_dense_rows(name, monkeypatch):
     try:
         res = {}
         for mode in ("1", "0"):
-            monkeypatch.setenv("ASR_PAD_LOGITS", mode)
+            monkeypatch.setattr(E.Engine, "PAD_HEAD_ROWS", mode == "1")
             model = build(cfg, 56, name, dtype="bf16").cuda()
             model.load_state_dict(sd)
             model.train()
@@ -943,10 +945,10 @@ def test_armed_hand_over_matches_event_fork(name, monkeypatch):
     assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
 
 
-@pytest.mark.parametrize("env", [dict(ASR_WGRAD_DEFER="w2"), dict(ASR_WGRAD_GROUP="block", ASR_FUSE_RELU_BWD="0"), dict(ASR_WGRAD_DEFER="w2,fc", ASR_FUSE_RELU_BWD="0")])
+@pytest.mark.parametrize("env", [dict(ASR_WGRAD_DEFER="w2"), dict(ASR_WGRAD_GROUP="block"), dict(ASR_WGRAD_GROUP="layer", ASR_WGRAD_DEFER="w2,fc")])
 def test_arm_does_not_outlive_its_producer(env, monkeypatch):
     """Round-3 ADVICE: with a weight gradient held back (ASR_WGRAD_DEFER=w2 at B*T < 4096) or collected for a grouped launch
-    (ASR_WGRAD_GROUP=block with the ReLU backward as its own kernel) `_wgrad` returns without forking, and the arm set for the LayerNorm
+    (ASR_WGRAD_GROUP=block / layer; at these row counts the ReLU backward is its own kernel behind the input-gradient GEMM) `_wgrad` returns without forking, and the arm set for the LayerNorm
     backward used to survive until a later `_fork(side)` - which then skipped its event although other main-stream kernels had produced
     the operand since: the weight-gradient stream read a dY ordered only behind the armed kernel.  The arm is now dropped wherever no
     fork follows its producer: with the two streams live (NOT deterministic mode) the gradients of armed and event-record hand-overs
@@ -978,34 +980,6 @@ def test_arm_does_not_outlive_its_producer(env, monkeypatch):
         a, b = res["1"][1][off:off + n], res["0"][1][off:off + n]
         gmax = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * gmax + 1e-9, (name, float((a - b).abs().max()), gmax)
-
-
-def test_relu_bit_mask_matches_activation_mask(monkeypatch):
-    """ASR_RELU_BITS=1: the encoder's feed-forward blocks keep the ReLU mask as one bit per element (written by the w_1 GEMM, read by the
-    w_2 input gradient) instead of re-reading the activations in the backward pass (the default): same loss and, in deterministic
-    mode, the same gradients bit for bit."""
-    from asr_chinese_e2e_amd import kernels as K
-    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, use_decoder=False, ctc_weight=1.0)
-    cfg, sd, batch = oracle_case(9, 500, 80, 56, 12, over, seed=17)
-    pack = to_pack(batch)
-    prev = K.set_deterministic(True)
-    try:
-        res = {}
-        for mode in ("1", "0"):
-            monkeypatch.setenv("ASR_RELU_BITS", mode)
-            model = build(cfg, 56, "TransformerCTC", dtype="bf16").cuda()
-            model.load_state_dict(sd)
-            model.train()
-            eng = model._ensure_engine(DEV)
-            assert eng.relu_bits == (mode == "1")
-            model.zero_flat_grads()
-            loss, _ = model.train_step(pack)
-            torch.cuda.synchronize()
-            res[mode] = (loss.clone(), model._flat.g.clone())
-    finally:
-        K.set_deterministic(prev)
-    assert torch.isfinite(res["1"][0]).all()
-    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1]), float((res["1"][1] - res["0"][1]).abs().max())
 
 
 def test_decoder_sequencer_buffer_cache_is_bounded():

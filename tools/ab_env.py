@@ -15,8 +15,6 @@ def apply(val):
     os.environ[name] = val
     if name == "ASR_DETERMINISTIC":      # library-level switch (the environment is only read when the library loads)
         K.set_deterministic(val == "1")
-    if name.startswith("opt:"):          # tuning option of the library (asr_set_option), e.g. opt:nt_store 0 1
-        K.set_option(name[4:], int(val))
 def build(val):
     apply(val)
     cfg = M.get_default_config()(); cfg.fn_build(dict(n_mels=80, lfr_m=1, dropout=float(os.environ.get("AB_DROPOUT", "0.0")), ctc_weight=0.3 if JOINT else 1.0, cer_in_iterate=False))

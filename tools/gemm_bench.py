@@ -42,8 +42,6 @@ for N, Kd, name in (SHAPES if which not in ("grp", "grp1", "pad", "mask") else [
         tl = timeit(lambda: torch.addmm(b.bfloat16(), x, w.t(), out=out))
         line += f" | NT mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s  lib {tl:7.1f} us {fl / tl / 1e6:6.0f} TF/s"
     if which in ("tn", "all"):
-        if os.environ.get("TN_CFG"):
-            K.set_option("tn_cfg", int(os.environ["TN_CFG"]))
         t = timeit(lambda: K.gemm_tn(dy, x, dw, accumulate=True))
         tl = timeit(lambda: torch.mm(dy.t(), x))
         line += f" | TN mine {t:7.1f} us {fl / t / 1e6:6.0f} TF/s  lib {tl:7.1f} us {fl / tl / 1e6:6.0f} TF/s"

@@ -30,7 +30,6 @@ B=8 T=2000 WINDOW=50 REPS=5 rocprofv3 --pmc WRITE_SIZE -d $OUT/bwrite -o p --out
 cd $R
 python3 tools/pmc_summary.py $(find $OUT/bfetch -name "*counter_collection.csv") $(find $OUT/bwrite -name "*counter_collection.csv") $OUT/pmc_traffic_band.json > $OUT/pmc_traffic_band.txt
 B=8 T=2000 WINDOW=50 python3 tools/sdpa_bench.py > $OUT/band_bench_plain.txt 2>&1
-B=8 T=2000 WINDOW=50 ASR_SDPA_BWD_SPLIT=1 python3 tools/sdpa_bench.py > $OUT/band_bench_pair.txt 2>&1
 rm -rf $OUT/bfetch $OUT/bwrite
 # SQ counters of the attention kernels at the config-2 shape (issue mix, LDS bank conflicts), two passes
 cd /tmp

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from asr_chinese_e2e_amd import kernels as K
 
-B, H, T, dk = int(os.environ.get("B", "32")), 8, int(os.environ.get("T", "500")), 64      # long-form band: B=8 T=2000 WINDOW=50 (ASR_SDPA_BWD_SPLIT=1: the kernel pair)
+B, H, T, dk = int(os.environ.get("B", "32")), 8, int(os.environ.get("T", "500")), 64      # long-form band: B=8 T=2000 WINDOW=50
 window = int(os.environ.get("WINDOW", "-1"))
 d = H * dk
 def timeit(fn, reps=int(os.environ.get("REPS", "20"))):
@@ -18,15 +18,12 @@ def timeit(fn, reps=int(os.environ.get("REPS", "20"))):
 qkv = torch.randn(B * T, 3 * d, device="cuda").bfloat16()
 q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
 klen = torch.full((B,), T, dtype=torch.int32, device="cuda")
-DROP = float(os.environ.get("DROP", "0"))      # attention dropout; BITS=1: keep mask handed to the backward as bits
-bits = None
-if DROP > 0 and os.environ.get("BITS") == "1":
-    bits = torch.zeros(K.sdpa_drop_bits_bytes(B, H, T, T, dk, torch.bfloat16), dtype=torch.uint8, device="cuda")
-o, lse = K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, drop_p=DROP, drop_seed=7, drop_bits=bits)
+DROP = float(os.environ.get("DROP", "0"))      # attention dropout
+o, lse = K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, drop_p=DROP, drop_seed=7)
 do = torch.randn_like(o)
 dqkv = torch.empty_like(qkv)
 fl = 4.0 * B * H * T * T * dk
-t = timeit(lambda: K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, o=o, lse=lse, drop_p=DROP, drop_seed=7, drop_bits=bits))
+t = timeit(lambda: K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, o=o, lse=lse, drop_p=DROP, drop_seed=7))
 print(f"fwd  {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s  {4 * B * T * d * 2 / t / 1e6:6.2f} TB/s algorithmic")
-t = timeit(lambda: K.sdpa_bwd(q, k, v, o, do, lse, klen, B, H, T, T, dk, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], False, window, drop_p=DROP, drop_seed=7, drop_bits=bits))
+t = timeit(lambda: K.sdpa_bwd(q, k, v, o, do, lse, klen, B, H, T, T, dk, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], False, window, drop_p=DROP, drop_seed=7))
 print(f"bwd  {t:7.1f} us  {2.5 * fl / t / 1e6:6.0f} TF/s (5 products: algorithmic)  {8 * B * T * d * 2 / t / 1e6:6.2f} TB/s algorithmic")
