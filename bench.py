@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round3_e_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round4_c_pmc_traffic.json")
 
 
 def parse(argv=None):
