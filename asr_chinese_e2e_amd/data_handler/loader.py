@@ -121,8 +121,15 @@ class BucketedWaveLoader:
         self.parser = parser or AudioParser(device=self.device)
         self.rng = random.Random(seed)          # batch order AND SpecAugment masks (the reference uses the global `random`)
         self.bucket_size = bucket_size
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = self._copy_stream()
         self.lengths = [dataset.num_samples(i) for i in range(len(dataset))]
+
+    def _copy_stream(self):
+        """The stream of the host-to-device copies and the feature front end of the NEXT batch: on a hardware queue other than the current
+        (training) stream's, or the copies would queue behind the training step's kernels (engine.pick_stream)."""
+        from .. import engine as E
+        with torch.cuda.device(self.device):
+            return E.pick_stream(self.device, [torch.cuda.current_stream()])
 
     def __len__(self):
         n = len(self.ds)

@@ -83,14 +83,18 @@ class GradBucketer:
     wire_dtype torch.bfloat16: each bucket travels as bf16 (cast -> all-reduce -> cast back, all on the
     communication stream); None / torch.float32: the fp32 slice itself is reduced in place."""
 
-    def __init__(self, flat_g, block_ranges, bucket_bytes=32 << 20, group=None, force_cuts=(), wire_dtype=None):
+    def __init__(self, flat_g, block_ranges, bucket_bytes=32 << 20, group=None, force_cuts=(), wire_dtype=None, avoid_streams=()):
         self.g = flat_g
         self.group = group
         self.buckets = make_buckets(block_ranges, flat_g.numel(), max(1, bucket_bytes // flat_g.element_size()), force_cuts)
         self.cuda = flat_g.is_cuda
-        # NORMAL priority: a high-priority HIP stream (priority=-1) next to the two compute streams
-        # doubled the step time on MI355X / ROCm 7 (11.0 vs 5.2 ms, measured with one rank)
-        self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        # NORMAL priority (a high-priority HIP stream next to the two compute streams doubled the step time on MI355X / ROCm 7: 11.0 vs
+        # 5.2 ms, one rank), and on a hardware queue of its own: sharing one with the compute or weight-gradient stream blocks that
+        # stream behind every bucket's event waits (engine.pick_stream; round 4: 7.0 instead of 3.1 ms per step at one rank)
+        self.comm_stream = None
+        if self.cuda:
+            from . import engine as E
+            self.comm_stream = E.pick_stream(flat_g.device, [torch.cuda.current_stream()] + list(avoid_streams))
         self.wire = None
         if wire_dtype is not None and wire_dtype != flat_g.dtype:
             if not self.cuda:
@@ -214,8 +218,6 @@ class DataParallel:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         eng = model._ensure_engine(device)
         flat = model._flat
-        dist.broadcast(flat.p, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)          # identical replicas
-        flat.refresh_lowp()
         if wire_dtype == "auto":      # bf16 models send bf16 gradients; ASR_DP_WIRE=fp32|bf16 overrides
             env = os.environ.get("ASR_DP_WIRE", "")
             wire_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(env, torch.bfloat16 if flat.lp is not None else torch.float32)
@@ -223,8 +225,17 @@ class DataParallel:
         # backward ends and is fully exposed: cut it at the feed-forward block of encoder layer 0, whose gradients
         # are final one block earlier (the engine raises a mark there), so only ~4 MB remain for the very end.
         tail = eng.tail_mark_name()
+        compute_streams = (eng.side, eng.ctc_stream) if flat.g.is_cuda else ()
         self.bucketer = GradBucketer(flat.g, flat.block_range, bucket_bytes, group=group, force_cuts=[flat.index[tail][0]] if tail else (),
-                                     wire_dtype=wire_dtype)
+                                     wire_dtype=wire_dtype, avoid_streams=compute_streams)
+        # BEFORE the process group's first collective (it takes its internal stream from torch's pool then): leave the pool's counter in
+        # front of a stream that runs beside the compute streams (engine.steer_stream_pool) - RCCL's kernels will run on it
+        self.pool_draws = 0
+        if flat.g.is_cuda:
+            from . import engine as E
+            self.pool_draws = E.steer_stream_pool(flat.g.device, [torch.cuda.current_stream()] + list(compute_streams))
+        dist.broadcast(flat.p, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)          # identical replicas
+        flat.refresh_lowp()
         self._counts = _Counts(torch.zeros(2, dtype=torch.float32, device=flat.g.device), self.bucketer.comm_stream, group)
         eng.grad_ready = self.bucketer.ready
 

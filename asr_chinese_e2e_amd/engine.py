@@ -267,18 +267,104 @@ def ffn_param_block(pre, d, ff):
 
 
 _STREAMS = {}
+_HELD = []          # candidate streams that were rejected by pick_stream: kept alive, so that their hardware queue stays "in use" for later streams
+QUEUE_PROBE = True  # False: take streams as they come (tests of the probe itself)
+
+
+_CHAIN_BASE = {}
+
+
+def _chain_ms(streams, n=40, cycles=50000):
+    """Wall time of n short spin kernels (one workgroup, ~20 us each) enqueued on EACH of `streams` at the same time."""
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        for s in streams:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cycles)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0)
+
+
+def streams_conflict(a, b):
+    """True when two streams cannot run side by side.  Measured, because no API tells: a chain of 40 short spin kernels goes to each stream
+    at the same time.  tools/queue_probe.py on MI355X / ROCm 7 (100-kernel chains, 2.2 ms alone) shows three cases: 2.2 ms - the streams
+    sit on different hardware queues served by different command-processor pipes: concurrent; 4.4 ms - the HIP runtime has mapped both
+    onto ONE in-order hardware queue (it multiplexes streams onto GPU_MAX_HW_QUEUES = 4 queues per priority, in the order of first use);
+    5.5 ms - two hardware queues on the SAME pipe, which alternates between them at a cost: worse than one queue."""
+    dev = a.device.index
+    if dev not in _CHAIN_BASE:
+        _CHAIN_BASE[dev] = min(_chain_ms([a]) for _ in range(3))
+    return min(_chain_ms([a, b]) for _ in range(2)) > 1.5 * _CHAIN_BASE[dev]
+
+
+def pick_stream(device, avoid, factory=None, tries=12):
+    """A stream that can run beside every stream in `avoid` (streams_conflict).
+    Which hardware queue - and so which command-processor pipe - a stream gets depends on how many other streams the process has USED
+    before it: a data loader's copy stream, the process group's internal stream, a second model.  Round 4 (tools/dp_probe.py): with the
+    weight-gradient or auxiliary stream on the main stream's queue or pipe the CTC step takes 6.3 - 7.1 ms instead of 3.0 and the joint
+    step 11.4 - 12.4 instead of 4.8 (every kernel of the trace ~40 us longer) - through the data-parallel wrapper at one rank in the CTC
+    configuration, or after two or three unrelated streams had been used first.  So the streams are CHOSEN: candidates come from `factory`
+    (default: torch's stream pool), each is tested against every stream in `avoid`; rejected candidates stay referenced (their queue then
+    counts as used for whatever stream the process creates next)."""
+    factory = factory or (lambda: torch.cuda.Stream(device=device))
+    cand = None
+    for _ in range(tries):
+        cand = factory()
+        if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing():
+            return cand
+        if not any(streams_conflict(a, cand) for a in avoid if a is not None):
+            return cand
+        _HELD.append(cand)
+    import warnings
+    warnings.warn("asr_chinese_e2e_amd: no stream that runs beside the main stream after %d candidates (GPU_MAX_HW_QUEUES too small for the streams "
+                  "of this process?): the multi-stream step may run serialised" % tries)
+    return cand
+
+
+def steer_stream_pool(device, avoid, ring_max=64):
+    """Advance torch's stream-pool counter until the NEXT stream the pool hands out runs beside every stream in `avoid`.
+    The process group takes its internal stream - the one RCCL's kernels run on - from that pool (at::cuda::getStreamFromPool, a ring of 32
+    streams per priority) at its first collective, and nothing lets the caller choose it; but the ring is deterministic: drawing streams
+    until one repeats walks it once (every stream tested against `avoid` on the way), after which the position of the counter and the
+    verdict for the stream behind it are known.  Returns how many draws it took, or -1 when no stream of the ring qualifies."""
+    if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing():
+        return 0
+    order, verdict = [], {}
+    with torch.cuda.device(device):
+        s = torch.cuda.Stream(device=device)
+        while s.cuda_stream not in verdict and len(order) < ring_max:
+            verdict[s.cuda_stream] = not any(streams_conflict(a, s) for a in avoid if a is not None)
+            order.append(s.cuda_stream)
+            _HELD.append(s)
+            s = torch.cuda.Stream(device=device)
+        if s.cuda_stream not in verdict:
+            return -1      # not a ring we understand: leave the counter where it is
+        pos, n, draws = order.index(s.cuda_stream), len(order), len(order) + 1
+        if not any(verdict.values()):
+            return -1
+        while not verdict[order[(pos + 1) % n]]:      # the stream after the last one drawn is what the next caller gets
+            torch.cuda.Stream(device=device)
+            pos, draws = pos + 1, draws + 1
+        return draws
 
 
 def _shared_stream(device, kind):
-    """One auxiliary stream of each kind per device and PROCESS, shared by every engine: the HIP runtime multiplexes
-    streams onto a few hardware queues, and a second model with streams of its own ran its step 2.5x slower
-    (13.8 against 5.6 ms, joint config) - its main and side work landed on one queue.  Engines of one process run
-    their steps one after the other, so sharing costs nothing."""
-    key = (torch.device(device).index, kind)
+    """One auxiliary stream of each kind per device and PROCESS, shared by every engine (engines of one process run their steps one
+    after the other, so sharing costs nothing; a second set of streams would only compete for the few hardware queues), each on a
+    hardware queue of its own (pick_stream): "wgrad" - the weight-gradient stream, lowest priority - against the current (main) stream,
+    "aux" (the CTC branch / cross-attention K|V work beside the decoder; normal priority: at the lowest 5.49 vs 5.48 ms, nothing) against
+    the main and the weight-gradient stream."""
+    dev = torch.device(device)
+    key = (dev.index, kind)
     if key not in _STREAMS:
-        # "wgrad": lowest priority (off the critical path); "aux" (the CTC branch / cross-attention K|V work beside the decoder): normal
-        # (at the lowest priority too: 5.49 vs 5.48 ms, nothing)
-        _STREAMS[key] = _side_stream(device) if kind == "wgrad" else torch.cuda.Stream(device=device)
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream()
+            if kind == "wgrad":
+                _STREAMS[key] = pick_stream(dev, [main], factory=lambda: _side_stream(dev))
+            else:
+                _STREAMS[key] = pick_stream(dev, [main, _shared_stream(dev, "wgrad")])
     return _STREAMS[key]
 
 

@@ -223,6 +223,14 @@ class Run:
                 raise SystemExit("bench: the caching allocator grew inside a timed region - the number would include hipMalloc synchronisations")
         return dt
 
+    def streams_independent(self):
+        """True when main, weight-gradient, auxiliary and communication stream pairwise run side by side (engine.streams_conflict)."""
+        from asr_chinese_e2e_amd import engine as E
+        eng = self.model._engine
+        ss = [self.torch.cuda.current_stream(), eng.side, eng.ctc_stream] + ([self.dp.bucketer.comm_stream] if self.dp is not None else [])
+        self.torch.cuda.synchronize()
+        return not any(E.streams_conflict(a, b) for i, a in enumerate(ss) for b in ss[i + 1:])
+
     def replica_checksum(self):
         """(min, max) over the ranks of the sum of all parameters after the timed steps: equal unless the replicas diverged
         (the bf16 wire format rounds, but every rank receives the SAME reduced bucket and applies the same update)."""
@@ -234,15 +242,18 @@ class Run:
             torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         return float(lo), float(hi)
 
-    def kernel_pass(self, n_inst):
+    def kernel_pass(self, n_inst, in_step=False):
         """The SAME steps once more with HIP events around every launch of the listed kernel families (recorded on
         the stream the kernel is launched on).  A separate pass: ~100 event pairs per step cost ~25 % wall time on
-        ROCm; the wgrad overlap is off so the durations are stand-alone."""
+        ROCm.  in_step = False: the weight-gradient overlap is off, so the durations are stand-alone (what the roofline fractions are
+        priced on); in_step = True: both streams live as in the timed region - a kernel's duration then includes what it loses to the
+        kernels running beside it (the weight gradients take 51 us there, 40 alone)."""
         from asr_chinese_e2e_amd import kernels as K
         torch = self.torch
         timer = K.LaunchTimer(list(KERNEL_NAMES))
         K.TIMER = timer
-        self.model._engine.overlap_wgrad = False
+        if not in_step:
+            self.model._engine.overlap_wgrad = False
         # every GEMM of the step is an own kernel (round 3): count what still reaches the library through torch during these steps
         self.lib_gemm_calls = 0
         saved = {}
@@ -321,27 +332,42 @@ def main():
         try:
             D.init(backend)
             world = torch.distributed.get_world_size()      # the ranks the process group actually formed
+        except Exception as e:      # noqa: BLE001 - reported verbatim, then the run ends
+            log(f"rank {rank}: process group FAILED over backend {backend}: {type(e).__name__}: {e}")
+            log("environment: " + ", ".join(f"{k}={os.environ.get(k)}" for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                                  "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")))
+            raise SystemExit(3)
+
+    # The model (and with it the engine's streams) is built BEFORE the first collective: the process group takes its internal stream from
+    # torch's pool at that moment, and dist.DataParallel first leaves the pool in front of a stream that runs beside the compute streams
+    # (engine.steer_stream_pool).  The first collectives - the wrapper's parameter broadcast, then a one-element all-reduce - are checked here.
+    try:
+        run = Run(args, config, args.dropout, rank, dev, use_dp)
+        if use_dp:
             probe = torch.ones(1, device=dev)
             torch.distributed.all_reduce(probe)
             torch.cuda.synchronize()
             if int(probe.item()) != world:
                 raise RuntimeError(f"first all-reduce summed {probe.item()} over a group of {world}")
-        except Exception as e:      # noqa: BLE001 - reported verbatim, then the run ends
-            log(f"rank {rank}: process group / first collective FAILED over backend {backend}: {type(e).__name__}: {e}")
-            log("environment: " + ", ".join(f"{k}={os.environ.get(k)}" for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
-                                                                                  "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")))
-            raise SystemExit(3)
+    except Exception as e:      # noqa: BLE001
+        if not use_dp:
+            raise
+        log(f"rank {rank}: first collective FAILED over backend {backend}: {type(e).__name__}: {e}")
+        log("environment: " + ", ".join(f"{k}={os.environ.get(k)}" for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                              "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")))
+        raise SystemExit(3)
 
-    run = Run(args, config, args.dropout, rank, dev, use_dp)
     log(f"rank {rank}/{world}: {config} model on {dev}, warm-up {args.warmup} steps")
     dt = run.timed(args.warmup, args.steps, strict=(world == 1))      # N > 1 has never run on xGMI: count and report, do not end the run
     alloc_growth = run.alloc_growth
     log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
     summary, n_inst = None, min(args.steps, 10)
     lib_gemm_per_step = None
+    in_step = None
     if not args.no_kernel_timer:
         summary = run.kernel_pass(n_inst)
         lib_gemm_per_step = run.lib_gemm_calls_per_step
+        in_step = run.kernel_pass(n_inst, in_step=True)
     if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -364,6 +390,9 @@ def main():
                                      "RCCL backend (gloo blocks the host instead)",
                 # replicas must stay identical: every rank receives the same reduced buckets and applies the same fused update
                 "replica_param_checksum_min": lo, "replica_param_checksum_max": hi, "replicas_identical": lo == hi,
+                # the step's streams were chosen by measurement (engine.pick_stream): each runs beside the others (no shared hardware queue / pipe)
+                "streams_independent": run.streams_independent(), "pool_draws_before_first_collective": run.dp.pool_draws,
+                "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "nccl_env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE")
                              if os.environ.get(k) is not None}}
         if lo != hi:
@@ -462,10 +491,14 @@ def main():
                 if k in MATRIX_FAMILIES:
                     tf = v["work_per_s"] / 1e12
                     row.update(flop_per_launch=v["work_per_launch"], tflops=tf, mfma_frac=tf / MFMA_BF16_PEAK_TFLOPS)
+                if in_step and k in in_step:
+                    row["in_step_avg_us"] = in_step[k]["avg_us"]
                 table[k] = row
             out["kernels"] = table
-            out["kernels_note"] = ("HIP events on the launch stream, weight-gradient overlap off (stand-alone durations); bytes / FLOP per launch are the "
-                                   "algorithmic figures of SURVEY.md 8(d) / DESIGN.md section 4; hbm_frac against 8 TB/s, mfma_frac against 2.5 PFLOP/s dense bf16")
+            out["kernels_note"] = ("HIP events on the launch stream.  avg_us and the fractions: weight-gradient overlap off (stand-alone durations); "
+                                   "in_step_avg_us: a second instrumented pass with both streams live, as in the timed region (includes what a kernel loses to "
+                                   "the kernels beside it); bytes / FLOP per launch are the algorithmic figures of SURVEY.md 8(d) / DESIGN.md section 4; "
+                                   "hbm_frac against 8 TB/s, mfma_frac against 2.5 PFLOP/s dense bf16")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, config)
         sys.stdout.flush()

@@ -630,3 +630,47 @@ def test_graphed_shapes_keep_their_decoder_buffers():
     b, _ = g.iterate(packs[0], optimizer=o2)
     torch.cuda.synchronize()
     assert abs(float(a.loss) - float(b.loss)) < 2e-3 * abs(float(a.loss)), (float(a.loss), float(b.loss))
+
+
+@pytest.mark.gpu
+def test_step_streams_are_chosen_by_measurement():
+    """The HIP runtime maps streams onto a few in-order hardware queues (and those onto fewer command-processor pipes) in the order in which a
+    process first USES them; two busy streams on one queue or one pipe do not run side by side (tools/queue_probe.py: 2.2 ms for two
+    chains of spin kernels on separate pipes, 4.4 on one queue, 5.5 on one pipe) and the two-stream training step then takes 2 - 2.5x as
+    long (round 4: through the data-parallel wrapper, or after a few unrelated streams had been used first).  engine.pick_stream tests
+    candidates and keeps one that runs beside the streams it must overlap with; engine.steer_stream_pool leaves torch's pool in front of
+    such a stream for the process group.  Here: a child process uses three unrelated pool streams first, then builds a model - its main,
+    weight-gradient and auxiliary streams must not conflict, the next pool stream after steering must not either, and the conflict test
+    itself must find at least one conflicting pair among twelve pool streams (there are only four hardware queues per priority)."""
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from asr_chinese_e2e_amd import engine as E, Models
+from asr_chinese_e2e_amd.data_handler import Vocab
+buf = torch.zeros(64, device="cuda")
+touched = [torch.cuda.Stream() for _ in range(3)]
+for s in touched:
+    with torch.cuda.stream(s):
+        buf.add_(1.0)
+torch.cuda.synchronize()
+M = Models.TransformerOffical
+cfg = M.get_default_config()(); cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=1, dropout=0.0, ctc_weight=0.3))
+model = M(cfg, Vocab.synthetic(60)).cuda()
+eng = model._ensure_engine(torch.device("cuda", 0))
+main = torch.cuda.current_stream()
+assert not E.streams_conflict(main, eng.side), "weight-gradient stream conflicts with the main stream"
+assert not E.streams_conflict(main, eng.ctc_stream) and not E.streams_conflict(eng.side, eng.ctc_stream), "auxiliary stream conflicts"
+draws = E.steer_stream_pool(torch.device("cuda", 0), [main, eng.side, eng.ctc_stream])
+assert draws > 0, draws
+nxt = torch.cuda.Stream()
+assert not any(E.streams_conflict(a, nxt) for a in (main, eng.side, eng.ctc_stream)), "the pool's next stream conflicts after steering"
+pool = [torch.cuda.Stream() for _ in range(12)]
+pairs = sum(E.streams_conflict(a, b) for i, a in enumerate(pool) for b in pool[i + 1:])
+assert pairs >= 1, "twelve pool streams on four hardware queues and no conflict found: the test cannot see conflicts"
+print("streams ok", draws, pairs)
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "streams ok" in p.stdout, p.stdout + p.stderr
