@@ -312,7 +312,7 @@ def pick_stream(device, avoid, factory=None, tries=12):
     cand = None
     for _ in range(tries):
         cand = factory()
-        if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing():
+        if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):      # (_sleep: the spin kernel of the test)
             return cand
         if not any(streams_conflict(a, cand) for a in avoid if a is not None):
             return cand
@@ -329,7 +329,7 @@ def steer_stream_pool(device, avoid, ring_max=64):
     streams per priority) at its first collective, and nothing lets the caller choose it; but the ring is deterministic: drawing streams
     until one repeats walks it once (every stream tested against `avoid` on the way), after which the position of the counter and the
     verdict for the stream behind it are known.  Returns how many draws it took, or -1 when no stream of the ring qualifies."""
-    if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing():
+    if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):
         return 0
     order, verdict = [], {}
     with torch.cuda.device(device):
