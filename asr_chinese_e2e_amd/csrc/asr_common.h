@@ -98,6 +98,11 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 // 16 lanes (quad swaps, half-row and row mirrors), two row broadcasts, one v_readlane.  As six __shfl_xor steps each of them was a
 // ds_bpermute_b32 through the LDS crossbar followed by s_waitcnt lgkmcnt(0): ~100 cycles of exposed latency per step, and the
 // one-wave-per-row kernels (LayerNorm) run two to four such reductions per row.
+// PRECONDITION (wave_sum, wave_max and block_sum / block_max on top of them): the WHOLE wave executes the call - all 64 lanes active, wave-uniform
+// control flow around it - because the result is read from lane 63 (v_readlane) and the row broadcasts feed from lanes 15 / 31.  The __shfl_xor form
+// they replaced returned a correct value on every active lane of a partial wave; these do not.  Every launch in this library that reaches them uses a
+// block size that is a multiple of 64 (checked at compile time where it is a constant: ASR_FULL_WAVES) and calls them outside divergent branches.
+#define ASR_FULL_WAVES(threads) static_assert((threads) % 64 == 0, "wave_sum / wave_max need full 64-lane waves: block sizes must be multiples of 64")
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float wave_dpp(float v) {      // lanes outside ROW_MASK, and lanes without a source, get 0 / keep v's identity
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
@@ -121,7 +126,7 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xC, 0xf, false)));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// block-wide sum for blocks of up to 1024 threads; `red` is >= 16 floats of LDS.  All threads
+// block-wide sum for blocks of up to 1024 threads (a multiple of 64: see the precondition above); `red` is >= 16 floats of LDS.  All threads
 // get the result.  Contains two barriers.
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

@@ -144,6 +144,7 @@ extern "C" int asr_stream_create(int priority, void** out_stream) {
 namespace {
 
 constexpr int EW_BLOCK = 256;
+ASR_FULL_WAVES(EW_BLOCK);
 static int ew_grid(size_t nvec) {
     size_t g = (nvec + EW_BLOCK - 1) / EW_BLOCK;
     return (int)(g < 2048 ? (g ? g : 1) : 2048);  // cap + grid-stride (guide G11)
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* mask, size_t
 
 // ---- optimizer -------------------------------------------------------------------------------
 constexpr int SS_BLOCK = 256;
+ASR_FULL_WAVES(SS_BLOCK);
 __global__ __launch_bounds__(SS_BLOCK) void sumsq_partial_kernel(const float* __restrict__ g, size_t n4, size_t n, float* __restrict__ part) {
     __shared__ float red[16];
     float s = 0.f;
