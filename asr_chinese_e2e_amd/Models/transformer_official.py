@@ -272,6 +272,32 @@ class _SpeechTransformer(BaseModel):
                     hyp_len=hyp_len, ref_len=ref_len)
         return (per.sum() * (100.0 / per.numel())).reshape(1)
 
+    CER_BESIDE_BACKWARD = True      # False: score the step's CER on the main stream behind the optimizer (A/B, tests)
+
+    def _cer_beside_backward(self, eng, pg):
+        """The per-step CER of the greedy ids (five small launches, ~65 us behind the optimizer on the main stream: 1.3 % of the joint step) on
+        the auxiliary stream instead, which is idle once the decoder's backward pass has joined it: it runs beside the encoder's backward pass,
+        and iterate() makes the main stream wait for its event before handing the metric out.  Returns (cer, event); the ids stay referenced by
+        the model until the next step (blocks of the main stream's pool read on another stream)."""
+        if not (self.CER_BESIDE_BACKWARD and eng.aux_overlap) or torch.cuda.is_current_stream_capturing():
+            return pg
+        eng._fork(eng.ctc_stream)
+        with torch.cuda.stream(eng.ctc_stream):
+            cer = self._cer_ids(pg[0], pg[1])
+        if getattr(self, "_cer_event", None) is None:
+            self._cer_event = torch.cuda.Event()
+        self._cer_event.record(eng.ctc_stream)
+        self._cer_keep = pg
+        return cer, self._cer_event
+
+    def _cer_of(self, pg):
+        """The CER tensor of what train_step returned: (cer, event) when it was computed on the auxiliary stream (the current stream then waits
+        for the event), else (ids, gold) to be scored here."""
+        if isinstance(pg[1], torch.cuda.Event):
+            torch.cuda.current_stream().wait_event(pg[1])
+            return pg[0]
+        return self._cer_ids(pg[0], pg[1])
+
     def _cer(self, pred, gold):
         """transformer_official.py:87-91.  Greedy ids by argmax (first index wins ties - the
         reference's topk(1) tie order at exactly-zero padded rows is implementation-defined)."""
@@ -368,6 +394,8 @@ class _SpeechTransformer(BaseModel):
             if d_enc is None:
                 d_enc = torch.zeros_like(enc)
             eng.decoder_bwd(dcache, dpred, d_enc, d_enc_ready=ctc_done)
+            if pg is not None:
+                pg = self._cer_beside_backward(eng, pg)
         eng.encoder_bwd(ecache, d_enc)
         loss = K.loss_combine(row_nll, n_valid, nll, (1.0 - lam) if self.use_ctc else 1.0, lam)
         return loss, pg
@@ -399,7 +427,7 @@ class _SpeechTransformer(BaseModel):
         if self.use_decoder and self.use_ctc:
             metrics.add(ce=loss[1], ctc=loss[2])
         if pg is not None:
-            metrics.add(cer=self._cer_ids(pg[0], pg[1]))      # no device-to-host copy, no sync
+            metrics.add(cer=self._cer_of(pg))                 # no device-to-host copy, no sync
         return metrics, None
 
     def greedy_search(self, input, decode_max_len=0):

@@ -254,7 +254,7 @@ class DataParallel:
         loss, pg = model.train_step(input, count_hook=self._counts.start)
         self.bucketer.finish()
         optimizer.fused_step(model._flat, CLIP_NORM)
-        cer = model._cer_ids(pg[0], pg[1]) if pg is not None else None      # of this rank's utterances, computed on the device
+        cer = model._cer_of(pg) if pg is not None else None      # of this rank's utterances, computed on the device (beside the backward pass)
         if not self.reduce_loss:      # rank-local loss estimate (no extra collective per step)
             metrics = Pack()
             metrics.add(loss=loss[0])
