@@ -420,6 +420,7 @@ __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, f
         coef = fminf(max_norm / (norm + 1e-6f), 1.f);
     }
     const float step_size = lr / bc1;
+    write_clipped = write_clipped && coef != 1.f;      // nothing clipped: g already holds what would be written (4 of 34 B per parameter less)
     for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * EW_BLOCK) {
         f32x4 gv = *(const f32x4*)(g + i * 4), mv = *(const f32x4*)(m + i * 4), vv = *(const f32x4*)(v + i * 4), pv = *(const f32x4*)(p + i * 4);
 #pragma unroll
