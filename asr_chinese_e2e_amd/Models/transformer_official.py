@@ -281,6 +281,7 @@ class _SpeechTransformer(BaseModel):
         the model until the next step (blocks of the main stream's pool read on another stream)."""
         if not (self.CER_BESIDE_BACKWARD and eng.aux_overlap) or torch.cuda.is_current_stream_capturing():
             return pg
+        eng._disarm()      # this fork is for the auxiliary stream: it must not consume a hand-over meant for the weight-gradient stream
         eng._fork(eng.ctc_stream)
         with torch.cuda.stream(eng.ctc_stream):
             cer = self._cer_ids(pg[0], pg[1])
