@@ -211,11 +211,28 @@ class Run:
         self.barrier()
         if self.dp is not None:
             self.dp.bucketer.exposed_ms()      # drop the warm-up steps' samples
+        # a full collection of this process takes ~80 ms (270 k tracked objects: tools/gc_probe in DESIGN section 5) and the steps themselves create almost
+        # nothing for it to find: collect now, then keep what exists out of the collector's way for the timed region (what a long-running trainer does)
+        import gc
+        gc.collect()
+        gc.freeze()
+        # five stream events inside the timed region (no host synchronisation): per-fifth step times, so that a one-off stall of the box
+        # (seen twice in round 4: 30 ms inside one 50-step region, gone in the next run) shows in the line instead of hiding in the mean
+        nchunk = min(5, steps)
+        bounds = [steps * (i + 1) // nchunk for i in range(nchunk)]
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nchunk + 1)]
         a0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
         t0 = time.perf_counter()
-        self.steps(steps)
+        evs[0].record()
+        done = 0
+        for i, upto in enumerate(bounds):
+            self.steps(upto - done)
+            done = upto
+            evs[i + 1].record()
         self.barrier()
         dt = time.perf_counter() - t0
+        self.chunk_ms = [round(evs[i].elapsed_time(evs[i + 1]) / max(1, bounds[i] - (bounds[i - 1] if i else 0)), 4) for i in range(nchunk)]
+        gc.unfreeze()
         self.alloc_growth = torch.cuda.memory_stats().get("num_device_alloc", 0) - a0
         if self.alloc_growth:
             log(f"{self.alloc_growth} device allocation(s) INSIDE the timed region ({'joint' if self.joint else 'ctc'} model, {warmup} warm-up steps)")
@@ -360,6 +377,7 @@ def main():
     log(f"rank {rank}/{world}: {config} model on {dev}, warm-up {args.warmup} steps")
     dt = run.timed(args.warmup, args.steps, strict=(world == 1))      # N > 1 has never run on xGMI: count and report, do not end the run
     alloc_growth = run.alloc_growth
+    headline_chunks = run.chunk_ms
     log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
     summary, n_inst = None, min(args.steps, 10)
     lib_gemm_per_step = None
@@ -416,6 +434,7 @@ def main():
         extras[f"{other}_ms_per_step"] = 1e3 * d2 / es
         extras[f"{other}_utterances_per_s"] = args.batch * es / d2
         extras_alloc = {other: r2.alloc_growth}
+        extras_chunks = {other: r2.chunk_ms}
         del r2
         gc.collect()
         if args.dropout == 0.0:
@@ -424,6 +443,7 @@ def main():
             extras["dropout_0.1_ms_per_step"] = 1e3 * d3 / es      # reference recipe: transformer_official.py:115-122
             extras["dropout_0.1_utterances_per_s"] = args.batch * es / d3
             extras_alloc["dropout_0.1"] = r3.alloc_growth
+            extras_chunks["dropout_0.1"] = r3.chunk_ms
             del r3
             gc.collect()
         # BASELINE.json configs[4] per GPU: long-form utterances (T = 2000 frames, +-50-frame attention band, batch 8), joint model
@@ -437,10 +457,12 @@ def main():
             extras["long_form_kernels"] = {k: {"avg_us": v["avg_us"], "launches_per_step": v["launches"] / min(es, 5)}
                                            for k, v in ks.items() if k in ("sdpa_fwd", "sdpa_bwd", "ctc", "gemm_nt", "gemm_tn")}
         extras_alloc["long_form"] = r4.alloc_growth
+        extras_chunks["long_form"] = r4.chunk_ms
         del r4
         gc.collect()
         extras["extras_protocol"] = f"{ew} warm-up + {es} timed steps each, caching allocator kept between configurations"
         extras["allocator_growth_in_timed_regions"] = dict(extras_alloc, headline=alloc_growth)
+        extras["ms_per_step_by_fifth_of_each_timed_region"] = dict(extras_chunks, headline=headline_chunks)
         log(f"extras: {extras}")
 
     if rank == 0:
@@ -452,6 +474,7 @@ def main():
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic", "ranks_formed": world, "allocator_growth_in_timed_region": alloc_growth,
             "frames_per_s": utt * args.frames, "final_loss": loss,
+            "ms_per_step_by_fifth": headline_chunks,      # rank 0's stream events inside the timed region: a stall of the box shows as one outlier
             "config": {"workload": (("configs[3]: data-parallel " if world > 1 else "configs[2]: ") + "joint CTC/attention (lambda=0.3) encoder-decoder" if joint else
                                     "configs[1]: 6-layer Transformer encoder + CTC-only") +
                                    f", bf16, per-GPU batch {args.batch}, T={args.frames}, F=80, V={args.vocab}, "
