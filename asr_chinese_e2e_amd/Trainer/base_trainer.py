@@ -10,6 +10,8 @@ e{epoch}_s{step}.model/.opt), same differences from Trainer11 as in the referenc
   * evaluation always logs under 'dev/' (base_trainer.py:117).
 TensorBoard is replaced by JSON lines, MetricsManager's string round trip by plain means (SURVEY.md section 2 row 4:
 out of scope)."""
+import gc
+
 from .trainer11 import Trainer11
 
 
@@ -28,6 +30,11 @@ class BaseTrainer(Trainer11):
         self.best = 1e10 if self.reference[0] == "-" else 0       # base_trainer.py:42
         if from_ckpt is not None:
             self.load_from_ckpt(*from_ckpt)
+        # the model, the engine's plans and the loaders exist by now: ~270 k collector-tracked objects that stay for the whole run.  A full
+        # collection over them takes ~80 ms - 25 training steps - and the steps themselves leave almost nothing to collect: move what exists
+        # out of the collector's way (bench.py does the same around its timed regions; round 4 traced its one-off 30-ms stalls to this)
+        gc.collect()
+        gc.freeze()
         for _ in range(self.config.num_epoch):
             self.train_epoch()
             self.global_epoch += 1

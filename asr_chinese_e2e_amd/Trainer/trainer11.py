@@ -3,6 +3,7 @@ minibatch, checkpoints named e{epoch}_s{step}.model/.opt, periodic evaluation.  
 `SummaryWriter(self.exp_root).add_scalar(tag, value, global_step)` puts them - a TensorBoard event file under
 exp_root (`self.summary_writer`, written by Utils/tfevents.py: the tensorboard package is not a dependency) -
 and, for scripts, to scalars.jsonl beside it."""
+import gc
 import datetime
 import json
 import os
@@ -49,6 +50,11 @@ class Trainer11:
     def train(self, from_ckpt=None, from_epoch=None, from_step=None):
         if from_ckpt is not None and from_epoch is not None and from_step is not None:
             self.load_from_ckpt(from_ckpt, from_epoch, from_step)
+        # the model, the engine's plans and the loaders exist by now: ~270 k collector-tracked objects that stay for the whole run.  A full
+        # collection over them takes ~80 ms - 25 training steps - and the steps themselves leave almost nothing to collect: move what exists
+        # out of the collector's way (bench.py does the same around its timed regions; round 4 traced its one-off 30-ms stalls to this)
+        gc.collect()
+        gc.freeze()
         for _ in range(self.config.num_epoch):
             self.train_epoch()
             self.global_epoch += 1

@@ -207,15 +207,16 @@ class Run:
         alive itself instead of Tensor.record_stream, so the allocation sequence repeats from the second step on (DESIGN.md section 5,
         round 4) - counted here, and with `strict` a non-zero count ends the run instead of reporting a number measured across it."""
         torch = self.torch
+        # a full collection of this process takes ~80 ms (270 k tracked objects) and the steps themselves create almost nothing for it to find:
+        # collect BEFORE the warm-up steps (an 80-ms pause of the host right in front of the timed region left the GPU idle and the first fifth
+        # 5 % slow), then keep what exists out of the collector's way until the region ends (what a long-running trainer does)
+        import gc
+        gc.collect()
+        gc.freeze()
         self.steps(warmup)
         self.barrier()
         if self.dp is not None:
             self.dp.bucketer.exposed_ms()      # drop the warm-up steps' samples
-        # a full collection of this process takes ~80 ms (270 k tracked objects: tools/gc_probe in DESIGN section 5) and the steps themselves create almost
-        # nothing for it to find: collect now, then keep what exists out of the collector's way for the timed region (what a long-running trainer does)
-        import gc
-        gc.collect()
-        gc.freeze()
         # five stream events inside the timed region (no host synchronisation): per-fifth step times, so that a one-off stall of the box
         # (seen twice in round 4: 30 ms inside one 50-step region, gone in the next run) shows in the line instead of hiding in the mean
         nchunk = min(5, steps)
