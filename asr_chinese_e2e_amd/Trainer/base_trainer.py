@@ -31,8 +31,9 @@ class BaseTrainer(Trainer11):
         if from_ckpt is not None:
             self.load_from_ckpt(*from_ckpt)
         # the model, the engine's plans and the loaders exist by now: ~270 k collector-tracked objects that stay for the whole run.  A full
-        # collection over them takes ~80 ms - 25 training steps - and the steps themselves leave almost nothing to collect: move what exists
-        # out of the collector's way (bench.py does the same around its timed regions; round 4 traced its one-off 30-ms stalls to this)
+        # collection over them takes ~80 ms - 25 training steps - and the steps themselves leave almost nothing to collect: collect once, then
+        # move what exists out of the collector's way (bench.py does the same in front of its timed regions, where it also removed the
+        # one-off 30-ms stalls of round 4: DESIGN.md section 5)
         gc.collect()
         gc.freeze()
         for _ in range(self.config.num_epoch):

@@ -211,8 +211,11 @@ class Run:
         # collect BEFORE the warm-up steps (an 80-ms pause of the host right in front of the timed region left the GPU idle and the first fifth
         # 5 % slow), then keep what exists out of the collector's way until the region ends (what a long-running trainer does)
         import gc
-        gc.collect()
-        gc.freeze()
+        mode = os.environ.get("BENCH_GC_FREEZE", "1")      # 0: collect but do not freeze; 2: neither (the state before this was added: to watch a pass land in a timed region)
+        if mode != "2":
+            gc.collect()
+        if mode == "1":
+            gc.freeze()
         self.steps(warmup)
         self.barrier()
         if self.dp is not None:
@@ -222,6 +225,14 @@ class Run:
         nchunk = min(5, steps)
         bounds = [steps * (i + 1) // nchunk for i in range(nchunk)]
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(nchunk + 1)]
+        passes = []      # (generation, ms) of every collector pass that starts inside the timed region
+
+        def on_gc(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                passes.append((info["generation"], round(1e3 * (time.perf_counter() - _t[0]), 2)))
+        gc.callbacks.append(on_gc)
         a0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
         t0 = time.perf_counter()
         evs[0].record()
@@ -233,6 +244,8 @@ class Run:
         self.barrier()
         dt = time.perf_counter() - t0
         self.chunk_ms = [round(evs[i].elapsed_time(evs[i + 1]) / max(1, bounds[i] - (bounds[i - 1] if i else 0)), 4) for i in range(nchunk)]
+        gc.callbacks.remove(on_gc)
+        self.gc_passes = [p for p in passes if p[0] >= 1 or p[1] >= 1.0]      # young-generation passes of microseconds are not worth a line
         gc.unfreeze()
         self.alloc_growth = torch.cuda.memory_stats().get("num_device_alloc", 0) - a0
         if self.alloc_growth:
@@ -379,6 +392,7 @@ def main():
     dt = run.timed(args.warmup, args.steps, strict=(world == 1))      # N > 1 has never run on xGMI: count and report, do not end the run
     alloc_growth = run.alloc_growth
     headline_chunks = run.chunk_ms
+    headline_gc = run.gc_passes
     log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
     summary, n_inst = None, min(args.steps, 10)
     lib_gemm_per_step = None
@@ -436,6 +450,7 @@ def main():
         extras[f"{other}_utterances_per_s"] = args.batch * es / d2
         extras_alloc = {other: r2.alloc_growth}
         extras_chunks = {other: r2.chunk_ms}
+        extras_gc = {other: r2.gc_passes}
         del r2
         gc.collect()
         if args.dropout == 0.0:
@@ -445,6 +460,7 @@ def main():
             extras["dropout_0.1_utterances_per_s"] = args.batch * es / d3
             extras_alloc["dropout_0.1"] = r3.alloc_growth
             extras_chunks["dropout_0.1"] = r3.chunk_ms
+            extras_gc["dropout_0.1"] = r3.gc_passes
             del r3
             gc.collect()
         # BASELINE.json configs[4] per GPU: long-form utterances (T = 2000 frames, +-50-frame attention band, batch 8), joint model
@@ -459,11 +475,13 @@ def main():
                                            for k, v in ks.items() if k in ("sdpa_fwd", "sdpa_bwd", "ctc", "gemm_nt", "gemm_tn")}
         extras_alloc["long_form"] = r4.alloc_growth
         extras_chunks["long_form"] = r4.chunk_ms
+        extras_gc["long_form"] = r4.gc_passes
         del r4
         gc.collect()
         extras["extras_protocol"] = f"{ew} warm-up + {es} timed steps each, caching allocator kept between configurations"
         extras["allocator_growth_in_timed_regions"] = dict(extras_alloc, headline=alloc_growth)
         extras["ms_per_step_by_fifth_of_each_timed_region"] = dict(extras_chunks, headline=headline_chunks)
+        extras["collector_passes_in_timed_regions"] = dict(extras_gc, headline=headline_gc)      # (generation, ms) each; [] = none
         log(f"extras: {extras}")
 
     if rank == 0:
