@@ -10,6 +10,7 @@ e{epoch}_s{step}.model/.opt), same differences from Trainer11 as in the referenc
   * evaluation always logs under 'dev/' (base_trainer.py:117).
 TensorBoard is replaced by JSON lines, MetricsManager's string round trip by plain means (SURVEY.md section 2 row 4:
 out of scope)."""
+import ctypes
 import gc
 
 from .trainer11 import Trainer11
@@ -30,11 +31,16 @@ class BaseTrainer(Trainer11):
         self.best = 1e10 if self.reference[0] == "-" else 0       # base_trainer.py:42
         if from_ckpt is not None:
             self.load_from_ckpt(*from_ckpt)
-        # the model, the engine's plans and the loaders exist by now: ~270 k collector-tracked objects that stay for the whole run.  A full
-        # collection over them takes ~80 ms - 25 training steps - and the steps themselves leave almost nothing to collect: collect once, then
-        # move what exists out of the collector's way (bench.py does the same in front of its timed regions, where it also removed the
-        # one-off 30-ms stalls of round 4: DESIGN.md section 5)
+        # the model, the engine's plans and the loaders exist by now.  (1) Their construction left a few hundred MB of freed host memory at the
+        # top of the C heap, which glibc hands back to the kernel at some later free() - a ~30-ms pause of this thread, ten training steps, at a
+        # random step (found in bench.py's timed regions, round 4: DESIGN.md section 5): hand it back now.  (2) ~270 k collector-tracked objects
+        # stay for the whole run; a full pass over them takes ~80 ms and the steps leave almost nothing to collect: collect once, then move what
+        # exists out of the collector's way.
         gc.collect()
+        try:
+            ctypes.CDLL("libc.so.6").malloc_trim(0)
+        except (OSError, AttributeError):
+            pass
         gc.freeze()
         for _ in range(self.config.num_epoch):
             self.train_epoch()

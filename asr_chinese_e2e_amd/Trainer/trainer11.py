@@ -3,6 +3,7 @@ minibatch, checkpoints named e{epoch}_s{step}.model/.opt, periodic evaluation.  
 `SummaryWriter(self.exp_root).add_scalar(tag, value, global_step)` puts them - a TensorBoard event file under
 exp_root (`self.summary_writer`, written by Utils/tfevents.py: the tensorboard package is not a dependency) -
 and, for scripts, to scalars.jsonl beside it."""
+import ctypes
 import gc
 import datetime
 import json
@@ -50,11 +51,16 @@ class Trainer11:
     def train(self, from_ckpt=None, from_epoch=None, from_step=None):
         if from_ckpt is not None and from_epoch is not None and from_step is not None:
             self.load_from_ckpt(from_ckpt, from_epoch, from_step)
-        # the model, the engine's plans and the loaders exist by now: ~270 k collector-tracked objects that stay for the whole run.  A full
-        # collection over them takes ~80 ms - 25 training steps - and the steps themselves leave almost nothing to collect: collect once, then
-        # move what exists out of the collector's way (bench.py does the same in front of its timed regions, where it also removed the
-        # one-off 30-ms stalls of round 4: DESIGN.md section 5)
+        # the model, the engine's plans and the loaders exist by now.  (1) Their construction left a few hundred MB of freed host memory at the
+        # top of the C heap, which glibc hands back to the kernel at some later free() - a ~30-ms pause of this thread, ten training steps, at a
+        # random step (found in bench.py's timed regions, round 4: DESIGN.md section 5): hand it back now.  (2) ~270 k collector-tracked objects
+        # stay for the whole run; a full pass over them takes ~80 ms and the steps leave almost nothing to collect: collect once, then move what
+        # exists out of the collector's way.
         gc.collect()
+        try:
+            ctypes.CDLL("libc.so.6").malloc_trim(0)
+        except (OSError, AttributeError):
+            pass
         gc.freeze()
         for _ in range(self.config.num_epoch):
             self.train_epoch()

@@ -207,14 +207,23 @@ class Run:
         alive itself instead of Tensor.record_stream, so the allocation sequence repeats from the second step on (DESIGN.md section 5,
         round 4) - counted here, and with `strict` a non-zero count ends the run instead of reporting a number measured across it."""
         torch = self.torch
-        # a full collection of this process takes ~80 ms (270 k tracked objects) and the steps themselves create almost nothing for it to find:
-        # collect BEFORE the warm-up steps (an 80-ms pause of the host right in front of the timed region left the GPU idle and the first fifth
-        # 5 % slow), then keep what exists out of the collector's way until the region ends (what a long-running trainer does)
+        # Building a model leaves a few hundred MB of freed host memory at the top of the C heap (parameter initialisation on the host), and glibc
+        # gives it back to the kernel at some LATER free(): one ~30-ms pause of the launching thread at a random step - seen as one fifth of a
+        # timed region running 40 % slow in 4 of 9 runs, with no collector pass in it (counted below); with malloc_trim(0) here: 0 of 8 runs
+        # (BENCH_PREP=trim), with collect + trim + freeze: 0 of 18.  So: collect what the construction left, trim the heap, and keep the
+        # survivors out of the collector's way (a full pass over this process takes 80 ms) - all BEFORE the warm-up steps: an 80-ms host pause
+        # right in front of the timed region left the GPU idle and the first fifth 5 % slow.  BENCH_PREP=none restores the old state.
+        import ctypes
         import gc
-        mode = os.environ.get("BENCH_GC_FREEZE", "1")      # 0: collect but do not freeze; 2: neither (the state before this was added: to watch a pass land in a timed region)
-        if mode != "2":
+        prep = os.environ.get("BENCH_PREP", "all")
+        if prep == "all":
             gc.collect()
-        if mode == "1":
+        if prep in ("all", "trim"):
+            try:
+                ctypes.CDLL("libc.so.6").malloc_trim(0)
+            except (OSError, AttributeError):
+                pass
+        if prep == "all":
             gc.freeze()
         self.steps(warmup)
         self.barrier()
