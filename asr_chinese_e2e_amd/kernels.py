@@ -2,6 +2,7 @@
 assumes (device, dtype, contiguity, shapes) ON THE HOST before launching, and passes raw device
 pointers + the current HIP stream.  PyTorch is only the allocator / stream provider here.
 """
+import threading
 import ctypes
 
 import torch
@@ -29,6 +30,8 @@ def _p(t):
 
 
 _DEV_INDEX = None
+_TLS = threading.local()   # .own_stream = True on a helper thread (the loader's): its launches never follow STREAM_OVERRIDE, which the
+                           # training thread sets around ITS side-stream launches
 STREAM_OVERRIDE = None     # raw stream handle (int) the next launches go to instead of torch's current stream:
                            # the engine sets it around its side-stream launches of own kernels, which saves the
                            # `with torch.cuda.stream(...)` context switch (~6 us of host time, 25 times per step)
@@ -39,7 +42,7 @@ def _stream():
     resolves the device index through several Python layers (~8 us, ~160 calls per step); the
     private raw getter is a single C call."""
     global _DEV_INDEX
-    if STREAM_OVERRIDE is not None:
+    if STREAM_OVERRIDE is not None and not getattr(_TLS, "own_stream", False):
         return STREAM_OVERRIDE
     if _DEV_INDEX is None:
         _DEV_INDEX = torch.cuda.current_device()   # one process per GPU: bind_device() (engine construction) or the first launch sets it
