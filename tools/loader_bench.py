@@ -12,6 +12,16 @@ B, S, NB = 32, 16000 * 5, 40
 rng = np.random.RandomState(0)
 vocab = Vocab.synthetic(4232)
 items = [((rng.randn(S) * 0.1).astype(np.float32), [int(t) for t in rng.randint(4, 4232, size=16)]) for _ in range(B * NB)]
+if os.environ.get("FILES") == "1":      # the same utterances as 16-bit WAV files (decoded by the loader)
+    import tempfile, wave
+    d = tempfile.mkdtemp(prefix="asr_wav_")
+    for i, (w, t) in enumerate(items):
+        path = os.path.join(d, f"u{i}.wav")
+        with wave.open(path, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((np.clip(w, -1, 1) * 32767).astype("<i2").tobytes())
+        items[i] = (path, t)
+    print(f"{len(items)} WAV files under {d}")
 ds = WaveDataset(items, vocab)
 parser = AudioParser(n_mels=80, lfr_m=1, lfr_n=1, device="cuda")
 M = Models.TransformerOffical if JOINT else Models.TransformerCTC
