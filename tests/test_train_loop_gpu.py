@@ -236,6 +236,41 @@ def test_any_torch_optimizer_still_works():
             assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), n
 
 
+def test_loader_prefetch_thread_order_labels_and_early_exit():
+    """BucketedWaveLoader prepares batches on a helper thread, two ahead, into reused pinned slots: an abandoned iteration must not leave the
+    thread (or a slot) behind, a second pass over the same loader yields the same batches as a loader built afresh (same seed), every label
+    row / length arrives as the dataset holds it, and more batches than staging slots pass through (slot reuse)."""
+    import threading
+    from asr_chinese_e2e_amd.data_handler import AudioParser, BucketedWaveLoader, Vocab, WaveDataset
+    rng = np.random.RandomState(3)
+    vocab = Vocab.synthetic(40)
+    items = [((rng.randn(int(rng.randint(4000, 9000))) * 0.1).astype(np.float32), [int(t) for t in rng.randint(4, 40, size=rng.randint(1, 6))]) for _ in range(37)]
+    ds = WaveDataset(items, vocab)
+    parser = AudioParser(n_mels=40, lfr_m=1, lfr_n=1, device="cuda")
+    mk = lambda: BucketedWaveLoader(ds, 4, parser=parser, augment=False, shuffle=True, seed=5, dtype=torch.float32)
+    loader = mk()
+    assert len(loader) == 10 > BucketedWaveLoader.SLOTS
+    it = iter(loader)
+    first = next(it)
+    it.close()                                                   # abandoned after one batch
+    torch.cuda.synchronize()
+    assert not [t for t in threading.enumerate() if t.name == "asr-loader" and t.is_alive()]
+    fresh = [p for p in mk()]
+    order = mk()._batches(__import__("random").Random(5))
+    assert len(fresh) == 10 and torch.equal(first.wave, fresh[0].wave)
+    for pack, idx in zip(fresh, order):
+        want_len = [len(items[i][1]) for i in idx]
+        assert pack.tgt_len.tolist() == want_len and pack.tgt_for_input.dtype == torch.int64
+        for r, i in enumerate(idx):
+            assert pack.tgt_for_input[r, :want_len[r]].tolist() == items[i][1] and int(pack.tgt_for_input[r, want_len[r]:].abs().sum()) == 0
+        assert torch.equal(pack.tgt_for_input, pack.tgt_for_metric) and pack.tgt_for_input.data_ptr() != pack.tgt_for_metric.data_ptr()
+        assert pack.wave.shape[0] == len(idx) and int(pack.wave_len.max()) == pack.wave.shape[1]
+    # a second pass over ONE loader object continues its random stream (new order), but still covers every utterance once
+    again = mk()
+    seen = sorted(int(n) for _ in range(2) for p in again for n in p.tgt_len.tolist())
+    assert seen == sorted([len(t) for _, t in items] * 2)
+
+
 def test_bucketed_wave_loader_feeds_the_model(tmp_path):
     """Waveforms -> bucketed loader (pinned copy on a side stream, log-mel / normalisation / SpecAugment /
     frame stacking on the GPU) -> the reference's batch contract -> a training step."""
