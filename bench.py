@@ -263,6 +263,31 @@ class Run:
                 raise SystemExit("bench: the caching allocator grew inside a timed region - the number would include hipMalloc synchronisations")
         return dt
 
+    def from_waveforms(self, nbatch=24, epochs=2):
+        """ms/step when the batches come from WAVEFORMS instead of one resident batch: `nbatch` batches of args.batch synthetic 5-s utterances
+        in host memory -> BucketedWaveLoader (pinned staging, two copies, log-mel / normalisation / SpecAugment on the loader's stream, a helper
+        thread two batches ahead) -> iterate.  One warm-up epoch, then `epochs` timed ones.  Never `value`: the contract's inputs are resident."""
+        import numpy as np
+        torch = self.torch
+        from asr_chinese_e2e_amd.data_handler import AudioParser, BucketedWaveLoader, WaveDataset
+        rng = np.random.RandomState(0)
+        B, S = self.args.batch, 16000 * 5
+        items = [((rng.randn(S) * 0.1).astype(np.float32), [int(t) for t in rng.randint(4, self.args.vocab, size=16)]) for _ in range(B * nbatch)]
+        dev = next(self.model.parameters()).device
+        loader = BucketedWaveLoader(WaveDataset(items, self.model.vocab), B, parser=AudioParser(n_mels=80, lfr_m=1, lfr_n=1, device=dev), augment=True, shuffle=True,
+                                    seed=1, dtype=torch.bfloat16, device=dev)
+
+        def epoch():
+            for pack in loader:
+                self.model.iterate(pack, optimizer=self.opt, is_train=True)
+        epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            epoch()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / (epochs * nbatch)
+
     def streams_independent(self):
         """True when main, weight-gradient, auxiliary and communication stream pairwise run side by side (engine.streams_conflict)."""
         from asr_chinese_e2e_amd import engine as E
@@ -486,6 +511,12 @@ def main():
         extras_chunks["long_form"] = r4.chunk_ms
         extras_gc["long_form"] = r4.gc_passes
         del r4
+        gc.collect()
+        # the headline configuration fed from waveforms through the loader (host staging + front end included): never `value`
+        r5 = Run(args, config, args.dropout, rank, dev, False)
+        extras[f"{config}_from_waveforms_ms_per_step"] = r5.from_waveforms()
+        extras["from_waveforms_config"] = "24 batches per epoch of synthetic 5-s utterances in host memory, SpecAugment on, BucketedWaveLoader (helper thread, 2 ahead); 1 warm-up + 2 timed epochs"
+        del r5
         gc.collect()
         extras["extras_protocol"] = f"{ew} warm-up + {es} timed steps each, caching allocator kept between configurations"
         extras["allocator_growth_in_timed_regions"] = dict(extras_alloc, headline=alloc_growth)
