@@ -239,23 +239,25 @@ class BucketedWaveLoader:
         stop = threading.Event()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()      # the consumer's device
 
+        def hand_over(item):      # False: the consumer is gone
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def work():
             K._TLS.own_stream = True      # never follow the training thread's stream override (kernels._stream)
             try:
                 torch.cuda.set_device(dev_index)
                 for k, idx in enumerate(batches):
-                    item = self._prepare(idx, k)
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
+                    if not hand_over(self._prepare(idx, k)):
                         return
-                q.put(None)
+                hand_over(None)
             except BaseException as e:      # noqa: BLE001 - handed to the consumer
-                q.put(e)
+                hand_over(e)
 
         th = threading.Thread(target=work, name="asr-loader", daemon=True)
         th.start()
