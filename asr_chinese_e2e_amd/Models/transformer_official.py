@@ -291,11 +291,31 @@ class _SpeechTransformer(BaseModel):
         self._cer_keep = pg
         return cer, self._cer_event
 
+    def _ctc_cer_beside_backward(self, eng, path, wave_len, labels32, lab_len):
+        """CTC-only model: collapse the greedy path and score it against the label strings (as cal_metrics does for a CTC-only model), on the
+        auxiliary stream beside the encoder's backward pass when the step runs on several streams.  Returns what _cer_of takes."""
+        def score():
+            ids, lens = K.ctc_collapse(path, wave_len, PAD_ID)
+            return self._cer_ids(ids, labels32, hyp_len=lens, ref_len=lab_len)
+        if not (self.CER_BESIDE_BACKWARD and eng.aux_overlap) or torch.cuda.is_current_stream_capturing():
+            return score(), None
+        eng._disarm()
+        eng._fork(eng.ctc_stream)
+        with torch.cuda.stream(eng.ctc_stream):
+            cer = score()
+        if getattr(self, "_cer_event", None) is None:
+            self._cer_event = torch.cuda.Event()
+        self._cer_event.record(eng.ctc_stream)
+        self._cer_keep = (path, wave_len, labels32, lab_len)      # blocks of the main stream's pool read on another stream: alive until the next step
+        return cer, self._cer_event
+
     def _cer_of(self, pg):
         """The CER tensor of what train_step returned: (cer, event) when it was computed on the auxiliary stream (the current stream then waits
         for the event), else (ids, gold) to be scored here."""
         if isinstance(pg[1], torch.cuda.Event):
             torch.cuda.current_stream().wait_event(pg[1])
+            return pg[0]
+        if pg[1] is None:      # already scored on the current stream
             return pg[0]
         return self._cer_ids(pg[0], pg[1])
 
@@ -390,7 +410,12 @@ class _SpeechTransformer(BaseModel):
             w_ce = (1.0 - lam) if self.use_ctc else 1.0
             row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, smoothing=self.label_smoothing, grad_scale=w_ce * loss_scale, dlogits=pred)
         if self.use_ctc and not ctc_async:
-            nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, **ctc_scale)
+            # CTC-only model: the step's CER (the reference's trainer reads metrics.cer every step, Trainer/trainer11.py:73-75) is scored on the
+            # greedy CTC path, which the loss kernels hand out (the gradient overwrites the logits in place)
+            path = torch.empty(B, T, dtype=torch.int32, device=enc.device) if (self.cer_in_iterate and not self.use_decoder) else None
+            nll, d_enc = eng.ctc_fwd_bwd(enc, wave_len, labels32, lab_len, B, T, best_path=path, **ctc_scale)
+            if path is not None:
+                pg = self._ctc_cer_beside_backward(eng, path, wave_len, labels32, lab_len)
         if self.use_decoder:
             if d_enc is None:
                 d_enc = torch.zeros_like(enc)

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -81,8 +81,10 @@ SIGNATURES = {
     "asr_dropout_mask": (I, [P, I, I, F, U, P]),
     "asr_sdpa_dropout_mask": (I, [P, I, I, I, I, F, U, P]),
     "asr_ctc_workspace_bytes": (Z, [I, I, I]),
-    "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, I, P, Z, I, P]),
+    "asr_ctc_fwd_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, I, P, P, Z, I, P]),
     "asr_ctc_greedy_decode": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "asr_ctc_frame_argmax": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "asr_ctc_collapse": (I, [P, P, P, I, I, I, P]),
     "asr_decode_attn": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, I, P]),
     "asr_logsoftmax_topk": (I, [P, P, P, I, I, I, I, I, P]),
     "asr_ctc_frame_topk": (I, [P, P, P, P, I, I, I, I, I, I, P]),

@@ -111,7 +111,7 @@ __device__ __forceinline__ void wave_row_load(const bf16_t* __restrict__ x, int 
 // log-sum-exp of the row in xv: all loads in flight at once, ONE maximum, then one fma + v_exp_f32
 // per element (the online form costs an extra rescale exp per vector and a precise expf per element)
 template <int NV>
-__device__ __forceinline__ float wave_row_lse_regs(const u32x4 (&xv)[NV], int nvec, int lane) {
+__device__ __forceinline__ float wave_row_lse_regs(const u32x4 (&xv)[NV], int nvec, int lane, float* row_max = nullptr) {
     float m = NEG_INF;
 #pragma unroll
     for (int k = 0; k < NV; ++k)
@@ -119,6 +119,7 @@ __device__ __forceinline__ float wave_row_lse_regs(const u32x4 (&xv)[NV], int nv
         for (int j = 0; j < 4; ++j) m = fmaxf(m, fmaxf(bf16_lo(xv[k][j]), bf16_hi(xv[k][j])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (row_max) *row_max = m;
     const float mb = m * LOG2E;
     float s = 0.f;
 #pragma unroll
@@ -132,6 +133,27 @@ __device__ __forceinline__ float wave_row_lse_regs(const u32x4 (&xv)[NV], int nv
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     return m + __logf(s);
+}
+
+// Index of the FIRST element of the row that equals its maximum m (torch.argmax's tie rule): every lane scans its vectors from the
+// last to the first (a lane's indices ascend with k and inside a vector, so the last overwrite is its smallest), then a wave minimum.
+// Out-of-range vectors repeat the row's last vector (wave_row_load): excluded.
+template <int NV>
+__device__ __forceinline__ int wave_row_argmax_regs(const u32x4 (&xv)[NV], int nvec, int lane, float m) {
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = NV - 1; k >= 0; --k) {
+        const int i = lane + 64 * k;
+        const int base = i < nvec ? i * 8 : 0x7ffffff0;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            bi = bf16_hi(xv[k][j]) == m ? base + 2 * j + 1 : bi;
+            bi = bf16_lo(xv[k][j]) == m ? base + 2 * j : bi;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bi = min(bi, __shfl_xor(bi, o, 64));
+    return bi;
 }
 
 // ---------------------------------------------------------------------------------- lattice layout
@@ -173,11 +195,14 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict
 // (at most L + 1) classes that occur in the label sequence.  One pass over the logits less than with a
 // separate gradient kernel (270 instead of 406 MB at config 2).  dlogits may alias logits (no __restrict__:
 // the gathers below must stay in front of the stores).
-template <int NV, bool WRITE>
+// PATH: the wave also writes the frame's best class (first index of the row maximum; `blank` for padded frames) to best_path - the
+// greedy CTC path of the training step's CER, taken from the row while it is in registers (the gradient overwrites the logits in place).
+template <int NV, bool WRITE, bool PATH>
 __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* logits, const int32_t* __restrict__ in_len,
                                                                   const int32_t* __restrict__ labels, const int32_t* __restrict__ lab_len,
                                                                   double* __restrict__ lp, float* __restrict__ lse_out, int B, int T_, int V, int ld, int Lmax,
-                                                                  int W, int blank, bf16_t* dlogits, float scale_in, const float* __restrict__ scale_div) {
+                                                                  int W, int blank, bf16_t* dlogits, float scale_in, const float* __restrict__ scale_div,
+                                                                  int32_t* __restrict__ best_path) {
     const float scale = scale_div ? scale_in / *scale_div : scale_in;     // scale_div: a device scalar (global batch under data parallelism)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = B * T_, nvec = V >> 3;
@@ -188,6 +213,7 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* 
                 const u32x4 z = {0u, 0u, 0u, 0u};
                 for (int i = lane; i < nvec; i += 64) *(u32x4*)(dlogits + (size_t)row * ld + (size_t)i * 8) = z;
             }
+            if (PATH && lane == 0) best_path[row] = blank;
             continue;
         }
         const bf16_t* x = logits + (size_t)row * ld;
@@ -202,8 +228,13 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* 
             xl[j] = (i < W) ? (float)x[labels[(size_t)b * Lmax + min(i, Lmax - 1)]] : 0.f;
         }
         const float xb = (float)x[blank];
-        const float lse = wave_row_lse_regs<NV>(xv, nvec, lane);
+        float row_max;
+        const float lse = wave_row_lse_regs<NV>(xv, nvec, lane, &row_max);
         if (lane == 0) lse_out[row] = lse;
+        if (PATH) {
+            const int bi = wave_row_argmax_regs<NV>(xv, nvec, lane, row_max);
+            if (lane == 0) best_path[row] = bi;
+        }
         if (WRITE) {
             bf16_t* dl = dlogits + (size_t)row * ld;
             const float lb = lse * LOG2E;
@@ -701,7 +732,7 @@ extern "C" size_t asr_ctc_workspace_bytes(int B, int T, int Lmax) {
 
 extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len, const int32_t* labels, const int32_t* lab_len,
                                float* nll, int B, int T, int V, int ld, int Lmax, int blank, float grad_scale, const float* grad_scale_div,
-                               int zero_infinity, void* ws, size_t ws_bytes, int dtype, void* stream) {
+                               int zero_infinity, int32_t* best_path, void* ws, size_t ws_bytes, int dtype, void* stream) {
     if (!logits || !in_len || !labels || !lab_len || !nll || !ws) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: null pointer");
     if (B <= 0 || T <= 0 || V <= 1 || Lmax <= 0 || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: bad shape B=%d T=%d V=%d Lmax=%d blank=%d", B, T, V, Lmax, blank);
     if (ld < V || (ld != V && ld % 8)) ASR_FAIL(ASR_EINVAL, "asr_ctc_fwd_bwd: row stride ld=%d (V=%d): V, or a multiple of 8 above it", ld, V);
@@ -732,15 +763,27 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
         else if (need <= 12) { CALL(12); } \
         else { CALL(16); }            \
     } while (0)
+    if (best_path && !rows_path) {      // fp32 / odd shapes: the decoding kernel, in front of the gradient kernel that may overwrite the logits in place
+        const int rc = asr_ctc_frame_argmax(logits, in_len, best_path, B, T, V, ld, blank, dtype, stream);
+        if (rc != ASR_OK) return rc;
+    }
     if (rows_path) {
         // with a gradient: the softmax part of it is written by the same wave that reduces the row (one pass over the logits less than
         // with a separate row-in-registers gradient kernel: 110 vs 127 us; that kernel, ctc_grad_rows_kernel, is in the git history)
-        if (dlogits) {
-#define K1(NV) ctc_lse_gather_rows_kernel<NV, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, (bf16_t*)dlogits, grad_scale, grad_scale_div)
+        if (dlogits && best_path) {
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, true, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, (bf16_t*)dlogits, grad_scale, grad_scale_div, best_path)
+            ROWS_DISPATCH(K1);
+#undef K1
+        } else if (dlogits) {
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, true, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, (bf16_t*)dlogits, grad_scale, grad_scale_div, nullptr)
+            ROWS_DISPATCH(K1);
+#undef K1
+        } else if (best_path) {
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, false, true><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, nullptr, 0.f, nullptr, best_path)
             ROWS_DISPATCH(K1);
 #undef K1
         } else {
-#define K1(NV) ctc_lse_gather_rows_kernel<NV, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, nullptr, 0.f, nullptr)
+#define K1(NV) ctc_lse_gather_rows_kernel<NV, false, false><<<g1, 256, 0, st>>>((const bf16_t*)logits, in_len, labels, lab_len, lp, lse, B, T, V, ld, Lmax, W, blank, nullptr, 0.f, nullptr, nullptr)
             ROWS_DISPATCH(K1);
 #undef K1
         }

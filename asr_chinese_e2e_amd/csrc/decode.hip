@@ -89,21 +89,35 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(int32_t* __restrict__ 
 
 }  // namespace
 
-extern "C" int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* out_ids, int32_t* out_len, int B, int T, int V, int ld, int blank,
-                                     int dtype, void* stream) {
-    if (!logits || !in_len || !out_ids || !out_len) ASR_FAIL(ASR_EINVAL, "asr_ctc_greedy_decode: null pointer");
-    if (B <= 0 || T <= 0 || V <= 1 || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_greedy_decode: bad shape B=%d T=%d V=%d blank=%d", B, T, V, blank);
-    if (ld < V) ASR_FAIL(ASR_EINVAL, "asr_ctc_greedy_decode: row stride ld=%d < V=%d", ld, V);
-    if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_ctc_greedy_decode: dtype %d", dtype);
+extern "C" int asr_ctc_frame_argmax(const void* logits, const int32_t* in_len, int32_t* path, int B, int T, int V, int ld, int blank, int dtype, void* stream) {
+    if (!logits || !in_len || !path) ASR_FAIL(ASR_EINVAL, "asr_ctc_frame_argmax: null pointer");
+    if (B <= 0 || T <= 0 || V <= 1 || blank < 0 || blank >= V) ASR_FAIL(ASR_EINVAL, "asr_ctc_frame_argmax: bad shape B=%d T=%d V=%d blank=%d", B, T, V, blank);
+    if (ld < V) ASR_FAIL(ASR_EINVAL, "asr_ctc_frame_argmax: row stride ld=%d < V=%d", ld, V);
+    if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_ctc_frame_argmax: dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
     const int rows = B * T;
     int g = ceil_div(rows, 4);
     if (g > 4096) g = 4096;
-    if (dtype == ASR_F32) frame_argmax_kernel<float><<<g, 256, 0, st>>>((const float*)logits, in_len, out_ids, B, T, V, ld, blank);
-    else frame_argmax_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)logits, in_len, out_ids, B, T, V, ld, blank);
-    ctc_collapse_kernel<<<B, 64, 0, st>>>(out_ids, in_len, out_len, T, blank);
-    ASR_CHECK_LAUNCH("asr_ctc_greedy_decode");
+    if (dtype == ASR_F32) frame_argmax_kernel<float><<<g, 256, 0, st>>>((const float*)logits, in_len, path, B, T, V, ld, blank);
+    else frame_argmax_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)logits, in_len, path, B, T, V, ld, blank);
+    ASR_CHECK_LAUNCH("asr_ctc_frame_argmax");
     return ASR_OK;
+}
+
+extern "C" int asr_ctc_collapse(int32_t* ids, const int32_t* in_len, int32_t* out_len, int B, int T, int blank, void* stream) {
+    if (!ids || !in_len || !out_len) ASR_FAIL(ASR_EINVAL, "asr_ctc_collapse: null pointer");
+    if (B <= 0 || T <= 0 || blank < 0) ASR_FAIL(ASR_EINVAL, "asr_ctc_collapse: bad shape B=%d T=%d blank=%d", B, T, blank);
+    ctc_collapse_kernel<<<B, 64, 0, (hipStream_t)stream>>>(ids, in_len, out_len, T, blank);
+    ASR_CHECK_LAUNCH("asr_ctc_collapse");
+    return ASR_OK;
+}
+
+extern "C" int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* out_ids, int32_t* out_len, int B, int T, int V, int ld, int blank,
+                                     int dtype, void* stream) {
+    if (!out_len) ASR_FAIL(ASR_EINVAL, "asr_ctc_greedy_decode: null pointer");
+    const int rc = asr_ctc_frame_argmax(logits, in_len, out_ids, B, T, V, ld, blank, dtype, stream);
+    if (rc != ASR_OK) return rc;
+    return asr_ctc_collapse(out_ids, in_len, out_len, B, T, blank, stream);
 }
 
 // ================================================================================================

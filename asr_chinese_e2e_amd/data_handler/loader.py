@@ -12,8 +12,11 @@ from length buckets so that padding stays small.
 The yielded Pack has the reference's batch contract (collat, ai_shell_1.py:75-88): wave (B, T, F),
 wave_len, tgt_for_input, tgt_for_metric (0-padded, int64), tgt_len.
 """
+import contextlib
 import random
+import threading
 import wave as wave_module
+import weakref
 
 import numpy as np
 import torch
@@ -68,10 +71,13 @@ class WaveDataset:
                 if sr != self.sample_rate:
                     raise ValueError(f"{w}: sample rate {sr}, expected {self.sample_rate}")
                 pcm = np.frombuffer(f.readframes(n), dtype="<i2")
-            if ch > 1:
-                row[:n] = pcm.reshape(-1, ch).mean(axis=1) / 32768.0
+            # the sample count is what the file actually holds (a data chunk shorter than its header says is a truncated recording, not an
+            # error), never more than the row the loader sized from the header
+            n = min(pcm.size // ch, row.size)
+            if ch > 1:      # same arithmetic as load_wav: scale in float32, then average the channels
+                row[:n] = (pcm[:n * ch].astype(np.float32) / np.float32(32768.0)).reshape(-1, ch).mean(axis=1)
             else:
-                np.multiply(pcm, np.float32(1.0 / 32768.0), out=row[:n], casting="unsafe")
+                np.multiply(pcm[:n], np.float32(1.0 / 32768.0), out=row[:n], casting="unsafe")
         else:
             a = np.asarray(w, dtype=np.float32).reshape(-1)
             n = a.size
@@ -125,8 +131,30 @@ def shard_batches(batches, rank, world):
     return batches[: len(batches) // world * world][rank::world]
 
 
+_LOADERS = weakref.WeakSet()      # loaders of this process (paused() holds every one's gate)
+
+
+@contextlib.contextmanager
+def paused():
+    """No loader's helper thread touches the GPU runtime inside this block: each helper takes its loader's gate around the preparation of a
+    batch (pinned allocations, copies, front-end kernels, event calls), and this context holds all the gates.  graph.GraphedStep wraps its
+    warm-up and capture in it: under torch.cuda.graph's default capture mode an allocation or an event synchronisation on ANOTHER thread
+    invalidates the capture (round-4 ADVICE).  Work a helper has already queued on its stream keeps running - only API calls matter."""
+    gates = [l._gate for l in list(_LOADERS)]
+    for g in gates:
+        g.acquire()
+    try:
+        yield
+    finally:
+        for g in reversed(gates):
+            g.release()
+
+
 class BucketedWaveLoader:
-    """Iterating yields Packs on `device`; one batch is prepared ahead on a side stream."""
+    """Iterating yields Packs on `device`; batches are prepared ahead on the loader's stream by a helper thread.
+    A yielded Pack (and every tensor in it) is valid until the NEXT one is requested: its memory belongs to a staging slot that the helper
+    reuses SLOTS batches later, ordered behind an event the consumer's stream records when it asks for the next batch (copy what must live
+    longer)."""
 
     def __init__(self, dataset, batch_size, parser=None, augment=False, shuffle=True, drop_last=False, seed=0, bucket_size=None,
                  device="cuda", dtype=torch.bfloat16, rank=0, world=1):
@@ -146,13 +174,15 @@ class BucketedWaveLoader:
         self.bucket_size = bucket_size
         self.stream = self._copy_stream()
         self.lengths = [dataset.num_samples(i) for i in range(len(dataset))]
+        self._gate = threading.Lock()      # held by the helper thread around _prepare; paused() takes it
+        _LOADERS.add(self)
 
     def _copy_stream(self):
-        """The stream of the host-to-device copies and the feature front end of the NEXT batch: on a hardware queue other than the current
-        (training) stream's, or the copies would queue behind the training step's kernels (engine.pick_stream)."""
+        """The stream of the host-to-device copies and the feature front end of the NEXT batch: ONE per device and process, on a hardware
+        queue other than the training stream's and the engine's weight-gradient / auxiliary streams' - whichever of the two is built first
+        (engine.shared_stream keeps the registry: a stream chosen later avoids every stream chosen before it)."""
         from .. import engine as E
-        with torch.cuda.device(self.device):
-            return E.pick_stream(self.device, [torch.cuda.current_stream()])
+        return E.shared_stream(self.device, "loader")
 
     def __len__(self):
         n = len(self.ds)
@@ -170,17 +200,24 @@ class BucketedWaveLoader:
     SLOTS = 4
 
     def _slot(self, k, n_wave, n_meta):
+        """Staging slot k, free for a new batch.  A slot owns the pinned host buffers AND the device tensors of the batch it staged last
+        (`keep`): those go back to the loader stream's pool only here, SLOTS batches later, after the loader's stream has been made to wait
+        for `consumed` - the event the consumer's stream recorded when it asked for the batch after that one.  (Round 4 marked every tensor
+        of a pack with Tensor.record_stream instead: the mechanism that made the caching allocator regrow by hipMalloc in the engine.)"""
         slots = self.__dict__.setdefault("_slots", [None] * self.SLOTS)
         s = slots[k]
+        if s is not None:
+            s["copied"].synchronize()      # the copy out of this slot (SLOTS batches ago) has run: the host may overwrite the pinned buffers
+            if s["handed"]:
+                self.stream.wait_event(s["consumed"])      # recorded before the consumer took the batch after this slot's (see __iter__)
+            s["keep"], s["handed"] = None, False
         if s is None or s["wave"].numel() < n_wave or s["meta"].numel() < n_meta:
             cap_w = max(n_wave, s["wave"].numel() if s else 0) * 5 // 4
             cap_m = max(n_meta, s["meta"].numel() if s else 0) * 2
             s = dict(wave=torch.empty(cap_w, dtype=torch.float32, pin_memory=True), meta=torch.empty(cap_m, dtype=torch.int32, pin_memory=True),
-                     copied=torch.cuda.Event())
+                     copied=torch.cuda.Event(), consumed=torch.cuda.Event(), keep=None, handed=False)
             s["wave_np"], s["meta_np"] = s["wave"].numpy(), s["meta"].numpy()
             slots[k] = s
-        else:
-            s["copied"].synchronize()      # the copy out of this slot (four batches ago) has run
         return s
 
     def _prepare(self, idx, k=0):
@@ -224,7 +261,8 @@ class BucketedWaveLoader:
             pack.add(wave=feat, wave_len=feat_len.long(), tgt_for_input=tgt_dev, tgt_for_metric=tgt_dev.clone(), tgt_len=dev_meta[B:2 * B].long())
             done = torch.cuda.Event()
             done.record()
-        return pack, done
+        slot["keep"] = (dev_wav, dev_meta, feat, feat_len) + tuple(v for v in pack.values() if torch.is_tensor(v))
+        return pack, done, slot
 
     PREFETCH = 2      # batches prepared ahead by the helper thread
 
@@ -232,7 +270,6 @@ class BucketedWaveLoader:
         """Batches are prepared by a helper thread, PREFETCH ahead: decoding / padding into the pinned slot (memcpy: no GIL), the two
         host-to-device copies and the feature kernels on the loader's stream.  The consumer's stream waits for the batch's event."""
         import queue
-        import threading
         from .. import kernels as K
         batches = self._batches(self.rng)
         q = queue.Queue(maxsize=self.PREFETCH)
@@ -253,7 +290,9 @@ class BucketedWaveLoader:
             try:
                 torch.cuda.set_device(dev_index)
                 for k, idx in enumerate(batches):
-                    if not hand_over(self._prepare(idx, k)):
+                    with self._gate:      # paused() (a hipGraph capture on the consumer thread) keeps this thread off the GPU runtime
+                        item = self._prepare(idx, k)
+                    if not hand_over(item):
                         return
                 hand_over(None)
             except BaseException as e:      # noqa: BLE001 - handed to the consumer
@@ -261,22 +300,30 @@ class BucketedWaveLoader:
 
         th = threading.Thread(target=work, name="asr-loader", daemon=True)
         th.start()
+        last = None      # slot of the batch the consumer is working on
         try:
             while True:
+                if last is not None:
+                    # the consumer is back for the next batch: everything it queued on its stream with the previous one is in front of this
+                    # event, and the helper makes the loader's stream wait for it before that slot's device memory is reused (SLOTS batches
+                    # later; the queue's depth guarantees the record happens before the helper gets there, see _slot)
+                    last["consumed"].record(torch.cuda.current_stream())
+                    last["handed"] = True
+                    last = None
                 item = q.get()
                 if item is None:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                pack, done = item
+                pack, done, last = item
                 torch.cuda.current_stream().wait_event(done)
-                for v in pack.values():
-                    if torch.is_tensor(v):
-                        v.record_stream(torch.cuda.current_stream())
                 yield pack
         finally:
             stop.set()
             th.join(timeout=5.0)
+            if last is not None:      # the consumer left in the middle of an epoch
+                last["consumed"].record(torch.cuda.current_stream())
+                last["handed"] = True
 
 def build_dataloader(collector_path, vocab, batch_size, part="test", use_cuda=True, sample_rate=16000, window_size=400, n_mels=40,
                      augment=False, predump=False, use_old=False, lfr_m=4, lfr_n=3, dtype=torch.bfloat16, shuffle=None, seed=0,

@@ -94,7 +94,9 @@ class GradBucketer:
         self.comm_stream = None
         if self.cuda:
             from . import engine as E
-            self.comm_stream = E.pick_stream(flat_g.device, [torch.cuda.current_stream()] + list(avoid_streams))
+            avoid = [torch.cuda.current_stream()] + list(avoid_streams)
+            avoid += [s for s in E.registered_streams(flat_g.device) if all(s is not a for a in avoid)]      # e.g. a loader's copy stream
+            self.comm_stream = E.pick_stream(flat_g.device, avoid)
         self.wire = None
         if wire_dtype is not None and wire_dtype != flat_g.dtype:
             if not self.cuda:
@@ -233,7 +235,9 @@ class DataParallel:
         self.pool_draws = 0
         if flat.g.is_cuda:
             from . import engine as E
-            self.pool_draws = E.steer_stream_pool(flat.g.device, [torch.cuda.current_stream()] + list(compute_streams))
+            avoid = [torch.cuda.current_stream()] + list(compute_streams)
+            avoid += [s for s in E.registered_streams(flat.g.device) if all(s is not a for a in avoid)]
+            self.pool_draws = E.steer_stream_pool(flat.g.device, avoid)
         dist.broadcast(flat.p, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)          # identical replicas
         flat.refresh_lowp()
         self._counts = _Counts(torch.zeros(2, dtype=torch.float32, device=flat.g.device), self.bucketer.comm_stream, group)

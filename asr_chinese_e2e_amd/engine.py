@@ -350,22 +350,33 @@ def steer_stream_pool(device, avoid, ring_max=64):
         return draws
 
 
-def _shared_stream(device, kind):
+def shared_stream(device, kind):
     """One auxiliary stream of each kind per device and PROCESS, shared by every engine (engines of one process run their steps one
     after the other, so sharing costs nothing; a second set of streams would only compete for the few hardware queues), each on a
-    hardware queue of its own (pick_stream): "wgrad" - the weight-gradient stream, lowest priority - against the current (main) stream,
-    "aux" (the CTC branch / cross-attention K|V work beside the decoder; normal priority: at the lowest 5.49 vs 5.48 ms, nothing) against
-    the main and the weight-gradient stream."""
+    hardware queue of its own (pick_stream): "wgrad" - the weight-gradient stream, lowest priority; "aux" (the CTC branch /
+    cross-attention K|V work beside the decoder; normal priority: at the lowest 5.49 vs 5.48 ms, nothing); "comm" (dist.GradBucketer's
+    all-reduces); "loader" (data_handler.loader's copies and front-end kernels).  A stream is tested against the current (main) stream
+    and against EVERY stream registered before it for the device, whatever the order in which a process builds its loader, model and
+    data-parallel wrapper (round-4 ADVICE: the loader's stream used to be picked against the main stream only)."""
     dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     key = (dev.index, kind)
     if key not in _STREAMS:
         with torch.cuda.device(dev):
-            main = torch.cuda.current_stream()
-            if kind == "wgrad":
-                _STREAMS[key] = pick_stream(dev, [main], factory=lambda: _side_stream(dev))
-            else:
-                _STREAMS[key] = pick_stream(dev, [main, _shared_stream(dev, "wgrad")])
+            avoid = [torch.cuda.current_stream()] + [s for (i, _), s in _STREAMS.items() if i == dev.index]
+            _STREAMS[key] = pick_stream(dev, avoid, factory=(lambda: _side_stream(dev)) if kind == "wgrad" else None)
     return _STREAMS[key]
+
+
+_shared_stream = shared_stream
+
+
+def registered_streams(device):
+    """Every stream chosen so far for this device (weight-gradient, auxiliary, loader, ...): what a stream chosen later must run beside."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return [s for (i, _), s in _STREAMS.items() if i == idx]
 
 
 def _side_stream(device):
@@ -459,9 +470,9 @@ class Engine:
         # latency-bound kernels of both chains fill each other's idle CUs.
         # the CTC branch of the joint model runs on its own stream beside the decoder's forward pass (ctc_branch_async);
         # off in deterministic mode (the weight gradients then share one scratch buffer on whatever stream is current)
+        self.side = _shared_stream(flat.device, "wgrad")      # first: the stream the step depends on most gets the first pick
         self.ctc_stream = _shared_stream(flat.device, "aux")
         self.ws_ctc = K.Workspace(flat.device)
-        self.side = _shared_stream(flat.device, "wgrad")
         self._side_handle = self.side.cuda_stream
         self._events, self._ev_next = [torch.cuda.Event() for _ in range(64)], 0     # reused round-robin (a wait captures the record it follows)
         # ---- environment switches of the engine (all read here, when the engine is built; the complete list is in README.md):
@@ -898,8 +909,9 @@ class Engine:
         self._keep += (enc, wave_len, labels32, lab_len, nll, d_enc)
         return nll, d_enc, done
 
-    def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None, ws=None):
-        """Returns (nll (B,), d_enc contribution or None)."""
+    def ctc_fwd_bwd(self, enc, wave_len, labels32, lab_len, B, T, grad_scale, want_grad=True, grad_scale_div=None, ws=None, best_path=None):
+        """Returns (nll (B,), d_enc contribution or None).  best_path: optional (B, T) int32 tensor for the frame-wise argmax of the
+        logits (the greedy path of the step's CER; the gradient overwrites the logits in place, so it is taken inside the loss kernels)."""
         buf = torch.empty(B * T, self.ld_v, dtype=enc.dtype, device=enc.device)      # rows padded to whole lines (see self.ld_v)
         ws = ws if ws is not None else self.ws
         logits = self.ctc_lo.fwd(enc, out=buf[:, :self.V])
@@ -907,7 +919,7 @@ class Engine:
         if want_grad:
             self._arm()      # the head's weight gradient follows the loss kernels directly
         nll, dl = K.ctc_fwd_bwd(frames, wave_len, labels32, lab_len, ws, blank=0, grad_scale=grad_scale,
-                                dlogits=frames if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div)
+                                dlogits=frames if want_grad else None, want_grad=want_grad, grad_scale_div=grad_scale_div, best_path=best_path)
         if not want_grad:
             return nll, None
         dl = logits      # the gradient was written in place

@@ -36,20 +36,26 @@ class GraphedStep:
 
         def body():
             model.zero_flat_grads()
-            loss, _ = model.train_step(self.static)
+            loss, pg = model.train_step(self.static)
             optimizer.fused_step(flat, CLIP_NORM)
-            return loss
+            cer = model._cer_of(pg) if pg is not None else None      # the step's CER (iterate's `cer` key), scored inside the graph
+            return loss, cer
 
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                body()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = body()
+        # A loader's helper thread (data_handler.loader) allocates pinned memory, grows the caching allocator and synchronises events while
+        # it prepares the next batches: under torch.cuda.graph's default capture mode any such call on another thread invalidates the
+        # capture.  loader.paused() holds every loader's gate for the warm-up and the capture (round-4 ADVICE).
+        from .data_handler import loader as _loader
+        with _loader.paused():
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    body()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss, self.cer = body()
         # restore: warm-up / capture leave no trace
         flat.p.copy_(snap[0]); flat.m.copy_(snap[1]); flat.v.copy_(snap[2]); step_dev.copy_(snap[3])
         flat.refresh_lowp()
@@ -71,6 +77,8 @@ class GraphedStep:
         m.add(loss=self.loss[0])
         if self.model.use_decoder and self.model.use_ctc:
             m.add(ce=self.loss[1], ctc=self.loss[2])
+        if self.cer is not None:
+            m.add(cer=self.cer)
         return m, None
 
 

@@ -281,9 +281,10 @@ def _frame_rows(logits):
 
 
 def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, zero_infinity=False, dlogits=None,
-                want_grad=True, nll=None, grad_scale_div=None):
+                want_grad=True, nll=None, grad_scale_div=None, best_path=None):
     """logits (B,T,V); returns (nll (B,), dlogits or None).  dlogits may alias logits.
-    grad_scale_div: optional 1-element f32 device tensor; the gradient scale is then grad_scale / grad_scale_div[0]."""
+    grad_scale_div: optional 1-element f32 device tensor; the gradient scale is then grad_scale / grad_scale_div[0].
+    best_path: optional (B, T) int32 tensor that receives the frame-wise argmax of the logits (the greedy CTC path; see ctc_collapse)."""
     B, T, V = logits.shape
     ld = _frame_rows(logits)
     _chk_i32(in_len, labels, lab_len)
@@ -296,9 +297,11 @@ def ctc_fwd_bwd(logits, in_len, labels, lab_len, ws, blank=0, grad_scale=1.0, ze
         assert dlogits.shape == logits.shape and dlogits.stride() == logits.stride() and dlogits.dtype == logits.dtype
     w = ws.get(lib.asr_ctc_workspace_bytes(B, T, Lmax))
     _chk_f32(grad_scale_div)
+    _chk_i32(best_path)
+    assert best_path is None or best_path.numel() == B * T
     timed("ctc", 0.0, lambda: check(
         lib.asr_ctc_fwd_bwd(_p(logits), _p(dlogits), _p(in_len), _p(labels), _p(lab_len), _p(nll), B, T, V, ld, Lmax,
-                            int(blank), float(grad_scale), _p(grad_scale_div), int(zero_infinity), _p(w), w.numel(), _dt(logits), _stream()),
+                            int(blank), float(grad_scale), _p(grad_scale_div), int(zero_infinity), _p(best_path), _p(w), w.numel(), _dt(logits), _stream()),
         "asr_ctc_fwd_bwd"), (3.0 if dlogits is not None else 1.0) * logits.numel() * logits.element_size())   # 3 B T V e
 
     return nll, dlogits
@@ -314,6 +317,16 @@ def ctc_greedy_decode(logits, in_len, blank=0):
     check(lib.asr_ctc_greedy_decode(_p(logits), _p(in_len), _p(ids), _p(lens), B, T, V, ld, int(blank), _dt(logits), _stream()),
           "asr_ctc_greedy_decode")
     return ids, lens
+
+
+def ctc_collapse(path, in_len, blank=0):
+    """CTC collapse IN PLACE of a frame-wise best path (B, T) int32 (ctc_fwd_bwd's best_path): repeats merged, blanks dropped, 0-padded.
+    Returns (path, lens (B,) int32)."""
+    B, T = path.shape
+    _chk_i32(path, in_len)
+    lens = torch.empty(B, dtype=torch.int32, device=path.device)
+    check(lib.asr_ctc_collapse(_p(path), _p(in_len), _p(lens), B, T, int(blank), _stream()), "asr_ctc_collapse")
+    return path, lens
 
 
 def decode_attn(q, k, v, H, dk, Tk_cap, kv_div=1, k_len=None, k_len_uniform=0, len_div=1, scale=None, o=None):

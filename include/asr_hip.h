@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 8
+#define ASR_ABI_VERSION 9
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -193,12 +193,16 @@ int asr_sdpa_dropout_mask(uint8_t* mask, int B, int H, int Tq, int Tk, float dro
  * scale = grad_scale, or grad_scale / *grad_scale_div when grad_scale_div (a DEVICE f32 scalar) is not NULL: under data
  * parallelism the CTC term is normalised by the GLOBAL batch, which arrives from an all-reduce on the device - the
  * host never waits for it (ABI 3; the cross-entropy kernel takes its token count the same way).
+ * best_path (ABI 9; may be NULL): (B, T) int32, the frame-wise argmax of the logits (first index on ties, `blank` for frames
+ * t >= in_len[b]) - the greedy CTC path, taken by the kernel that holds the row anyway.  With dlogits aliasing logits the
+ * logits are gone after the call; the training step's per-batch CER (the reference's trainer reads metrics.cer every step,
+ * Trainer/trainer11.py:73-75, computed by transformer_official.py:83-94) collapses this path with asr_ctc_collapse.
  */
 size_t asr_ctc_workspace_bytes(int B, int T, int Lmax);
 int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len,
                     const int32_t* labels, const int32_t* lab_len, float* nll, int B, int T, int V, int ld,
                     int Lmax, int blank, float grad_scale, const float* grad_scale_div, int zero_infinity,
-                    void* ws, size_t ws_bytes, int dtype, void* stream);
+                    int32_t* best_path, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Greedy CTC decoding: per-frame argmax over the vocabulary (first index wins ties, as
@@ -207,9 +211,15 @@ int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t* in_len,
  * transformer_official.py:331-434) - SURVEY.md 8(f) rank 1.
  * logits: (B, T, V) `dtype`, rows `ld` elements apart (ABI 6; V for a dense tensor); out_ids: (B, T) int32 = collapsed label ids,
  * 0-padded; out_len: (B).
+ * ABI 9: the two halves are entry points of their own - asr_ctc_frame_argmax writes the frame-wise best path (B, T), asr_ctc_collapse
+ * collapses a path in place (ids: (B, T) -> collapsed ids, 0-padded; out_len) - so that the training step can collapse the path
+ * asr_ctc_fwd_bwd hands out (best_path) without a second pass over the logits.
  */
 int asr_ctc_greedy_decode(const void* logits, const int32_t* in_len, int32_t* out_ids,
                           int32_t* out_len, int B, int T, int V, int ld, int blank, int dtype, void* stream);
+int asr_ctc_frame_argmax(const void* logits, const int32_t* in_len, int32_t* path, int B, int T, int V, int ld, int blank,
+                         int dtype, void* stream);
+int asr_ctc_collapse(int32_t* ids, const int32_t* in_len, int32_t* out_len, int B, int T, int blank, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Beam search of the attention decoder, batched over utterances x beams

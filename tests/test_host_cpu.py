@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/asr_hip.h but not exported by libasr_hip.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert _lib.lib.asr_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib.asr_abi_version() == _lib.ABI_VERSION == 9
     # argument counts of the binding match the header declarations
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "asr_hip.h")).read(), flags=re.S)
     for n in names:
@@ -488,3 +488,36 @@ def test_library_refuses_runtime_settings_that_hang_the_step():
     env = dict(os.environ, ROC_SYSTEM_SCOPE_SIGNAL="0")
     r = subprocess.run([sys.executable, "-c", "import asr_chinese_e2e_amd._lib"], cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "ROC_SYSTEM_SCOPE_SIGNAL" in r.stderr
+
+
+def test_wave_into_matches_load_wav_for_stereo_and_truncated_files(tmp_path):
+    """The loader decodes PCM straight into its pinned rows (WaveDataset.wave_into): same values as load_wav (scale in float32, then the
+    channel mean) for a stereo file, and a file whose data chunk is shorter than its header says yields the samples it holds instead of a
+    numpy shape error on the helper thread (round-4 ADVICE)."""
+    import wave
+    import numpy as np
+    from asr_chinese_e2e_amd.data_handler.loader import WaveDataset, load_wav
+    rng = np.random.RandomState(0)
+    pcm = (rng.randn(3000, 2) * 8000).astype("<i2")
+    stereo = str(tmp_path / "stereo.wav")
+    with wave.open(stereo, "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes(pcm.tobytes())
+    mono = str(tmp_path / "short.wav")
+    with wave.open(mono, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes(pcm[:, 0].tobytes())
+    raw = open(mono, "rb").read()
+    open(mono, "wb").write(raw[:-2000])      # header still says 3000 frames, the data chunk holds 2000
+    ds = WaveDataset([(stereo, [5]), (mono, [6])])
+    row = np.full(4000, 7.0, dtype=np.float32)
+    n = ds.wave_into(0, row)
+    want, sr = load_wav(stereo)
+    assert n == 3000 == want.size and sr == 16000
+    assert np.array_equal(row[:n], want) and not row[n:].any()
+    assert np.array_equal(ds.wave(0), want)
+    row[:] = 7.0
+    assert ds.num_samples(1) == 3000      # what the header says: the loader sizes the row from it
+    n = ds.wave_into(1, row[:3000])
+    assert n == 2000
+    assert np.array_equal(row[:n], pcm[:2000, 0].astype(np.float32) / np.float32(32768.0)) and not row[n:3000].any()

@@ -7,6 +7,7 @@ rounded values, so the remaining error is the output rounding (2^-9 rel) plus, f
 attention, the bf16 rounding of the probabilities.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -322,6 +323,47 @@ def test_ctc_greedy_decode(K, dtype, B, T, V):
     for b in range(B):
         assert ids[b, : int(n[b])].tolist() == want[b]
         assert int(ids[b, int(n[b]):].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype,B,T,V,ld", [(torch.bfloat16, 3, 40, 4232, 4288), (torch.bfloat16, 4, 130, 64, 64), (torch.bfloat16, 2, 24, 256, 320),
+                                            (torch.bfloat16, 2, 20, 50, 56), (torch.float32, 3, 37, 11, 11), (torch.bfloat16, 2, 30, 1024, 1024)])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_ctc_best_path_from_the_loss_kernels(K, ws, dtype, B, T, V, ld, inplace):
+    """asr_ctc_fwd_bwd's best_path (ABI 9): the frame-wise argmax taken by the kernel that holds the row (first index on ties, blank past
+    in_len), also when the gradient overwrites the logits in place; collapsed by asr_ctc_collapse it is asr_ctc_greedy_decode's result and
+    the oracle's (oracle.ref_model.ctc_greedy_decode).  Loss and gradient are the same bits with and without the extra output."""
+    from oracle import ref_model as R
+    lt, in_len, labels, lab_len = ctc_case(41, B, T, V, 6, True, dtype)
+    lt[0, 2, :] = 0.0                      # all-equal frame: index 0 (blank) wins
+    lt[1, 3, 1] = lt[1, 3, V - 1] = 30.0   # two-way tie at the two ends of the row: id 1 wins
+    lt[B - 1, 5, V - 1] = 31.0             # the row's last element
+    in_len[0] = T
+    dev = lambda a: torch.from_numpy(a).int().to(DEV)
+    buf = torch.full((B * T, ld), 40.0, dtype=dtype, device=DEV)      # the padding columns hold a LARGER value: they must not be looked at
+    frames = buf.view(B, T, ld)[:, :, :V]
+    frames.copy_(lt.to(DEV))
+    ids0, n0 = K.ctc_greedy_decode(frames, dev(in_len))
+    nll0, dl0 = K.ctc_fwd_bwd(frames.clone(), dev(in_len), dev(labels), dev(lab_len), ws, grad_scale=0.5)
+    path = torch.full((B, T), -7, dtype=torch.int32, device=DEV)
+    nll1, dl1 = K.ctc_fwd_bwd(frames, dev(in_len), dev(labels), dev(lab_len), ws, grad_scale=0.5, dlogits=frames if inplace else None, best_path=path)
+    assert torch.equal(nll0, nll1) and torch.equal(dl0.contiguous(), dl1.contiguous())
+    want = lt.float().argmax(-1)
+    for b in range(B):
+        assert path[b, : in_len[b]].cpu().tolist() == want[b, : in_len[b]].tolist(), b
+        assert int(path[b, in_len[b]:].abs().sum()) == 0
+    ids1, n1 = K.ctc_collapse(path, dev(in_len))
+    assert ids1.data_ptr() == path.data_ptr()
+    assert torch.equal(ids0, ids1) and torch.equal(n0, n1)
+    hyp = R.ctc_greedy_decode(lt.float().numpy(), in_len)
+    for b in range(B):
+        assert ids1[b, : int(n1[b])].cpu().tolist() == hyp[b]
+    # forward only (no gradient): the path is available too
+    path2 = torch.empty(B, T, dtype=torch.int32, device=DEV)
+    buf2 = torch.zeros(B * T, ld, dtype=dtype, device=DEV)
+    fr2 = buf2.view(B, T, ld)[:, :, :V]
+    fr2.copy_(lt.to(DEV))
+    K.ctc_fwd_bwd(fr2, dev(in_len), dev(labels), dev(lab_len), ws, want_grad=False, best_path=path2)
+    assert torch.equal(K.ctc_collapse(path2, dev(in_len))[0], ids0)
 
 
 @pytest.mark.parametrize("dtype,B,T,V,ld", [(torch.bfloat16, 3, 40, 4232, 4288), (torch.bfloat16, 2, 24, 256, 320), (torch.float32, 2, 20, 12, 16),
@@ -849,6 +891,20 @@ def test_gemm_tn_grouped_rejects_bad_arguments(K):
 
 
 # ------------------------------------------------------------------------------------ CER on the device
+def test_cer_kernel_against_reference_golden(K):
+    """asr_cer against the REFERENCE's own values, no host function in between: tests/golden/ops.npz cer/* are outputs of the reference's
+    calculate_cer(convert_id2str(hyp), convert_id2str(ref)) (Utils/score.py:4-13 over vocab.py:75-79, written by oracle/gen_golden.py with
+    the 12-token synthetic vocabulary)."""
+    from asr_chinese_e2e_amd.data_handler import Vocab
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops.npz"))
+    v = Vocab.synthetic(12)
+    table = K.token_table(v._id2token, DEV)
+    hyp = torch.from_numpy(z["cer/hyp"]).int().to(DEV)
+    ref = torch.from_numpy(z["cer/ref"]).int().to(DEV)
+    got = K.cer(hyp, ref, table, v._token2id[v.PAD]).cpu().numpy()
+    assert np.allclose(got, z["cer/vals"], rtol=1e-6, atol=0), (got, z["cer/vals"])
+
+
 def test_cer_matches_host_convention(K):
     """asr_cer == calculate_cer(convert_id2str(hyp), convert_id2str(ref)) (score.py:4-13 over vocab.py:75-79
     strings): pads dropped anywhere in the row, multi-character tokens, empty strings, rows longer than one

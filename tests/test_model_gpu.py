@@ -1011,6 +1011,40 @@ def test_step_cer_beside_backward_matches_inline(monkeypatch):
     assert all(abs(a - b) <= 5.0 for a, b in zip(res["1"], res["0"])), res
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_ctc_only_training_step_returns_cer(monkeypatch, overlap):
+    """The reference's trainer reads metrics.cer.item() after EVERY training step (Trainer/trainer11.py:73-75; produced by cal_metrics,
+    transformer_official.py:83-94).  The CTC-only model (BASELINE configs[1]) scores the greedy CTC path of the step - handed out by the loss
+    kernels, collapsed and scored on the auxiliary stream beside the backward pass - and the value equals what the evaluation path
+    (forward -> cal_metrics: asr_ctc_greedy_decode on the logits) gives for the same weights, step after step."""
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+    monkeypatch.setenv("ASR_WGRAD_OVERLAP", overlap)
+    over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2, use_decoder=False, ctc_weight=1.0, dropout=0.0)
+    cfg, sd, batch = oracle_case(6, 120, 80, 56, 9, over, seed=33)
+    pack = to_pack(batch)
+    model = build(cfg, 56, "TransformerCTC", dtype="bf16").cuda()
+    model.load_state_dict(sd)
+    opt = NoamOpt(512, 1, 25, FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+    seen = []
+    for _ in range(4):
+        model.eval()
+        want, _ = model.iterate(pack, is_train=False)
+        model.train()
+        metrics, _ = model.iterate(pack, optimizer=opt, is_train=True)
+        cer, loss = metrics.cer.item(), metrics.loss.item()      # exactly the trainer's two reads
+        assert metrics.cer.detach().cpu().numpy().shape == (1,)      # trainer11.py:112
+        assert cer == want.cer.item(), (cer, want.cer.item())
+        assert abs(loss - want.loss.item()) <= 2e-3 * abs(loss)
+        seen.append(cer)
+    eng = model._ensure_engine(DEV)
+    assert (getattr(model, "_cer_event", None) is not None) == (overlap == "1" and eng.aux_overlap)
+    assert all(0.0 <= c < float("inf") for c in seen), seen      # an untrained model's greedy path is many times longer than the labels: CER >> 100 %
+    # cer_in_iterate = False: the step carries no CER work and the key is absent (Pack gives None)
+    model.cer_in_iterate = False
+    metrics, _ = model.iterate(pack, optimizer=opt, is_train=True)
+    assert metrics.cer is None
+
+
 @pytest.mark.parametrize("name", ["TransformerCTC", "TransformerOffical"])
 def test_padded_head_rows_match_dense_rows(name, monkeypatch):
     """The training step keeps the CTC head's logits / gradient rows 64-element aligned (V = 56 -> 64, like 4232 -> 4288 at full size;

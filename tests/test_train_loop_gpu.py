@@ -322,6 +322,48 @@ def test_bucketed_wave_loader_feeds_the_model(tmp_path):
     assert len(losses) == 6 and all(np.isfinite(losses))
 
 
+def test_graphed_model_fed_by_the_loader_thread():
+    """graph.GraphedModel captures a hipGraph whenever a new batch shape arrives - while the loader's helper thread prepares the next batches
+    (pinned allocations, caching-allocator growth, event synchronisation: calls that invalidate a capture on another thread under the
+    default capture mode).  GraphedStep holds loader.paused() for its warm-up and capture; here a loader with several batch shapes feeds a
+    graphed model for two epochs, the losses follow the eager model fed by an identical loader, and the step's CER comes out of the graph."""
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import AudioParser, BucketedWaveLoader, Vocab, WaveDataset
+    from asr_chinese_e2e_amd.graph import GraphedModel
+    from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+    rng = np.random.RandomState(7)
+    vocab = Vocab.synthetic(30)
+    lens = [8000] * 8 + [12000] * 8 + [16000] * 8      # three feature lengths -> at least three captured shapes
+    items = [((rng.randn(n) * 0.1).astype(np.float32), [int(t) for t in rng.randint(4, 30, size=4)]) for n in lens]
+    ds = WaveDataset(items, vocab)
+    parser = AudioParser(n_mels=40, lfr_m=4, lfr_n=3, device="cuda")
+
+    def run(graphed):
+        torch.manual_seed(0)
+        M = Models.TransformerCTC
+        cfg = M.get_default_config()()
+        cfg.fn_build(dict(n_mels=40, lfr_m=4, d_model=64, hidden_size=16, num_head=4, ff_size=128, layer_num=2, dropout=0.0, ctc_weight=1.0, dtype="fp32"))
+        model = M(cfg, vocab).cuda()
+        opt = NoamOpt(64, 1, 10, FusedAdam(model.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+        runner = GraphedModel(model) if graphed else model
+        loader = BucketedWaveLoader(ds, 4, parser=parser, augment=False, shuffle=True, seed=3, bucket_size=8, dtype=torch.float32)
+        out = []
+        for _ in range(2):
+            for pack in loader:
+                m, _ = runner.iterate(pack, optimizer=opt, is_train=True)
+                out.append((float(m.loss), float(m.cer)))
+        return out, (len(runner.graphs) if graphed else 0)
+
+    eager, _ = run(False)
+    graphed, ngraphs = run(True)
+    assert ngraphs >= 3 and len(eager) == len(graphed) == 12
+    for (le, ce), (lg, cg) in zip(eager, graphed):
+        assert abs(le - lg) <= 2e-3 * abs(le), (eager, graphed)      # atomics of the weight-gradient splits: not bit-identical
+        assert abs(ce - cg) <= 25.0 + 0.1 * ce and 0.0 <= cg < float("inf")      # near-ties of the greedy path may differ after an update
+    import threading
+    assert not [t for t in threading.enumerate() if t.name == "asr-loader" and t.is_alive()]
+
+
 def test_overfit_small_batch_then_decode_exactly():
     """End to end: a small joint model memorises four utterances (loss falls by > 10x), after which
     greedy CTC decoding and attention beam search both return the training transcripts."""
