@@ -635,28 +635,17 @@ __device__ __forceinline__ bf16x8 tn_frag_swz(unsigned addr) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// TRING ring slots of 64 rows; four waves (2 x 2 over the 128 x 128 tile).  (An 8-wave form with an intra-workgroup split of the
-// reduction - two wave groups per ring slot - is in the git history: faster alone, slower beside the main stream.)
+// The body of one workgroup: tile (n0, k0) of dW over reduction rows [mbeg, mend) - shared by the single-problem kernel and the
+// multi-problem kernel below (same code, same bits).
 template <int TRING>
-__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
-                                                             int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
-                                                             int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias, size_t split_stride,
-                                                             int bias_split_stride, int skew = 0) {
-    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+__device__ __forceinline__ void tn_dma_tile(char* smem_t, const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int N, int K, int ldy,
+                                            int ldx, int ldw, int n0, int k0, int tk, int mbeg, int mend, int use_atomic, const void* __restrict__ zero_page,
+                                            float* __restrict__ dbias, int split, int bias_split_stride) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntiles = tiles_k * tiles_n;
-    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
-    const int split = vid / ntiles, tile = vid - split * ntiles;
-    const int tk = tile % tiles_k, tn = tile / tiles_k;
-    const int n0 = tn * 128, k0 = tk * 128;
-    // skew > 0 (the default; tuning option "tn_cfg" = 3 switches it off): split s reduces rows_per_split + skew * s rows, so the splits - which all add their tile
-    // to memory with fp32 atomics when they finish - finish one after the other instead of together
-    const int mbeg = split * rows_per_split + skew * (split * (split - 1) / 2), mend = min(M, mbeg + rows_per_split + skew * split);
     constexpr int SR = TM;                     // rows per ring slot
     constexpr int SBYTES = TSTAGE;             // bytes per ring slot: [dY 64 x 256 B | X 64 x 256 B]
     const int nsteps = (mend - mbeg + SR - 1) / SR;
     if (nsteps <= 0) return;
-    dW += (size_t)split * split_stride;     // deterministic mode: every split owns a slab (summed by tn_slab_reduce_kernel)
     const int wn = w >> 1, wk = w & 1;
 
     // this lane's part of each of the wave's 8 one-KiB pieces: the first half of the waves stages dY
@@ -821,6 +810,58 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
             else atomicAdd(dbias + n0 + tid, t);
         }
     }
+}
+
+// TRING ring slots of 64 rows; four waves (2 x 2 over the 128 x 128 tile).  (An 8-wave form with an intra-workgroup split of the
+// reduction - two wave groups per ring slot - is in the git history: faster alone, slower beside the main stream.)
+template <int TRING>
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW, int M, int N,
+                                                             int K, int ldy, int ldx, int ldw, int tiles_k, int tiles_n, int rows_per_split,
+                                                             int use_atomic, const void* __restrict__ zero_page, float* __restrict__ dbias, size_t split_stride,
+                                                             int bias_split_stride, int skew = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    const int ntiles = tiles_k * tiles_n;
+    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    const int split = vid / ntiles, tile = vid - split * ntiles;
+    const int tk = tile % tiles_k, tn = tile / tiles_k;
+    // skew > 0 (the default): split s reduces rows_per_split + skew * s rows, so the splits - which all add their tile
+    // to memory with fp32 atomics when they finish - finish one after the other instead of together
+    const int mbeg = split * rows_per_split + skew * (split * (split - 1) / 2), mend = min(M, mbeg + rows_per_split + skew * split);
+    // deterministic mode: every split owns a slab (summed by tn_slab_reduce_kernel)
+    tn_dma_tile<TRING>(smem_t, dY, X, dW + (size_t)split * split_stride, N, K, ldy, ldx, ldw, tn * 128, tk * 128, tk, mbeg, mend, use_atomic, zero_page, dbias, split,
+                       bias_split_stride);
+}
+
+// Several weight gradients over the SAME M rows in ONE launch of the kernel above (round 5): the two projections of a feed-forward block
+// (w_2, w_1) or of an attention block (out-projection, Q|K|V) have 64 tiles of 128 x 128 between them, so one round of one workgroup per
+// CU needs 4 M-splits instead of 8 / 8 or 16 / 5 - and every workgroup ends by adding its 64-KiB fp32 tile to memory with atomics, which
+// costs a launch ~12 us whatever the projection (256 workgroups x 64 KiB at the chip's ~1.3 TB/s atomic rate).  Two launches of 16 MB of
+// atomics, two kernel boundaries and two ring prologues become one.  Same tile code, staggered splits as above.
+constexpr int TNM_MAX = 4;
+struct TnMultiProb {
+    const bf16_t* dY;
+    const bf16_t* X;
+    float* dW;
+    float* dbias;
+    int N, K, ldy, ldx, ldw;
+    int tiles_k, tiles, block_begin;      // 128 x 128 tiles; first workgroup (virtual id) of the problem
+};
+struct TnMulti {
+    TnMultiProb p[TNM_MAX];
+    int nprob, M, nsplit, r0, skew;
+};
+template <int TRING>
+__global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const TnMulti grp, const void* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    const int vid = xcd_virtual_id(blockIdx.x, gridDim.x);
+    int pi = 0;
+    for (int i = 1; i < grp.nprob; ++i) pi = vid >= grp.p[i].block_begin ? i : pi;
+    const TnMultiProb& pr = grp.p[pi];
+    const int local = vid - pr.block_begin;
+    const int split = local / pr.tiles, tile = local - split * pr.tiles;
+    const int tk = tile % pr.tiles_k, tn = tile / pr.tiles_k;
+    const int mbeg = split * grp.r0 + grp.skew * (split * (split - 1) / 2), mend = min(grp.M, mbeg + grp.r0 + grp.skew * split);
+    tn_dma_tile<TRING>(smem_t, pr.dY, pr.X, pr.dW, pr.N, pr.K, pr.ldy, pr.ldx, pr.ldw, tn * 128, tk * 128, tk, mbeg, mend, 1, zero_page, pr.dbias, split, 0);
 }
 
 template <int S>
@@ -1230,6 +1271,69 @@ extern "C" int asr_gemm_small_bf16(const void* A, const void* Bm, const float* b
     return ASR_OK;
 }
 
+namespace {
+// Staggered M-splits: lengths r0 + skew * s, s = 0 .. nsplit - 1, from ~0.75 to ~1.25 of the mean, all multiples of the 64-row stage,
+// covering M.  Every split ends by adding its 128 x 128 tile to memory with fp32 atomics (256 workgroups x 64 KiB = 16 MB per launch at
+// the chip's 1.3 TB/s atomic rate): splits that finish one after the other put that traffic under the others' compute (step 3.326 ->
+// 3.314 ms; a spread of 30 / 80 / 120 % of the mean: 3.328 / 3.376 / 3.459 against 3.305 at 50 %).
+static void tn_stagger(int M, int rows_per_split, int nsplit, int* r0, int* skew) {
+    *r0 = rows_per_split;
+    *skew = 0;
+    if (nsplit >= 3) {
+        int sk = (int)((long long)rows_per_split * 50 / 100 / (nsplit - 1)) / TM * TM;
+        const int tri = nsplit * (nsplit - 1) / 2;
+        int r = ceil_div(ceil_div(M - sk * tri > 0 ? M - sk * tri : M, nsplit), TM) * TM;
+        if (sk <= 0 || r < 4 * TM || r * (nsplit - 1) + sk * ((nsplit - 1) * (nsplit - 2) / 2) >= M) return;      // the last split must start inside the range
+        *r0 = r;
+        *skew = sk;
+    }
+}
+
+// Problems over the same >= 4096 rows whose 128 x 128 tiles fill the chip with a few M-splits: ONE launch of the single-problem kernel's tile
+// code (gemm_tn_multi_kernel).  Returns false when the group does not qualify (the caller then takes the 256 x 128-tile grouped kernel).
+static bool tn_multi_launch(const asr_tn_problem* probs, int nprob, int accumulate, hipStream_t st, void* zero_page) {
+    if (!asr_option(ASR_OPT_TN_MULTI) || nprob > TNM_MAX || probs[0].M < 4096) return false;
+    TnMulti g;
+    memset(&g, 0, sizeof(g));
+    int tiles = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const asr_tn_problem& q = probs[i];
+        if (q.M != probs[0].M) return false;
+        TnMultiProb& t = g.p[i];
+        t.dY = (const bf16_t*)q.dY; t.X = (const bf16_t*)q.X; t.dW = q.dW; t.dbias = q.dbias;
+        t.N = q.N; t.K = q.K; t.ldy = q.ldy; t.ldx = q.ldx; t.ldw = q.ldw;
+        t.tiles_k = ceil_div(q.K, 128);
+        t.tiles = ceil_div(q.N, 128) * t.tiles_k;
+        tiles += t.tiles;
+    }
+    const int cus = cu_count(), M = probs[0].M;
+    int splits = cus / tiles;
+    const int max_s = ceil_div(M, 4 * TM);   // at least 4 reduction stages per workgroup
+    if (splits > max_s) splits = max_s;
+    if (splits < 1) splits = 1;
+    if (tiles * splits * 5 < cus * 4 && splits < max_s) return false;      // would leave > 20 % of the CUs without a workgroup
+    const int rows_per_split = ceil_div(ceil_div(M, splits), TM) * TM;
+    g.nsplit = ceil_div(M, rows_per_split);
+    g.nprob = nprob;
+    g.M = M;
+    tn_stagger(M, rows_per_split, g.nsplit, &g.r0, &g.skew);
+    int begin = 0;
+    for (int i = 0; i < nprob; ++i) {
+        g.p[i].block_begin = begin;
+        begin += g.p[i].tiles * g.nsplit;
+        if (!accumulate) {      // the tile code adds with atomics
+            const size_t total = (size_t)g.p[i].N * g.p[i].K;
+            const int zg = (int)((total + 255) / 256);
+            zero_f32_kernel<<<zg < 1024 ? zg : 1024, 256, 0, st>>>(g.p[i].dW, g.p[i].N, g.p[i].K, g.p[i].ldw);
+        }
+    }
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_multi_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TSTAGE); attr = true; }
+    gemm_tn_multi_kernel<3><<<begin, 256, 3 * TSTAGE, st>>>(g, zero_page);
+    return true;
+}
+}  // namespace
+
 extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, int accumulate, void* stream) {
     if (!probs || nprob <= 0 || nprob > TG_MAX) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: 1..%d problems per call (got %d)", TG_MAX, nprob);
     if (asr_deterministic()) ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: the grouped kernel combines splits with fp32 atomics - in deterministic mode call asr_gemm_tn_bias_bf16 per problem");
@@ -1253,6 +1357,13 @@ extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, 
         t.tiles = ceil_div(q.N, 256) * t.tiles_k;
         work += (long long)t.tiles * q.M;
         if (q.M > max_m) max_m = q.M;
+    }
+    static void* zero_page = nullptr;
+    if (!zero_page && (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page))
+        ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: zero page symbol not found");
+    if (tn_multi_launch(probs, nprob, accumulate, st, zero_page)) {
+        ASR_CHECK_LAUNCH("asr_gemm_tn_grouped_bf16");
+        return ASR_OK;
     }
     // rows per workgroup R (one value for the whole group = balanced work): the smallest multiple of 64
     // with sum_p tiles_p * ceil(M_p / R) <= #CUs, i.e. one round of one workgroup per CU; >= 4 stages each
@@ -1280,9 +1391,6 @@ extern "C" int asr_gemm_tn_grouped_bf16(const asr_tn_problem* probs, int nprob, 
             zero_f32_kernel<<<zg < 1024 ? zg : 1024, 256, 0, st>>>(t.dW, t.N, t.K, t.ldw);
         }
     }
-    static void* zero_page = nullptr;
-    if (!zero_page && (hipGetSymbolAddress(&zero_page, HIP_SYMBOL(tn_zero_page)) != hipSuccess || !zero_page))
-        ASR_FAIL(ASR_EINVAL, "asr_gemm_tn_grouped_bf16: zero page symbol not found");
     // stage rows x ring: 64 x 3 = 144 KiB is the fastest alone (0.67 PFLOP/s on a config-2 layer), but this GEMM runs
     // beside the main stream, whose attention / LayerNorm workgroups need the rest of the CU's LDS
     static const int dbg = unsafe_debug_env("ASR_GEMM_TNG_DBG");
@@ -1372,17 +1480,8 @@ extern "C" int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, f
         zero_f32_kernel<<<g < 1024 ? g : 1024, 256, 0, st>>>(dW, N, K, ldw);
     }
     const int grid = tiles * nsplit;
-    // Staggered M-splits: lengths r0 + skew * s, s = 0 .. nsplit - 1, from ~0.75 to ~1.25 of the mean, all multiples of the 64-row stage,
-    // covering M.  Every split ends by adding its 128 x 128 tile to memory with fp32 atomics (256 workgroups x 64 KiB = 16 MB per launch at
-    // the chip's 1.3 TB/s atomic rate): splits that finish one after the other put that traffic under the others' compute (step 3.326 ->
-    // 3.314 ms; a spread of 30 / 80 / 120 % of the mean: 3.328 / 3.376 / 3.459 against 3.305 at 50 %).
-    int sk_r0 = rows_per_split, sk_skew = 0;
-    if (nsplit >= 3) {
-        sk_skew = (int)((long long)rows_per_split * 50 / 100 / (nsplit - 1)) / TM * TM;
-        const int tri = nsplit * (nsplit - 1) / 2;
-        sk_r0 = ceil_div(ceil_div(M - sk_skew * tri > 0 ? M - sk_skew * tri : M, nsplit), TM) * TM;
-        if (sk_skew <= 0 || sk_r0 < 4 * TM || sk_r0 * (nsplit - 1) + sk_skew * ((nsplit - 1) * (nsplit - 2) / 2) >= M) { sk_r0 = rows_per_split; sk_skew = 0; }      // the last split must start inside the range
-    }
+    int sk_r0, sk_skew;      // staggered M-splits (tn_stagger)
+    tn_stagger(M, rows_per_split, nsplit, &sk_r0, &sk_skew);
     static void* zero_page = nullptr;
     if (!zero_page) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);

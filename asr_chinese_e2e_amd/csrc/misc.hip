@@ -36,8 +36,10 @@ extern "C" int asr_set_deterministic(int on) {
 
 // ---- tuning options: process-wide integer switches under which every value gives correct results (asr_set_option).  ABI 8 keeps one,
 // "cu_limit" (gemm.hip: cu_count); the kernel-variant switches of rounds 2 - 3 left with the variants.
-static const char* const g_opt_names[ASR_OPT_COUNT] = {"cu_limit"};
-static int g_opt_val[ASR_OPT_COUNT] = {0};
+// "tn_multi" (round 5; default 1): asr_gemm_tn_grouped_bf16 runs problems over the same >= 4096 rows on the 128 x 128-tile kernel (one launch,
+// fewer M-splits); 0 = the 256 x 128-tile grouped kernel for every group (A/B timing inside one process).
+static const char* const g_opt_names[ASR_OPT_COUNT] = {"cu_limit", "tn_multi"};
+static int g_opt_val[ASR_OPT_COUNT] = {0, 1};
 static void opt_init() {}
 int asr_option(int key) {
     opt_init();

@@ -365,7 +365,7 @@ def shared_stream(device, kind):
     if key not in _STREAMS:
         with torch.cuda.device(dev):
             avoid = [torch.cuda.current_stream()] + [s for (i, _), s in _STREAMS.items() if i == dev.index]
-            _STREAMS[key] = pick_stream(dev, avoid, factory=(lambda: _side_stream(dev)) if kind == "wgrad" else None)
+            _STREAMS[key] = pick_stream(dev, avoid, factory=(lambda: _side_stream(dev)) if kind.startswith("wgrad") else None)
     return _STREAMS[key]
 
 
@@ -497,8 +497,19 @@ class Engine:
         # per layer / per attention or feed-forward block.  The grouped kernel is 1.6x faster alone (98 vs 160 us
         # per config-2 layer) but one 100-us launch filling every CU overlaps worse with the main stream than
         # four short ones spread over the layer: step 3.84 (layer) / 3.96 (block) vs 3.79 ms, joint 6.27 vs 6.16.
+        # "pair" (round 5; measured SLOWER in the step, see below) = "decoder" + the ENCODER's weight gradients as one launch per block: (w_2, w_1) behind the w_2 input
+        # gradient, (out-projection, Q|K|V) behind the attention backward.  Not the 256 x 128-tile grouped kernel that "block" measured
+        # slower with (its tiles double the bytes every workgroup adds to memory with atomics): the 128 x 128-tile code of the single
+        # launches on 64 tiles x 4 M-splits (asr_gemm_tn_grouped_bf16 picks it for problems over the same >= 4096 rows) - two launches'
+        # 2 x 16 MB of atomics, kernel boundaries and ring prologues become one launch's.  Stand-alone a layer's four gradients take 119 us as two
+        # pairs against 143 us as four launches (132 with the 256 x 128-tile kernel) - and the step is SLOWER: CTC 3.182 vs 3.143 ms, joint 4.912
+        # vs 4.894; only the feed-forward pair 3.212 vs 3.136; only the attention pair 3.144 vs 3.133 (A/B in one process, profiles/round5_a_*):
+        # the pair starts when the block's SECOND dY exists and then holds every CU for 60 us, the single launches start earlier and their short
+        # workgroups give the CUs back to the main stream's kernels sooner.  Opt-in.
         self.group_wgrad = os.environ.get("ASR_WGRAD_GROUP", "decoder")
         self.group_wgrad = None if (self.group_wgrad == "0" or self.deterministic) else self.group_wgrad
+        # "pair_ffn" / "pair_attn": only the feed-forward / only the attention block's pair (the other block keeps one launch per projection)
+        self._pair_tags = {"pair": ("w2", "w1", "fc", "qkv"), "pair_ffn": ("w2", "w1"), "pair_attn": ("fc", "qkv")}.get(self.group_wgrad, ())
         # The decoder of the joint model is a chain of ~25 small kernels per layer and direction on B*To ~ 550 rows whose workgroups need whole
         # CUs (the small-M GEMM holds 132 - 141 KiB of LDS, attention K / V images 128 KiB); the large launches that run BESIDE the chain on the
         # auxiliary / weight-gradient streams (CTC branch, cross-attention K|V projections and their input gradients, the layer's grouped
@@ -699,7 +710,8 @@ class Engine:
 
     def _wgrad(self, lin, dy, x, bias_from=None):
         """lin.gw += dy^T x (and lin.gb += colsum(bias_from)) on the side stream."""
-        if self.defer_wgrad and self.overlap_wgrad and not self._in_decoder and lin.tag in self.defer_wgrad:
+        pair = self._pair_tags and not self._in_decoder and lin.tag in self._pair_tags
+        if self.defer_wgrad and self.overlap_wgrad and not self._in_decoder and lin.tag in self.defer_wgrad and not pair:
             # ASR_WGRAD_DEFER (default "fc"): hold this projection's weight gradient until the layer's attention backward is
             # about to be launched.  For the out-projection that takes it from beside its own (short) dgrad GEMM to beside the
             # 83-us attention kernel: step 3.53 -> 3.50 ms.  Holding back any other projection (w1, w2, qkv) or releasing after
@@ -708,10 +720,15 @@ class Engine:
             self._disarm()      # no fork here: the arm must not outlive its producer (a later _fork would skip its event)
             return
         fused = bias_from is dy and lin.fused_bias_wgrad(dy, x)     # bias gradient inside the weight-gradient GEMM
-        if self.group_wgrad and (self.group_wgrad != "decoder" or self._in_decoder) and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
+        grouped_here = self.group_wgrad and (self._in_decoder or pair or self.group_wgrad in ("layer", "block"))      # ("decoder", "pair*": the decoder's layers)
+        if grouped_here and (bias_from is None or fused) and dy.dtype == torch.bfloat16 and lin.N % 8 == 0 and lin.K % 8 == 0 \
                 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
             self._pending.append((dy, x, lin.gw, lin.gb if fused else None))     # launched by flush_wgrads (end of the layer)
-            if not self._arm_covers_pending:      # only the decoder sequencer's arm (its layer's LAST kernel) orders everything collected here
+            if pair and lin.tag in ("w1", "qkv"):
+                # the block's second weight gradient: its dY was written by the kernel launched last (the w_2 input gradient, the attention
+                # backward) - that kernel's arm, if it took one, is this launch's hand-over
+                self.flush_wgrads()
+            elif not self._arm_covers_pending:      # only the decoder sequencer's arm (its layer's LAST kernel) orders everything collected here
                 self._disarm()
             return
         if not self.overlap_wgrad:
@@ -769,7 +786,7 @@ class Engine:
         H, dk, hd = self.H, self.dk, self.H * self.dk
         B, Tq, Tk = c["dims"]
         pa, sa, pf, sf = c["drop"]
-        fc_deferred = bool(self.defer_wgrad) and self.overlap_wgrad and not self._in_decoder and m.fc.tag in self.defer_wgrad
+        fc_deferred = bool(self.defer_wgrad) and self.overlap_wgrad and not self._in_decoder and m.fc.tag in self.defer_wgrad and "fc" not in self._pair_tags
         if not fc_deferred:
             self._arm()
         dz, dxg = self._ln_bwd(m.ln, m.fc.gb, dy, dy2, c["xhat"], c["rstd"], c["q_lens"], B, Tq, drop_p=pf, drop_seed=sf, drop_mode=1)

@@ -588,6 +588,13 @@ def set_cu_limit(n):
     check(lib.asr_set_option(ctypes.addressof(_CU_LIMIT_NAME), int(n), None), "asr_set_option")
 
 
+def set_option(name, value):
+    """asr_set_option (include/asr_hip.h): process-wide tuning switches under which every value gives correct results; returns the previous value."""
+    prev = ctypes.c_int(0)
+    check(_lib.lib.asr_set_option(name.encode(), int(value), ctypes.byref(prev)), "asr_set_option")
+    return prev.value
+
+
 def deterministic():
     """True when the library's reductions run in a fixed order (asr_set_deterministic / ASR_DETERMINISTIC=1)."""
     return bool(lib.asr_get_deterministic())

@@ -82,6 +82,8 @@ int asr_stream_create(int priority, void** out_stream);
  * many CUs instead of the device's; the engine sets it around the large launches that run beside the decoder's chain of small kernels;
  * 0 = the whole device).  (Rounds 2 - 3 carried switches between kernel variants here - store policy, tile shape, split plans; the variants
  * that lost their A/B left the library, see DESIGN.md section 4 "Tried".)  Initial value 0.
+ * "tn_multi" (round 5; initial value 1): asr_gemm_tn_grouped_bf16 runs a group of problems over the same >= 4096 rows on the 128 x 128-tile
+ * code of the single-problem kernel in one launch; 0 = always the 256 x 128-tile grouped kernel (A/B timing).
  * previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
 int asr_set_option(const char* name, int value, int* previous);
 int asr_get_deterministic(void);
@@ -422,7 +424,11 @@ int asr_gemm_tn_bias_bf16(const void* dY, const void* X, float* dW, float* dbias
  * autograd weight-gradient GEMMs the reference runs one by one (torch.autograd through
  * attention.py:43-59, module.py:70-71).  Together the problems fill the GPU with larger tiles and
  * fewer splits of the M = B*T reduction than each would alone.  `probs` is a HOST array, read
- * during the call.  Per problem: dY (M, N) ldy, X (M, K) ldx bf16; dW (N, K) ldw f32. */
+ * during the call.  Per problem: dY (M, N) ldy, X (M, K) ldx bf16; dW (N, K) ldw f32.
+ * Round 5: up to four problems over the SAME M >= 4096 rows whose 128 x 128 tiles fill the device with a few M-splits (the two projections
+ * of a feed-forward or attention block: 64 tiles x 4 splits) run on the tile code of asr_gemm_tn_bias_bf16 in one launch - every workgroup
+ * of either form ends by adding its fp32 tile to memory with atomics, so one launch for two problems halves that traffic; other groups
+ * (different M per problem: a decoder layer's) take the 256 x 128-tile kernel as before. */
 typedef struct asr_tn_problem {
     const void* dY;
     const void* X;

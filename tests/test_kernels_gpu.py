@@ -856,6 +856,9 @@ def _tn_problem(M, N, K_, with_bias, seed, strided=False):
 
 @pytest.mark.parametrize("shapes", [
     [(16000, 1536, 512, True), (16000, 512, 512, False), (16000, 1024, 512, True), (16000, 512, 1024, False)],   # one encoder layer of config 2
+    [(16000, 512, 1024, False), (16000, 1024, 512, True)],                                                       # a feed-forward block's pair (w_2, w_1): 64 tiles of 128 x 128 x 4 splits
+    [(16000, 512, 512, False), (16000, 1536, 512, True)],                                                        # an attention block's pair (out-projection, Q|K|V)
+    [(4100, 264, 136, True), (4100, 520, 72, False)],                                                            # same rows, ragged: last stage partial, clamped edge columns
     [(16000, 4232, 512, True)],                                                                                # one problem: the CTC output layer
     [(1000, 1536, 512, True), (16000, 1024, 512, True), (1000, 512, 512, False), (1037, 1024, 512, True), (1037, 512, 1024, False)],  # decoder-like: different M per problem
     [(70, 40, 24, True), (513, 264, 136, True), (8197, 512, 80, False), (300, 128, 128, True), (64, 8, 8, True),
@@ -880,6 +883,35 @@ def test_gemm_tn_grouped(K, shapes):
     K.gemm_tn_grouped([(dy, x, dw, None) for dy, x, dw, db in probs], accumulate=False)
     for (M, N, K_, wb), (dy, x, dw, db) in zip(shapes, probs):
         close(dw, dy.float().t() @ x.float(), rtol=2e-3, atol=2e-3 * math.sqrt(M), what=f"grouped gemm_tn overwrite {M}x{N}x{K_}")
+
+
+def test_gemm_tn_grouped_same_rows_takes_the_single_launch_tile_code(K):
+    """Problems over the same >= 4096 rows run on the 128 x 128-tile code of the single launches (gemm_tn_multi_kernel; option "tn_multi" = 0 keeps
+    the 256 x 128-tile grouped kernel): both give the fp32 product, and the single launches per problem give the same values."""
+    if K.deterministic():
+        pytest.skip("grouped launches are refused in deterministic mode")
+    shapes = [(16000, 512, 1024, False), (16000, 1024, 512, True)]
+    outs = {}
+    for mode in (1, 0, "single"):
+        probs = [_tn_problem(M, N, K_, wb, 7 * i + 3) for i, (M, N, K_, wb) in enumerate(shapes)]
+        if mode == "single":
+            for dy, x, dw, db in probs:
+                K.gemm_tn(dy, x, dw, accumulate=True, dbias=db)
+        else:
+            prev = K.set_option("tn_multi", mode)
+            try:
+                K.gemm_tn_grouped(probs, accumulate=True)
+            finally:
+                K.set_option("tn_multi", prev)
+        outs[mode] = probs
+    for i, (M, N, K_, wb) in enumerate(shapes):
+        dy, x = outs[1][i][0], outs[1][i][1]
+        ref = dy.float().t() @ x.float()
+        for mode in outs:
+            close(outs[mode][i][2] - 1, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M), what=f"tn_multi={mode} {M}x{N}x{K_}")
+            if wb:
+                close(outs[mode][i][3] - 2, dy.float().sum(0), rtol=1e-4, atol=1e-3 * math.sqrt(M), what=f"tn_multi={mode} bias gradient")
+        close(outs[1][i][2], outs["single"][i][2], rtol=1e-5, atol=1e-3, what="multi vs single launches")      # same tile code, other split boundaries: fp32 summation order only
 
 
 def test_gemm_tn_grouped_rejects_bad_arguments(K):
