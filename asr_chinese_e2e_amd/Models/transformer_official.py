@@ -77,9 +77,12 @@ class _SpeechTransformer(BaseModel):
             blocks += [[("ctc_lo.weight", (V, d))], [("ctc_lo.bias", (V,))]]
         if self.use_decoder:
             blocks += [[("decoder.tgt_word_emb.weight", (V, d))]]
+            # the cross-attention K | V projections of ALL decoder layers side by side: they all multiply the same encoder output
+            # (transformer_official.py:309-314, 446-458), so the six projections are one (L 2 H dk, d) matrix to the engine
+            blocks += E.cross_kv_param_blocks([f"decoder.layer_stack.{i}.enc_attn." for i in range(c.layer_num)], H, dk, d)
             for i in range(c.layer_num):
                 blocks += E.mha_param_block(f"decoder.layer_stack.{i}.slf_attn.", H, dk, d)
-                blocks += E.mha_param_block(f"decoder.layer_stack.{i}.enc_attn.", H, dk, d)
+                blocks += E.cross_q_param_block(f"decoder.layer_stack.{i}.enc_attn.", H, dk, d)
                 blocks += E.ffn_param_block(f"decoder.layer_stack.{i}.pos_ffn.", d, ff)
         self._flat = E.FlatParams(blocks)
         self._engine = None

@@ -58,7 +58,7 @@ class DecLayerPlan(ctypes.Structure):
                                   "dz_s", "g_as", "g_qkv", "dx_s",
                                   "dctx", "gb_2", "gb_fc_c", "gb_fc_s",
                                   "part_f", "part_c", "part_s", "delta")] +
-                [("delta_bytes", Z), ("d_enc", P), ("wgrad_stream", P), ("aux_cus", I)])
+                [("delta_bytes", Z), ("d_enc", P), ("wgrad_stream", P), ("aux_cus", I), ("ld_kv_c", I), ("kv_dgrad_cols", I), ("g_kv_group", P)])
 
 # name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
 SIGNATURES = {

@@ -50,7 +50,8 @@ extern "C" int asr_decoder_layer_fwd(const asr_dec_layer_plan* p, void* stream) 
         if (he != hipSuccess) ASR_FAIL(ASR_EHIP, "asr_decoder_layer_fwd: hipStreamWaitEvent: %s", hipGetErrorString(he));
     }
     char* kv = (char*)p->kv_c;
-    DEC_TRY(asr_sdpa_fwd(p->q_c, kv, kv + hd * e, p->ctx_c, p->lse_c, p->cross_len, B, H, To, T, dk, hd, 2 * hd, 2 * hd, hd, 0, -1, scale, p->drop_p, p->seed[2],
+    const int ldkv = p->ld_kv_c > 0 ? p->ld_kv_c : 2 * hd;      // the K | V of all layers may sit side by side in one buffer
+    DEC_TRY(asr_sdpa_fwd(p->q_c, kv, kv + hd * e, p->ctx_c, p->lse_c, p->cross_len, B, H, To, T, dk, hd, ldkv, ldkv, hd, 0, -1, scale, p->drop_p, p->seed[2],
                          ASR_BF16, stream));
     DEC_TRY(asr_gemm_small_bf16(p->ctx_c, p->w_fc_c, p->b_fc_c, nullptr, p->a_c, M, d, hd, hd, hd, d, 0, ASR_ACT_NONE, stream));
     DEC_TRY(asr_add_ln_fwd(p->a_c, p->y_s, p->g_c, p->be_c, nullptr, p->dec_len, p->y_c, p->a_c, p->rstd_c, B, To, d, p->drop_p, p->seed[3], ASR_DROP_PRE,
@@ -93,15 +94,20 @@ extern "C" int asr_decoder_layer_bwd(const asr_dec_layer_plan* p, const void* dy
     // d_enc += dK|dV W_kv (a (B*T)-row GEMM off the decoder's dependent chain, on aux_stream) needs only the attention backward's dK|dV:
     // that kernel hands over by its own completion event (no event record - a barrier packet - in front of the chain's next kernel)
     const bool kv_dgrad = p->d_enc && p->w_kv_c_T;
+    const int ldkv = p->ld_kv_c > 0 ? p->ld_kv_c : 2 * hd;
+    if (p->kv_dgrad_cols > 0 && (!p->g_kv_group || p->kv_dgrad_cols % 8 || p->kv_dgrad_cols > ldkv)) ASR_FAIL(ASR_EINVAL, "asr_decoder_layer_bwd: kv_dgrad_cols = %d needs g_kv_group, a multiple of 8, <= ld_kv_c = %d", p->kv_dgrad_cols, ldkv);
     if (kv_dgrad && aux_stream) DEC_TRY(asr_stream_arm(stream, aux_stream));
     DEC_TRY(asr_sdpa_bwd(p->q_c, kv, kv + hd * e, p->ctx_c, p->dctx, p->lse_c, p->delta, p->delta_bytes, p->g_qc, gkv, gkv + hd * e, p->cross_len, B, H, To, T, dk, hd,
-                         2 * hd, 2 * hd, hd, 0, -1, scale, p->drop_p, p->seed[2], ASR_BF16, stream));
+                         ldkv, ldkv, hd, 0, -1, scale, p->drop_p, p->seed[2], ASR_BF16, stream));
     if (kv_dgrad) {
         void* st2 = aux_stream ? aux_stream : stream;
         if (aux_stream && asr_stream_arm_pending()) DEC_TRY(asr_stream_fork(stream, aux_stream));      // the attention path taken had no armed launch
         // a (B*T)-row GEMM beside the chain of small kernels: sized for p->aux_cus CUs when the caller reserves the rest for the chain
         const int old_lim = p->aux_cus > 0 ? asr_option_set(ASR_OPT_CU_LIMIT, p->aux_cus) : 0;
-        const int rc_kv = asr_gemm_nt_bf16(p->g_kvc, p->w_kv_c_T, nullptr, p->d_enc, p->d_enc, B * T, d, 2 * hd, 2 * hd, p->ld_kv_c_T, d, ASR_ACT_NONE, st2);
+        // one layer's columns, or - this layer being the last of its group - the whole group's: ONE read-modify-write of d_enc per group
+        const void* g_a = p->kv_dgrad_cols > 0 ? p->g_kv_group : p->g_kvc;
+        const int cols = p->kv_dgrad_cols > 0 ? p->kv_dgrad_cols : 2 * hd;
+        const int rc_kv = asr_gemm_nt_bf16(g_a, p->w_kv_c_T, nullptr, p->d_enc, p->d_enc, B * T, d, cols, ldkv, p->ld_kv_c_T, d, ASR_ACT_NONE, st2);
         if (p->aux_cus > 0) asr_option_set(ASR_OPT_CU_LIMIT, old_lim);
         DEC_TRY(rc_kv);
     }

@@ -232,15 +232,23 @@ class LayerNormP:
 
 
 class MHA:
-    """MultiHeadAttention of the reference (attention.py:6-62) over fused projections."""
+    """MultiHeadAttention of the reference (attention.py:6-62) over fused projections.  cross = False: Q | K | V adjacent (one (3 H dk, d)
+    projection of the block's input).  cross = True (the decoder's encoder-decoder attention): Q on its own, K | V adjacent inside the
+    matrix that holds the K | V projections of every decoder layer (cross_kv_param_blocks)."""
 
-    def __init__(self, flat, pre, H, dk, d):
+    def __init__(self, flat, pre, H, dk, d, cross=False):
         self.H, self.dk, self.d = H, dk, d
         hd = H * dk
-        self.qkv = Linear(flat, [pre + "w_qs.weight", pre + "w_ks.weight", pre + "w_vs.weight"],
-                          [pre + "w_qs.bias", pre + "w_ks.bias", pre + "w_vs.bias"], 3 * hd, d)
-        self.q = self.qkv.rows(0, hd)
-        self.kv = self.qkv.rows(hd, 3 * hd)
+        if cross:
+            self.qkv = None
+            self.q = Linear(flat, [pre + "w_qs.weight"], [pre + "w_qs.bias"], hd, d)
+            self.kv = Linear(flat, [pre + "w_ks.weight", pre + "w_vs.weight"], [pre + "w_ks.bias", pre + "w_vs.bias"], 2 * hd, d)
+            self.q.tag, self.kv.tag = "q_c", "kv_c"
+        else:
+            self.qkv = Linear(flat, [pre + "w_qs.weight", pre + "w_ks.weight", pre + "w_vs.weight"],
+                              [pre + "w_qs.bias", pre + "w_ks.bias", pre + "w_vs.bias"], 3 * hd, d)
+            self.q = self.qkv.rows(0, hd)
+            self.kv = self.qkv.rows(hd, 3 * hd)
         self.fc = Linear(flat, [pre + "fc.weight"], [pre + "fc.bias"], d, hd)
         self.ln = LayerNormP(flat, pre + "layer_norm")
 
@@ -256,6 +264,21 @@ def mha_param_block(pre, H, dk, d):
     hd = H * dk
     return [[(pre + "w_qs.weight", (hd, d)), (pre + "w_ks.weight", (hd, d)), (pre + "w_vs.weight", (hd, d))],
             [(pre + "w_qs.bias", (hd,)), (pre + "w_ks.bias", (hd,)), (pre + "w_vs.bias", (hd,))],
+            [(pre + "layer_norm.weight", (d,))], [(pre + "layer_norm.bias", (d,))],
+            [(pre + "fc.weight", (d, hd))], [(pre + "fc.bias", (d,))]]
+
+
+def cross_kv_param_blocks(pres, H, dk, d):
+    """w_ks | w_vs of the encoder-decoder attention of every decoder layer as ONE (L 2 H dk, d) matrix (+ one bias vector)."""
+    hd = H * dk
+    return [[(pre + n + ".weight", (hd, d)) for pre in pres for n in ("w_ks", "w_vs")],
+            [(pre + n + ".bias", (hd,)) for pre in pres for n in ("w_ks", "w_vs")]]
+
+
+def cross_q_param_block(pre, H, dk, d):
+    """What is left of an encoder-decoder attention block beside its K | V projection (cross_kv_param_blocks)."""
+    hd = H * dk
+    return [[(pre + "w_qs.weight", (hd, d))], [(pre + "w_qs.bias", (hd,))],
             [(pre + "layer_norm.weight", (d,))], [(pre + "layer_norm.bias", (d,))],
             [(pre + "fc.weight", (d, hd))], [(pre + "fc.bias", (d,))]]
 
@@ -419,8 +442,12 @@ class Engine:
             self.emb32 = flat.view(flat.p, "decoder.tgt_word_emb.weight")
             self.gemb = flat.view(flat.g, "decoder.tgt_word_emb.weight")
             self.prj = Linear(flat, ["decoder.tgt_word_emb.weight"], None, vocab_size, d)
-            self.dec = [(MHA(flat, f"decoder.layer_stack.{i}.slf_attn.", H, dk, d), MHA(flat, f"decoder.layer_stack.{i}.enc_attn.", H, dk, d),
+            self.dec = [(MHA(flat, f"decoder.layer_stack.{i}.slf_attn.", H, dk, d), MHA(flat, f"decoder.layer_stack.{i}.enc_attn.", H, dk, d, cross=True),
                          FFN(flat, f"decoder.layer_stack.{i}.pos_ffn.", d, ff)) for i in range(self.L)]
+            # the K | V projections of all decoder layers' encoder-decoder attention as ONE projection of the encoder output
+            kvn = [f"decoder.layer_stack.{i}.enc_attn.{n}" for i in range(self.L) for n in ("w_ks", "w_vs")]
+            self.kv_all = Linear(flat, [n + ".weight" for n in kvn], [n + ".bias" for n in kvn], self.L * 2 * H * dk, d)
+            self.kv_all.tag = "kv_all"
         if use_ctc:
             self.ctc_lo = Linear(flat, ["ctc_lo.weight"], ["ctc_lo.bias"], vocab_size, d)
         # row stride of the CTC head's logits / gradient rows in the training step: whole 128-byte lines (bf16: multiples of 64
@@ -439,9 +466,9 @@ class Engine:
         if flat.lp is not None:
             # encoder projections only: the decoder's B*To ~ 500 rows run on the 64 x 64-tile kernel with W as stored
             lins = [l for mha, ffn in self.enc for l in (mha.qkv, mha.fc, ffn.w1, ffn.w2)]
-            # ... and the decoder's cross-attention Q|K|V weights: their K|V half multiplies all B*T encoder frames in the
+            # ... and the decoder's cross-attention K|V weights (one matrix for all layers): they multiply all B*T encoder frames in the
             # accumulating input gradient d_enc += dK|dV W_kv (the residual-add store tail of the own kernel, no library call)
-            cross_qkv = [cross.qkv for _, cross, _ in self.dec] if getattr(self, "dec", None) else []
+            cross_qkv = [self.kv_all] if getattr(self, "dec", None) else []
             # ... and the CTC head (reduction over V = 4232 columns: the kernel's last k-step is ragged)
             head = [self.ctc_lo] if use_ctc else []
             lins = [l for l in lins + cross_qkv + head if l.N % 8 == 0 and l.K % 8 == 0]
@@ -459,9 +486,9 @@ class Engine:
                     dst_off, ldd = l.w_off, l.N
                     l.wlpT = flat.lpT[l.w_off:l.w_off + l.N * l.K].view(l.K, l.N)
                 tiles += [[l.w_off, l.N, l.K, (r << 16) | c, dst_off, ldd] for r in range((l.N + 63) // 64) for c in range((l.K + 63) // 64)]
-            for _, cross, _ in (self.dec if getattr(self, "dec", None) else []):
-                if cross.qkv.wlpT is not None:
-                    cross.kv.wlpT = cross.qkv.wlpT[:, cross.H * cross.dk:]      # (d, 2 H dk) view, row stride 3 H dk
+            for i, (_, cross, _) in enumerate(self.dec if getattr(self, "dec", None) else []):
+                if self.kv_all.wlpT is not None:
+                    cross.kv.wlpT = self.kv_all.wlpT[:, i * cross.kv.N:(i + 1) * cross.kv.N]      # (d, 2 H dk) view, row stride L 2 H dk
             self._tr_tiles = torch.tensor(tiles, dtype=torch.int32, device=flat.device)
             self._tr_event = torch.cuda.Event()
             self._tr_pending = False
@@ -520,6 +547,16 @@ class Engine:
         # within 1 % of each other; 0 = the whole device).  The head's weight gradient queued BEHIND its input gradient on the auxiliary stream
         # instead of beside it on the weight-gradient stream: 4.880 vs 4.853 ms - not kept.
         self.dec_cu_limit = int(os.environ.get("ASR_DEC_CU_LIMIT", "192"))
+        # ASR_KV_GROUPS = g (default 3): the decoder layers' cross-attention K | V projections share one weight matrix, one activation buffer and
+        # one gradient buffer (all layers read the same encoder output): forward = layer 0's columns, then ONE GEMM for the rest; backward = the
+        # encoder-output gradient d_enc += G W_kv and the K | V weight gradient once per group of L / g adjacent layers (g = L: per layer, as
+        # before round 5; g = 1: one K = L 2 H dk GEMM behind the whole decoder backward pass).  Measured (joint step, one box, tools/ab_env.py and
+        # the previous commit's tree beside this one): g = 6 / 3 / 2 / 1: 5.01 / 5.01 / 5.04 / 5.09 ms, and 4.89 (previous commit) / 4.89 (g = 6) / 4.89 -
+        # 4.90 (g = 3) on another box: these GEMMs run on the auxiliary stream beside the decoder's chain of small kernels, off the critical path -
+        # fewer, larger launches there buy nothing, and one launch behind the whole backward pass (g = 1) is exposed.
+        g = max(1, min(self.L, int(os.environ.get("ASR_KV_GROUPS", "3"))))
+        cuts = [round(j * self.L / g) for j in range(g + 1)]
+        self.kv_groups = [(cuts[j], cuts[j + 1]) for j in range(g) if cuts[j + 1] > cuts[j]]
         self._kv_ahead = None
         self._pending = []
         self._deferred = []
@@ -985,11 +1022,16 @@ class Engine:
         need = max(_lib.lib.asr_sdpa_bwd_workspace_bytes(B, H, To, T, self.dk, 0, -1, _lib.ASR_BF16), _lib.lib.asr_sdpa_bwd_workspace_bytes(B, H, To, To, self.dk, 1, -1, _lib.ASR_BF16))
         delta = f32((need + 3) // 4)
         layers = []
+        # K | V of the encoder frames for ALL layers in one buffer (layer i = columns [i 2hd, (i+1) 2hd): the attention kernels take a row
+        # stride), and the gradient wrt it likewise: the six projections are one GEMM forward (two launches: layer 0's columns first), the
+        # encoder-output gradient d_enc += G W_kv one GEMM per layer GROUP with the reduction over the group's columns, and the weight
+        # gradient one problem per group (self.kv_groups)
+        kv_all, g_kv_all = bf(B * T, self.L * 2 * hd), bf(B * T, self.L * 2 * hd)
         for i, (slf, cross, ffn) in enumerate(self.dec):
             t = dict(qkv_s=bf(M, 3 * hd), ctx_s=bf(M, hd), a_s=bf(M, d), y_s=bf(M, d), lse_s=f32(B, H, To), rstd_s=f32(M),
-                     q_c=bf(M, hd), kv_c=bf(B * T, 2 * hd), ctx_c=bf(M, hd), a_c=bf(M, d), y_c=bf(M, d), lse_c=f32(B, H, To), rstd_c=f32(M),
+                     q_c=bf(M, hd), kv_c=kv_all[:, i * 2 * hd:(i + 1) * 2 * hd], ctx_c=bf(M, hd), a_c=bf(M, d), y_c=bf(M, d), lse_c=f32(B, H, To), rstd_c=f32(M),
                      h=bf(M, ff), o=bf(M, d), y_f=bf(M, d), rstd_f=f32(M),
-                     dz_f=bf(M, d), g_h=bf(M, ff), dx_f=bf(M, d), dz_c=bf(M, d), g_qc=bf(M, hd), g_kvc=bf(B * T, 2 * hd), dx_c=bf(M, d),
+                     dz_f=bf(M, d), g_h=bf(M, ff), dx_f=bf(M, d), dz_c=bf(M, d), g_qc=bf(M, hd), g_kvc=g_kv_all[:, i * 2 * hd:(i + 1) * 2 * hd], dx_c=bf(M, d),
                      dz_s=bf(M, d), g_qkv=bf(M, 3 * hd), dx_s=bf(M, d), dctx=bf(M, hd),
                      part_f=torch.empty(part_bytes, dtype=torch.uint8, device=dev), part_c=torch.empty(part_bytes, dtype=torch.uint8, device=dev),
                      part_s=torch.empty(part_bytes, dtype=torch.uint8, device=dev))
@@ -997,6 +1039,7 @@ class Engine:
                 t.update(g_o=bf(M, d), g_ac=bf(M, d), g_as=bf(M, d))
             pl = _lib.DecLayerPlan()
             pl.B, pl.To, pl.T, pl.d, pl.H, pl.dk, pl.ff = B, To, T, d, H, self.dk, ff
+            pl.ld_kv_c = self.L * 2 * hd
             for name, ten in t.items():
                 setattr(pl, name, ten.data_ptr())
             for name, lin in (("qkv_s", slf.qkv), ("fc_s", slf.fc), ("q_c", cross.q), ("fc_c", cross.fc), ("1", ffn.w1), ("2", ffn.w2)):
@@ -1011,7 +1054,7 @@ class Engine:
             pl.delta, pl.delta_bytes = delta.data_ptr(), delta.numel() * 4
             t["kv_event"] = torch.cuda.Event()
             layers.append((pl, t))
-        hit = self._dec_cache[key] = dict(layers=layers, delta=delta, pinned=capturing)
+        hit = self._dec_cache[key] = dict(layers=layers, delta=delta, pinned=capturing, kv_all=kv_all, g_kv_all=g_kv_all, kv_event_rest=torch.cuda.Event())
         return hit
 
     def _kv_exec_async(self, bufs, enc):
@@ -1022,10 +1065,17 @@ class Engine:
             if self.dec_cu_limit:
                 K.set_cu_limit(self.dec_cu_limit)
             try:
-                for (pl, t), (_, cross, _) in zip(bufs["layers"], self.dec):
-                    cross.kv.fwd(enc, out=t["kv_c"])
-                    t["kv_event"].record(self.ctc_stream)
-                    pl.kv_ready_event = t["kv_event"].cuda_event
+                # layer 0's columns first (the chain's first cross-attention, ~80 us in, waits for them), then layers 1 .. L-1 as ONE GEMM
+                n0 = self.dec[0][1].kv.N
+                pl0, t0 = bufs["layers"][0]
+                self.dec[0][1].kv.fwd(enc, out=t0["kv_c"])
+                t0["kv_event"].record(self.ctc_stream)
+                pl0.kv_ready_event = t0["kv_event"].cuda_event
+                if self.L > 1:
+                    self.kv_all.rows(n0, self.kv_all.N).fwd(enc, out=bufs["kv_all"][:, n0:])
+                    bufs["kv_event_rest"].record(self.ctc_stream)
+                    for pl, t in bufs["layers"][1:]:
+                        pl.kv_ready_event = bufs["kv_event_rest"].cuda_event
             finally:
                 if self.dec_cu_limit:
                     K.set_cu_limit(0)
@@ -1072,6 +1122,8 @@ class Engine:
         aux = self.ctc_stream.cuda_stream if (self.aux_overlap and not torch.cuda.is_current_stream_capturing()) else None
         dy2 = None
         M = dy.shape[0]
+        nkv = self.dec[0][1].kv.N
+        groups = {lo: (lo, hi) for lo, hi in self.kv_groups}      # keyed by the layer that closes the group
         for i in reversed(range(self.L)):
             pl, t = bufs["layers"][i]
             slf, cross, ffn = self.dec[i]
@@ -1080,7 +1132,15 @@ class Engine:
             if d_enc_ready is not None:      # d_enc must hold the CTC branch's contribution before the first cross-attention add
                 torch.cuda.current_stream().wait_event(d_enc_ready)
                 d_enc_ready = None
-            pl.d_enc = d_enc.data_ptr() if cross.kv.wlpT is not None else None
+            # the encoder-output gradient d_enc += G W_kv runs once per GROUP of layers (self.kv_groups), issued by the group's last layer
+            # (the lowest index: the backward pass walks downwards) over the group's columns of the shared gradient buffer
+            grp = groups.get(i) if cross.kv.wlpT is not None else None
+            pl.d_enc, pl.kv_dgrad_cols, pl.g_kv_group = None, 0, None
+            if grp is not None:
+                c0, c1 = grp[0] * nkv, grp[1] * nkv
+                pl.d_enc, pl.kv_dgrad_cols = d_enc.data_ptr(), c1 - c0
+                pl.g_kv_group = bufs["g_kv_all"][:, c0:].data_ptr()
+                pl.w_kv_c_T, pl.ld_kv_c_T = self.kv_all.wlpT[:, c0:].data_ptr(), self.kv_all.wlpT.stride(0)
             hand_over = self.armed_fork and self.overlap_wgrad and not torch.cuda.is_current_stream_capturing()
             pl.wgrad_stream = self._side_handle if hand_over else None      # the layer's last kernel signals the weight-gradient stream itself
             pl.aux_cus = self.dec_cu_limit if aux is not None else 0
@@ -1094,7 +1154,12 @@ class Engine:
             self._wgrad(ffn.w1, t["g_h"], t["y_c"], bias_from=t["g_h"])
             self._wgrad(cross.fc, t["g_ac"] if drop else t["dz_c"], t["ctx_c"])
             self._wgrad(cross.q, t["g_qc"], t["y_s"], bias_from=t["g_qc"])
-            self._wgrad(cross.kv, t["g_kvc"], enc, bias_from=t["g_kvc"])
+            if cross.kv.wlpT is None:
+                self._wgrad(cross.kv, t["g_kvc"], enc, bias_from=t["g_kvc"])
+            elif grp is not None:      # the K | V weight gradients of the group's layers as ONE problem (their rows of the shared matrix are adjacent)
+                c0, c1 = grp[0] * nkv, grp[1] * nkv
+                g = bufs["g_kv_all"][:, c0:c1]
+                self._wgrad(self.kv_all.rows(c0, c1), g, enc, bias_from=g)
             self._wgrad(slf.fc, t["g_as"] if drop else t["dz_s"], t["ctx_s"])
             self._wgrad(slf.qkv, t["g_qkv"], t["x_in"], bias_from=t["g_qkv"])
             self._ln_pending += [(t["part_f"], ffn.ln.gg, ffn.ln.gb, ffn.w2.gb, M), (t["part_c"], cross.ln.gg, cross.ln.gb, cross.fc.gb, M),

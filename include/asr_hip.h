@@ -464,7 +464,7 @@ typedef struct asr_dec_layer_plan {
     void *qkv_s, *ctx_s, *a_s, *y_s;       /* (M, 3 H dk), (M, H dk), (M, d) = fc output then xhat, (M, d) block output */
     float *lse_s, *rstd_s;                 /* (B, H, To), (M) */
     void* q_c;                             /* (M, H dk) */
-    const void* kv_c;                      /* (B*T, 2 H dk) K|V of the encoder frames, projected by the caller */
+    const void* kv_c;                      /* (B*T, 2 H dk) K|V of the encoder frames, projected by the caller (row stride ld_kv_c) */
     void* kv_ready_event;                  /* hipEvent_t after which kv_c is complete, or NULL (HOST handle) */
     void *ctx_c, *a_c, *y_c;
     float *lse_c, *rstd_c;
@@ -486,6 +486,15 @@ typedef struct asr_dec_layer_plan {
     int aux_cus;                           /* backward (ABI 8): > 0 = the (B*T)-row GEMM d_enc += g_kvc W_kv that the layer puts on aux_stream is
                                               sized for this many CUs (tuning option "cu_limit" around that one launch), so that the rest stay free
                                               for the layer's own chain of small kernels; 0 = the whole device */
+    /* ABI 9: the K | V projections of ALL decoder layers read the same encoder output (transformer_official.py:309-314, 446-458): the caller may
+     * keep them - and the gradients wrt them - side by side in one (B*T, L 2 H dk) buffer and run the encoder-output gradient once per GROUP of
+     * layers with the reduction over the group's columns, instead of one read-modify-write of d_enc per layer. */
+    int ld_kv_c;                           /* row stride (elements) of kv_c and g_kvc; 0 = 2 H dk (a buffer per layer) */
+    int kv_dgrad_cols;                     /* 0: d_enc += g_kvc W_kv over this layer's 2 H dk columns (as before).  > 0: this layer is the LAST of a
+                                              group to run its backward pass: d_enc += g_kv_group W_group over kv_dgrad_cols columns, with g_kv_group
+                                              (B*T, kv_dgrad_cols) at row stride ld_kv_c and w_kv_c_T = the group's (d, kv_dgrad_cols) slice of the
+                                              transposed weight; the other layers of the group pass d_enc = NULL */
+    const void* g_kv_group;
 } asr_dec_layer_plan;
 int asr_decoder_layer_fwd(const asr_dec_layer_plan* plan, void* stream);
 /* (dy, dy2): gradient wrt y_f (dy2 may be NULL; the two are added).  Results: plan->dx_s and plan->dz_s = gradient wrt x_in through the
