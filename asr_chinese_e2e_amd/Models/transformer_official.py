@@ -210,8 +210,14 @@ class _SpeechTransformer(BaseModel):
         return out
 
     def zero_flat_grads(self):
+        """Zero the flat gradient buffer for the step that follows.  With the multi-stream engine the fill (160 MB at the joint model's size,
+        ~20 us) is not queued in front of the forward pass on the main stream: train_step hands it to the weight-gradient stream - idle during
+        the forward pass - in front of the transposed weight copies, whose event every backward path waits for before its first gradient write."""
         f = self._flat
-        f.g.zero_()
+        eng = self._engine
+        self._zero_lazy = eng is not None and eng._tr_tiles is not None and eng.overlap_wgrad
+        if not self._zero_lazy:
+            f.g.zero_()
         if self._grads_checked:             # fast path: .grad views were verified and nobody reset them
             return
         for name, p in self._named_flat_params():
@@ -391,7 +397,8 @@ class _SpeechTransformer(BaseModel):
         lam = self.ctc_weight
         ys_in, ys_out, labels32, dec_len, lab_len, n_valid = prep
         pending = count_hook(n_valid, B) if count_hook is not None else None
-        eng.refresh_transposes()      # W^T copies for this step's input-gradient GEMMs (side stream, beside the forward pass)
+        zero, self._zero_lazy = (self._flat.g if getattr(self, "_zero_lazy", False) else None), False
+        eng.refresh_transposes(zero=zero)      # W^T copies for this step's input-gradient GEMMs (side stream, beside the forward pass)
         enc, ecache = eng.encoder_fwd(x, wave_len, self.attn_window)
         batch_div = None
         if pending is not None:
@@ -408,10 +415,13 @@ class _SpeechTransformer(BaseModel):
         if self.use_decoder:
             cross_len = self._tgt_len32 if self.cross_mask == "ref_compat" else wave_len
             pred, dcache = eng.decoder_fwd(prep, enc, cross_len, B, T)
-            if self.cer_in_iterate:
-                pg = (pred.view(B, -1, self.V).argmax(-1), ys_out)
+            # the greedy ids of the step's CER come out of the loss kernel (it reads every row anyway; the gradient overwrites the logits in place)
+            ids = torch.empty(ys_out.shape, dtype=torch.int32, device=pred.device) if self.cer_in_iterate else None
             w_ce = (1.0 - lam) if self.use_ctc else 1.0
-            row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, smoothing=self.label_smoothing, grad_scale=w_ce * loss_scale, dlogits=pred)
+            row_nll, dpred = K.xent_fwd_bwd(pred, ys_out.reshape(-1), n_valid, PAD_ID, smoothing=self.label_smoothing, grad_scale=w_ce * loss_scale, dlogits=pred,
+                                            argmax=ids)
+            if ids is not None:
+                pg = (ids, ys_out)
         if self.use_ctc and not ctc_async:
             # CTC-only model: the step's CER (the reference's trainer reads metrics.cer every step, Trainer/trainer11.py:73-75) is scored on the
             # greedy CTC path, which the loss kernels hand out (the gradient overwrites the logits in place)

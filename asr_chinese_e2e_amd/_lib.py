@@ -92,10 +92,10 @@ SIGNATURES = {
     "asr_ctc_prefix_beam": (I, [P, P, P, P, P, Z, P, P, P, I, I, I, I, I, I, I, P]),
     "asr_beam_step": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "asr_cache_gather": (I, [P, P, P, I, I, I, I, I, I, P]),
-    "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, I, P]),
+    "asr_xent_fwd_bwd": (I, [P, P, P, P, P, I, I, I, F, F, P, I, P]),
     "asr_dec_preprocess": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "asr_embed_pe_fwd": (I, [P, P, P, P, F, I, I, I, I, F, U, I, P]),
-    "asr_embed_bwd": (I, [P, P, P, F, I, I, I, F, U, I, P]),
+    "asr_embed_bwd": (I, [P, P, P, P, F, I, I, I, F, U, I, P]),
     "asr_relu_fwd": (I, [P, Z, I, P]),
     "asr_relu_bwd": (I, [P, P, P, P, Z, I, I, I, P]),
     "asr_colsum_workspace_bytes": (Z, [I, I]),

@@ -642,18 +642,51 @@ __global__ __launch_bounds__(256) void ctc_label_fix_kernel(bf16_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------- xent
-template <typename T>
+// (value, index) of the row maximum over the workgroup, first index on ties (torch.argmax): every thread brings the first maximum of its own
+// elements (ascending indices, strict >); `redi` = 8 ints of LDS
+__device__ __forceinline__ int block_argmax(float v, int i, float* red, int* redi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(v, o, 64);
+        const int i2 = __shfl_xor(i, o, 64);
+        if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) { red[w] = v; redi[w] = i; }
+    __syncthreads();
+    float bv = red[0];
+    int bi = redi[0];
+    for (int k = 1; k < nw; ++k)
+        if (red[k] > bv || (red[k] == bv && redi[k] < bi)) { bv = red[k]; bi = redi[k]; }
+    return bi;
+}
+
+// ARGMAX: also write the row's greedy class (first index of the maximum) to argmax_out[row] - for EVERY row, ignored ones included: the
+// reference's per-step CER takes pred.topk(1) of all rows (transformer_official.py:87-91), and the gradient overwrites the logits in place.
+template <typename T, bool ARGMAX>
 __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits, const int32_t* __restrict__ gold, const float* __restrict__ n_valid,
                                                    float* __restrict__ row_nll, T* __restrict__ dlogits, int M, int V, int ignore_index,
-                                                   float smoothing, float grad_scale) {
+                                                   float smoothing, float grad_scale, int32_t* __restrict__ argmax_out) {
     __shared__ float red[16];
+    __shared__ int redi[8];
     constexpr int N = Vec<T>::N;
     const int row = blockIdx.x;
     const T* x = logits + (size_t)row * V;
     const int g = gold[row];
     const bool ignored = (g == ignore_index) || g < 0 || g >= V;
     T* dl = dlogits ? dlogits + (size_t)row * V : nullptr;
+    float best = NEG_INF;
+    int bi = 0x7fffffff;
     if (ignored) {
+        if (ARGMAX) {
+            for (int i = threadIdx.x; i < V; i += 256) {
+                const float v = to_f32<T>(x[i]);
+                if (v > best) { best = v; bi = i; }
+            }
+            const int a = block_argmax(best, bi, red, redi);      // contains barriers: every thread of the row's workgroup is here
+            if (threadIdx.x == 0) argmax_out[row] = a;
+        }
         if (threadIdx.x == 0) row_nll[row] = 0.f;
         if (dl) for (int i = threadIdx.x; i < V; i += 256) dl[i] = from_f32<T>(0.f);
         return;
@@ -664,6 +697,11 @@ __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits,
         for (int i = threadIdx.x; i < V / N; i += 256) {
             float v[N];
             loadv<T>(x + (size_t)i * N, v);
+            if (ARGMAX) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (v[j] > best) { best = v[j]; bi = i * N + j; }
+            }
             float lm = v[0];
 #pragma unroll
             for (int j = 1; j < N; ++j) lm = fmaxf(lm, v[j]);
@@ -677,11 +715,16 @@ __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits,
     } else {
         for (int i = threadIdx.x; i < V; i += 256) {
             const float v = to_f32<T>(x[i]);
+            if (ARGMAX && v > best) { best = v; bi = i; }
             const float mn = fmaxf(m, v);
             s = s * expf(m - mn) + expf(v - mn);
             m = mn;
             sx += v;
         }
+    }
+    if (ARGMAX) {
+        const int a = block_argmax(best, bi, red, redi);
+        if (threadIdx.x == 0) argmax_out[row] = a;
     }
     const float gm = block_max(m, red);
     const float gs = block_sum(gm == NEG_INF ? 0.f : s * expf(m - gm), red);
@@ -807,13 +850,15 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
 }
 
 extern "C" int asr_xent_fwd_bwd(const void* logits, const int32_t* gold, const float* n_valid, float* row_nll, void* dlogits, int M,
-                                int V, int ignore_index, float smoothing, float grad_scale, int dtype, void* stream) {
+                                int V, int ignore_index, float smoothing, float grad_scale, int32_t* argmax_out, int dtype, void* stream) {
     if (!logits || !gold || !row_nll || (dlogits && !n_valid)) ASR_FAIL(ASR_EINVAL, "asr_xent_fwd_bwd: null pointer");
     if (M <= 0 || V <= 1) ASR_FAIL(ASR_EINVAL, "asr_xent_fwd_bwd: bad shape M=%d V=%d", M, V);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ASR_F32) xent_kernel<float><<<M, 256, 0, st>>>((const float*)logits, gold, n_valid, row_nll, (float*)dlogits, M, V, ignore_index, smoothing, grad_scale);
-    else if (dtype == ASR_BF16) xent_kernel<bf16_t><<<M, 256, 0, st>>>((const bf16_t*)logits, gold, n_valid, row_nll, (bf16_t*)dlogits, M, V, ignore_index, smoothing, grad_scale);
-    else ASR_FAIL(ASR_EDTYPE, "asr_xent_fwd_bwd: dtype %d", dtype);
+    if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_xent_fwd_bwd: dtype %d", dtype);
+#define XENT(T_, A_) xent_kernel<T_, A_><<<M, 256, 0, st>>>((const T_*)logits, gold, n_valid, row_nll, (T_*)dlogits, M, V, ignore_index, smoothing, grad_scale, argmax_out)
+    if (dtype == ASR_F32) { if (argmax_out) XENT(float, true); else XENT(float, false); }
+    else { if (argmax_out) XENT(bf16_t, true); else XENT(bf16_t, false); }
+#undef XENT
     ASR_CHECK_LAUNCH("asr_xent_fwd_bwd");
     return ASR_OK;
 }

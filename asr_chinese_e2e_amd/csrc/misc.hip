@@ -311,14 +311,14 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int32_t* __rest
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dy, const T* __restrict__ dy2,
                                                         float* __restrict__ demb, float scale, int d, int V, uint32_t seed, uint32_t thr,
                                                         float dscale) {
     const int row = blockIdx.x;
     const int id = ids[row];
     if (id < 0 || id >= V) return;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        float g = to_f32<T>(dy[(size_t)row * d + c]) * scale;
+        float g = (to_f32<T>(dy[(size_t)row * d + c]) + (dy2 ? to_f32<T>(dy2[(size_t)row * d + c]) : 0.f)) * scale;
         if (thr) g = drop_keep_at((uint32_t)row * (uint32_t)d + c, seed, thr) ? g * dscale : 0.f;
         if (g != 0.f) atomicAdd(&demb[(size_t)id * d + c], g);
     }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
 
 // Deterministic form: thread = one column, tokens in order (rows of the same id are added in a fixed order).
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_serial_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void embed_bwd_serial_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dy, const T* __restrict__ dy2,
                                                                float* demb, float scale, int rows, int d, int V, uint32_t seed, uint32_t thr,
                                                                float dscale) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void embed_bwd_serial_kernel(const int32_t* __
     for (int row = 0; row < rows; ++row) {
         const int id = ids[row];
         if (id < 0 || id >= V) continue;
-        float g = to_f32<T>(dy[(size_t)row * d + c]) * scale;
+        float g = (to_f32<T>(dy[(size_t)row * d + c]) + (dy2 ? to_f32<T>(dy2[(size_t)row * d + c]) : 0.f)) * scale;
         if (thr) g = drop_keep_at((uint32_t)row * (uint32_t)d + c, seed, thr) ? g * dscale : 0.f;
         if (g != 0.f) demb[(size_t)id * d + c] += g;
     }
@@ -587,7 +587,7 @@ extern "C" int asr_embed_pe_fwd(const int32_t* ids, const void* emb, const float
     return ASR_OK;
 }
 
-extern "C" int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, float scale, int rows, int d, int V, float drop_p,
+extern "C" int asr_embed_bwd(const int32_t* ids, const void* dy, const void* dy2, float* demb, float scale, int rows, int d, int V, float drop_p,
                              uint32_t drop_seed, int dtype, void* stream) {
     if (!ids || !dy || !demb) ASR_FAIL(ASR_EINVAL, "asr_embed_bwd: null pointer");
     if (rows <= 0 || d <= 0) ASR_FAIL(ASR_EINVAL, "asr_embed_bwd: bad shape");
@@ -597,10 +597,10 @@ extern "C" int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, fl
     const float ds = 1.f / (1.f - drop_p);
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_embed_bwd: dtype %d", dtype);
     if (asr_deterministic()) {
-        if (dtype == ASR_F32) embed_bwd_serial_kernel<float><<<ceil_div(d, 256), 256, 0, st>>>(ids, (const float*)dy, demb, scale, rows, d, V, drop_seed, thr, ds);
-        else embed_bwd_serial_kernel<bf16_t><<<ceil_div(d, 256), 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, rows, d, V, drop_seed, thr, ds);
-    } else if (dtype == ASR_F32) embed_bwd_kernel<float><<<rows, 256, 0, st>>>(ids, (const float*)dy, demb, scale, d, V, drop_seed, thr, ds);
-    else embed_bwd_kernel<bf16_t><<<rows, 256, 0, st>>>(ids, (const bf16_t*)dy, demb, scale, d, V, drop_seed, thr, ds);
+        if (dtype == ASR_F32) embed_bwd_serial_kernel<float><<<ceil_div(d, 256), 256, 0, st>>>(ids, (const float*)dy, (const float*)dy2, demb, scale, rows, d, V, drop_seed, thr, ds);
+        else embed_bwd_serial_kernel<bf16_t><<<ceil_div(d, 256), 256, 0, st>>>(ids, (const bf16_t*)dy, (const bf16_t*)dy2, demb, scale, rows, d, V, drop_seed, thr, ds);
+    } else if (dtype == ASR_F32) embed_bwd_kernel<float><<<rows, 256, 0, st>>>(ids, (const float*)dy, (const float*)dy2, demb, scale, d, V, drop_seed, thr, ds);
+    else embed_bwd_kernel<bf16_t><<<rows, 256, 0, st>>>(ids, (const bf16_t*)dy, (const bf16_t*)dy2, demb, scale, d, V, drop_seed, thr, ds);
     ASR_CHECK_LAUNCH("asr_embed_bwd");
     return ASR_OK;
 }

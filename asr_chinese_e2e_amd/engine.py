@@ -677,15 +677,20 @@ class Engine:
                 cur.wait_stream(self.ctc_stream)
             self._keep.clear()
 
-    def refresh_transposes(self):
+    def refresh_transposes(self, zero=None):
         """W^T copies for the own-kernel input gradients: one launch on the side stream, which is idle during the
         forward pass; the backward pass waits for it (wait_transposes) before its first input-gradient GEMM.
         Called by the model at the start of every step that will run a backward pass (train_step), whatever the
         module's train / eval flag says."""
         if self._tr_tiles is None:
+            if zero is not None:
+                zero.zero_()
             return
         self._disarm()      # an arm left by a step that raised must not skip this hand-over (the copies must follow the optimizer update)
         self._fork(self.side)
+        if zero is not None:      # the step's gradient buffer, zeroed beside the forward pass (Models.zero_flat_grads); ordered by _tr_event below
+            with torch.cuda.stream(self.side):
+                zero.zero_()
         K.STREAM_OVERRIDE = self._side_handle
         try:
             K.transpose_batched(self.flat.lp, self.flat.lpT, self._tr_tiles)
@@ -1226,8 +1231,9 @@ class Engine:
             dx, dz = self._attn_block_bwd(slf, c1, dx, dz)
             dy, dy2 = dx, dz
             self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
-        dx = dy + dy2  # gradient wrt the embedding output
-        K.embed_bwd(cache["ys_in"].reshape(-1), dx, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1])
+        # gradient wrt the embedding output = projection path + residual path, added inside the scatter kernel
+        K.embed_bwd(cache["ys_in"].reshape(-1), dy.contiguous(), self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1],
+                    dy2=dy2.contiguous() if dy2 is not None else None)
         if self.aux_overlap and not torch.cuda.is_current_stream_capturing():      # nothing is forked to that stream while capturing
             torch.cuda.current_stream().wait_stream(self.ctc_stream)      # d_enc is complete (CTC branch + every cross-attention add)
         self._in_decoder = False

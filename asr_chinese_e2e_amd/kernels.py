@@ -393,17 +393,19 @@ def cache_gather(src, dst, parent, L, R, beam, Lcap, n_pos, row_bytes):
 
 
 def xent_fwd_bwd(logits, gold, n_valid, ignore_index=0, smoothing=0.0, grad_scale=1.0, dlogits=None, want_grad=True,
-                 row_nll=None):
+                 row_nll=None, argmax=None):
+    """argmax: optional (M) int32 tensor that receives every row's greedy class (first index of the maximum, ignored rows included)."""
     M, V = logits.shape
     assert logits.is_contiguous() and gold.numel() == M
-    _chk_i32(gold)
+    _chk_i32(gold, argmax)
+    assert argmax is None or argmax.numel() == M
     _chk_f32(n_valid)
     row_nll = torch.empty(M, dtype=torch.float32, device=logits.device) if row_nll is None else row_nll
     if want_grad and dlogits is None:
         dlogits = torch.empty_like(logits)
     timed("xent", 0.0, lambda: check(
         lib.asr_xent_fwd_bwd(_p(logits), _p(gold), _p(n_valid), _p(row_nll), _p(dlogits), M, V, int(ignore_index),
-                             float(smoothing), float(grad_scale), _dt(logits), _stream()), "asr_xent_fwd_bwd"),
+                             float(smoothing), float(grad_scale), _p(argmax), _dt(logits), _stream()), "asr_xent_fwd_bwd"),
           (3.0 if dlogits is not None else 1.0) * logits.numel() * logits.element_size())                      # SURVEY 8(d): 3 M V e
     return row_nll, dlogits
 
@@ -454,12 +456,13 @@ def embed_pe_fwd(ids, emb, pe, scale, B, To, dtype, y=None, drop_p=0.0, drop_see
     return y
 
 
-def embed_bwd(ids, dy, demb, scale, drop_p=0.0, drop_seed=0):
+def embed_bwd(ids, dy, demb, scale, drop_p=0.0, drop_seed=0, dy2=None):
     V, d = demb.shape
     _chk_i32(ids)
     _chk_f32(demb)
     assert dy.is_contiguous() and dy.shape[-1] == d and dy.numel() == ids.numel() * d
-    check(lib.asr_embed_bwd(_p(ids), _p(dy), _p(demb), float(scale), ids.numel(), d, V, float(drop_p),
+    assert dy2 is None or (dy2.is_contiguous() and dy2.shape == dy.shape and dy2.dtype == dy.dtype)
+    check(lib.asr_embed_bwd(_p(ids), _p(dy), _p(dy2), _p(demb), float(scale), ids.numel(), d, V, float(drop_p),
                             int(drop_seed) & 0xFFFFFFFF, _dt(dy), _stream()), "asr_embed_bwd")
 
 

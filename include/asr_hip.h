@@ -297,10 +297,13 @@ int asr_cer(const int32_t* hyp, const int32_t* hyp_len, int Lh, int ldh, const i
  * logits: (M, V) `dtype`; gold: (M) int32.  row_nll: (M) f32 per-row loss (0 for ignored rows).
  * dlogits (may alias logits, may be NULL) = grad_scale / n_valid * d(sum row_nll)/dlogits where
  * n_valid is read from device memory (*n_valid, f32, e.g. written by asr_dec_preprocess).
+ * argmax_out (ABI 9; may be NULL): (M) int32, the greedy class of EVERY row (ignored ones included; first index on ties) - the ids of
+ * cal_metrics' pred.topk(1) (transformer_official.py:87-91), taken by the pass that reads the row anyway (with dlogits aliasing logits
+ * the logits are gone after the call).
  */
 int asr_xent_fwd_bwd(const void* logits, const int32_t* gold, const float* n_valid,
                      float* row_nll, void* dlogits, int M, int V, int ignore_index,
-                     float smoothing, float grad_scale, int dtype, void* stream);
+                     float smoothing, float grad_scale, int32_t* argmax_out, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder target preparation on device.
@@ -325,8 +328,9 @@ int asr_dec_preprocess(const int64_t* tgt, int32_t* ys_in, int32_t* ys_out, int3
 int asr_embed_pe_fwd(const int32_t* ids, const void* emb, const float* pe, void* y, float scale,
                      int B, int To, int d, int V, float drop_p, uint32_t drop_seed, int dtype,
                      void* stream);
-/* demb (V, d) f32 += scale * scatter-add over rows of (dy * keep / (1-p)) ((B*To, d) `dtype`). */
-int asr_embed_bwd(const int32_t* ids, const void* dy, float* demb, float scale, int rows, int d,
+/* demb (V, d) f32 += scale * scatter-add over rows of ((dy + dy2) * keep / (1-p)) ((B*To, d) `dtype`; dy2 may be NULL: ABI 9 - the
+ * gradient wrt the first decoder layer's input arrives as a (projection path, residual path) pair, added here in fp32). */
+int asr_embed_bwd(const int32_t* ids, const void* dy, const void* dy2, float* demb, float scale, int rows, int d,
                   int V, float drop_p, uint32_t drop_seed, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -77,7 +77,7 @@ def test_fastcall_trampolines_agree_with_ctypes():
     assert f.asr_gemm_nt_bf16(16, 16, None, None, 16, -3, 8, 8, 8, 8, 8, 0, None) == -1
     assert "M=-3" in _lib.last_error()
     # two floats interleaved with ints: the SECOND one (dropout p = 1.5) must arrive in its own register and is refused by value
-    assert f.asr_embed_bwd(16, 16, 16, 22.6, 4, 8, 100, 1.5, 0, 0, None) == -1
+    assert f.asr_embed_bwd(16, 16, None, 16, 22.6, 4, 8, 100, 1.5, 0, 0, None) == -1
     assert "p=1.5" in _lib.last_error()
     with pytest.raises(TypeError):
         f.asr_ctc_workspace_bytes(32, 500)                 # arity

@@ -437,6 +437,17 @@ def test_xent(K, dtype, M, V, smoothing):
     assert abs(float(loss) - float(ref)) < (2e-5 if dtype == torch.float32 else 2e-5) * abs(float(ref)) + 1e-6
     gt = dict(rtol=1e-4, atol=1e-7) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-4)
     close(dl, 0.7 * x.grad, **gt, what="xent grad")
+    # greedy ids from the same pass (ABI 9), in place too: every row - ignored ones included - first index on ties (torch.argmax)
+    lt = logits.clone()
+    lt[1, 5] = lt[1, V - 1] = 50.0      # a two-way tie at a valid row: the lower index wins
+    lt[0] = 0.0                         # an ignored row (gold 0) whose logits are all equal: index 0
+    buf = lt.to(DEV)
+    ids = torch.full((M,), -1, dtype=torch.int32, device=DEV)
+    row2, dl2 = K.xent_fwd_bwd(buf, gold.int().to(DEV), n_valid, smoothing=smoothing, grad_scale=0.7, dlogits=buf, argmax=ids)
+    assert dl2.data_ptr() == buf.data_ptr()
+    assert torch.equal(ids.cpu().long(), lt.float().argmax(-1)), (ids.cpu(), lt.float().argmax(-1))
+    row3, dl3 = K.xent_fwd_bwd(lt.to(DEV), gold.int().to(DEV), n_valid, smoothing=smoothing, grad_scale=0.7)
+    assert torch.equal(row2, row3) and torch.equal(dl2, dl3)      # the extra output changes nothing else
 
 
 def test_xent_golden(K):
@@ -481,6 +492,11 @@ def test_dec_preprocess_and_embed(K):
         K.embed_bwd(ids.to(DEV).reshape(-1), dy.to(DEV), demb, d ** -0.5)
         refg = torch.zeros(V, d).index_add_(0, ids.long().reshape(-1), dy.float() * d ** -0.5)
         close(demb, refg, rtol=1e-5, atol=1e-5, what="embed bwd")
+        dy2 = torch.randn(B * To, d).to(dtype)      # the gradient as a (projection path, residual path) pair, added in fp32 inside the kernel
+        demb.zero_()
+        K.embed_bwd(ids.to(DEV).reshape(-1), dy.to(DEV), demb, d ** -0.5, dy2=dy2.to(DEV))
+        refg = torch.zeros(V, d).index_add_(0, ids.long().reshape(-1), (dy.float() + dy2.float()) * d ** -0.5)
+        close(demb, refg, rtol=1e-5, atol=1e-5, what="embed bwd of a gradient pair")
 
 
 # ------------------------------------------------------------------------------------ elementwise
