@@ -297,17 +297,41 @@ QUEUE_PROBE = True  # False: take streams as they come (tests of the probe itsel
 _CHAIN_BASE = {}
 
 
-def _chain_ms(streams, n=40, cycles=50000):
-    """Wall time of n short spin kernels (one workgroup, ~20 us each) enqueued on EACH of `streams` at the same time."""
-    import time
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
+def _chain_ms(streams, n=40, cycles=50000, gate_cycles=8_000_000):
+    """GPU time (ms) of n short spin kernels (one workgroup, ~20 us each) queued on EACH of `streams` and started TOGETHER: every stream first
+    waits behind a gate - a long spin (~3 ms) on the first stream - while the host queues the chains, and the time is taken by events on the
+    device, from the gate's end to the last chain's end.  (Round 4 timed the host's wall clock around the enqueue loop: on a slow or busy
+    host - eight ranks starting together, a profiler - the launches of two chains take twice as long to ISSUE as one chain's, which read
+    as a conflict for streams that run side by side.)  If the host did not finish queueing before the gate opened, the gate is lengthened."""
+    for _ in range(4):
+        torch.cuda.synchronize()
+        gate = torch.cuda.Event()
+        with torch.cuda.stream(streams[0]):
+            torch.cuda._sleep(gate_cycles)
+            gate.record()
+        starts, ends = [], []
         for s in streams:
             with torch.cuda.stream(s):
-                torch.cuda._sleep(cycles)
-    torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0)
+                if s is not streams[0]:
+                    s.wait_event(gate)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                starts.append(e0)
+        for _ in range(n):
+            for s in streams:
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(cycles)
+        for s in streams:
+            with torch.cuda.stream(s):
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                ends.append(e1)
+        queued_in_time = not gate.query()      # the gate was still closed when the last launch was queued
+        torch.cuda.synchronize()
+        if queued_in_time:
+            return max(starts[0].elapsed_time(e) for e in ends)
+        gate_cycles *= 4
+    return max(starts[0].elapsed_time(e) for e in ends)      # a host this slow: the last (longest-gate) measurement, for what it is worth
 
 
 def streams_conflict(a, b):
@@ -319,7 +343,10 @@ def streams_conflict(a, b):
     dev = a.device.index
     if dev not in _CHAIN_BASE:
         _CHAIN_BASE[dev] = min(_chain_ms([a]) for _ in range(3))
-    return min(_chain_ms([a, b]) for _ in range(2)) > 1.5 * _CHAIN_BASE[dev]
+    t = _chain_ms([a, b])
+    if t > 1.5 * _CHAIN_BASE[dev]:      # a second look before a stream is rejected (a one-off stall of the box reads as a conflict)
+        t = min(t, _chain_ms([a, b]))
+    return t > 1.5 * _CHAIN_BASE[dev]
 
 
 def pick_stream(device, avoid, factory=None, tries=12):
@@ -332,18 +359,21 @@ def pick_stream(device, avoid, factory=None, tries=12):
     (default: torch's stream pool), each is tested against every stream in `avoid`; rejected candidates stay referenced (their queue then
     counts as used for whatever stream the process creates next)."""
     factory = factory or (lambda: torch.cuda.Stream(device=device))
-    cand = None
+    first, held = None, []
     for _ in range(tries):
         cand = factory()
+        first = first if first is not None else cand
         if not QUEUE_PROBE or torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):      # (_sleep: the spin kernel of the test)
             return cand
         if not any(streams_conflict(a, cand) for a in avoid if a is not None):
+            _HELD.extend(held)      # the rejected candidates stay referenced: their queues count as used for later streams
             return cand
-        _HELD.append(cand)
+        held.append(cand)
+    # EVERY candidate conflicted: more likely the probe failing on this box than twelve unlucky draws - take the first candidate and hold none
     import warnings
     warnings.warn("asr_chinese_e2e_amd: no stream that runs beside the main stream after %d candidates (GPU_MAX_HW_QUEUES too small for the streams "
-                  "of this process?): the multi-stream step may run serialised" % tries)
-    return cand
+                  "of this process, or the probe cannot tell on this box): taking the first candidate; the multi-stream step may run serialised" % tries)
+    return first
 
 
 def steer_stream_pool(device, avoid, ring_max=64):
