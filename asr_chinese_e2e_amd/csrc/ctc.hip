@@ -794,6 +794,10 @@ extern "C" int asr_ctc_fwd_bwd(const void* logits, void* dlogits, const int32_t*
     const int rows = B * T;
     int g1 = ceil_div(rows, 4);
     if (g1 > 4096) g1 = 4096;
+    // tuning option "cu_limit" (> 0 while the CTC branch of the joint model runs beside the decoder's chain of small kernels): the row kernels are
+    // grid-stride loops - size them for that many CUs (8 four-wave workgroups each) instead of flooding every CU with 4096 short workgroups
+    const int cu_lim = asr_option(ASR_OPT_CU_LIMIT);
+    if (cu_lim > 0 && g1 > 8 * cu_lim) g1 = 8 * cu_lim;
     // bf16 rows of whole 16-byte vectors that fit a wave's registers take the row-in-registers kernels
     const int need = ceil_div(V / 8, 64);
     const bool rows_path = dtype == ASR_BF16 && V % 8 == 0 && ld % 8 == 0 && need <= 16 && ((uintptr_t)logits % 16) == 0 && (!dlogits || ((uintptr_t)dlogits % 16) == 0);
