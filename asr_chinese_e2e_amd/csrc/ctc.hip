@@ -22,6 +22,7 @@
 namespace {
 
 constexpr float NEG_INF = -INFINITY;
+typedef __attribute__((ext_vector_type(2))) double f64x2;
 
 template <typename T> struct Vec {
     static constexpr int N = 16 / sizeof(T);  // elements per 16-byte load
@@ -159,8 +160,9 @@ __device__ __forceinline__ int wave_row_argmax_regs(const u32x4 (&xv)[NV], int n
 // ---------------------------------------------------------------------------------- lattice layout
 // The 2L+1 states of the blank-augmented label sequence are kept as two arrays per frame:
 //   blanks  Bk[i] = state 2i     (i = 0..L)        labels  Lb[i] = state 2i+1  (i = 0..L-1)
-// stored as one row of 2W doubles, [Bk 0..W) | Lb 0..W)], W = 32/64/128/256 >= L+1, zero beyond
-// the valid entries.  In this form the recursions need ONE lane shift per step instead of two:
+// stored as one row of 2W doubles, INTERLEAVED: entry i = (Bk[i], Lb[i]) at doubles 2i, 2i+1 (round 5: one 16-byte load / store per
+// lane and frame instead of two 8-byte ones - half the memory instructions the recursion has in flight, so that its prefetch can run
+// three chunks ahead inside the 6-bit vmcnt counter), W = 32/64/128/256 >= L+1, zero beyond the valid entries.  In this form the recursions need ONE lane shift per step instead of two:
 //   alpha: Bk'[i] = yB (Bk[i] + Lb[i-1])          Lb'[i] = yL[i] (Lb[i] + Bk[i]   + c[i]  Lb[i-1])
 //   beta : Bk'[i] = yB (Bk[i] + Lb[i])            Lb'[i] = yL[i] (Lb[i] + Bk[i+1] + c'[i] Lb[i+1])
 // with c[i] = lab[i] != lab[i-1], c'[i] = lab[i] != lab[i+1] (the skip transitions).
@@ -183,9 +185,9 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const T* __restrict
         double* out = lp + (size_t)row * 2 * W;
         const double yb = exp((double)(to_f32<T>(x[blank]) - lse));   // y_t(blank): linear domain, fp64
         for (int i = lane; i < W; i += 64) {   // zero beyond the valid entries: the recursion runs unpredicated
-            out[i] = i <= L ? yb : 0.0;
             const int c = labels[(size_t)b * Lmax + min(i, Lmax - 1)];
-            out[W + i] = i < L ? exp((double)(to_f32<T>(x[c]) - lse)) : 0.0;
+            const f64x2 e = {i <= L ? yb : 0.0, i < L ? exp((double)(to_f32<T>(x[c]) - lse)) : 0.0};
+            *(f64x2*)(out + 2 * i) = e;
         }
     }
 }
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_rows_kernel(const bf16_t* 
         for (int j = 0; j < 4; ++j) {
             const int i = lane + 64 * j;
             if (i < W) {   // zero beyond the valid entries: the recursion runs unpredicated
-                out[i] = i <= L ? yb : 0.0;
-                out[W + i] = i < L ? exp((double)(xl[j] - lse)) : 0.0;
+                const f64x2 e = {i <= L ? yb : 0.0, i < L ? exp((double)(xl[j] - lse)) : 0.0};
+                *(f64x2*)(out + 2 * i) = e;
             }
         }
     }
@@ -330,48 +332,49 @@ __device__ __forceinline__ double ctc_recursion(const double* __restrict__ y, do
         else c = i + 1 < L && lab[i] != lab[i + 1];
         skip[j] = c ? 1.0 : 0.0;
     }
-    const double* yp = y + (BWD ? (size_t)(Tb - 1) * RW : 0) + lane;   // step 0
-    double* op = out + (BWD ? (size_t)(Tb - 1) * RW : 0) + lane;
+    // entry i = lane + 64 j of a row sits at doubles 2 i (blank), 2 i + 1 (label): one 16-byte access per lane and register
+    const double* yp = y + (BWD ? (size_t)(Tb - 1) * RW : 0) + 2 * lane;   // step 0
+    double* op = out + (BWD ? (size_t)(Tb - 1) * RW : 0) + 2 * lane;
     double bk[NS], lb[NS];
     // step 0: the two entry states (alpha: Bk[0], Lb[0]; beta: Bk[L], Lb[L-1])
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const int i = lane + 64 * j;
-        bk[j] = (BWD ? i == L : i == 0) ? yp[64 * j] : 0.0;
-        lb[j] = (BWD ? i == L - 1 : i == 0) ? yp[W + 64 * j] : 0.0;
-        op[64 * j] = bk[j];
-        op[W + 64 * j] = lb[j];
+        const f64x2 y0 = *(const f64x2*)(yp + 128 * j);
+        bk[j] = (BWD ? i == L : i == 0) ? y0[0] : 0.0;
+        lb[j] = (BWD ? i == L - 1 : i == 0) ? y0[1] : 0.0;
+        const f64x2 o0 = {bk[j], lb[j]};
+        *(f64x2*)(op + 128 * j) = o0;
     }
     constexpr int CH = 8;  // steps per prefetch chunk; chunk c covers steps 1 + c*CH .. c*CH + CH
+    // Prefetch depth.  The recursion is a dependent chain of ~25 ns per frame; a lattice row comes from memory (written by the kernel before
+    // this one) in ~0.7 us.  With two chunk buffers (round 1 - 4) the chunk after the current one was requested one chunk = 8 frames earlier
+    // and every chunk ended in a wait for memory: 88 ns per frame.  NB buffers = NB - 1 chunks in flight; memory instructions per chunk =
+    // CH loads + CH stores (16-byte accesses), so three chunks in flight stay inside the 6-bit vmcnt counter (stores count too on gfx950).
+    constexpr int NB = NS == 1 ? 4 : 2;
     const int nsteps = Tb - 1;            // recursion steps 1 .. Tb-1
-    struct Chunk { double b[CH][NS], l[CH][NS]; };
-    Chunk c0, c1;
+    struct Chunk { f64x2 v[CH][NS]; };
+    Chunk q[NB];
     auto fetch = [&](Chunk& d, const double* p) {   // p = row of the chunk's first step
 #pragma unroll
         for (int k = 0; k < CH; ++k)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                d.b[k][j] = p[k * DT + 64 * j];
-                d.l[k][j] = p[k * DT + W + 64 * j];
-            }
+            for (int j = 0; j < NS; ++j) d.v[k][j] = *(const f64x2*)(p + k * DT + 128 * j);
     };
     auto fetch_clamped = [&](Chunk& d, int chunk) {   // rows past the last frame are clamped to it (never used)
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int step = min(1 + chunk * CH + k, nsteps);
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                d.b[k][j] = yp[(ptrdiff_t)step * DT + 64 * j];
-                d.l[k][j] = yp[(ptrdiff_t)step * DT + W + 64 * j];
-            }
+            for (int j = 0; j < NS; ++j) d.v[k][j] = *(const f64x2*)(yp + (ptrdiff_t)step * DT + 128 * j);
         }
     };
     double sc = 1.0;   // power-of-two scale waiting to be applied
     int e_pending = 0;
-    auto one_step = [&](const double (&ybk)[NS], const double (&ylk)[NS], double* o, int k) {
+    auto one_step = [&](const f64x2 (&yv)[NS], double* o, int k) {
         double yb[NS], yl[NS];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) { yb[j] = ybk[j]; yl[j] = ylk[j]; }
+        for (int j = 0; j < NS; ++j) { yb[j] = yv[j][0]; yl[j] = yv[j][1]; }
         if ((k & 3) == 1) {   // apply the scale found two steps ago: off the chain, it multiplies y
 #pragma unroll
             for (int j = 0; j < NS; ++j) { yb[j] *= sc; yl[j] *= sc; }
@@ -417,36 +420,38 @@ __device__ __forceinline__ double ctc_recursion(const double* __restrict__ y, do
         }
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            o[64 * j] = bk[j];
-            o[W + 64 * j] = lb[j];
+            const f64x2 ov = {bk[j], lb[j]};
+            *(f64x2*)(o + 128 * j) = ov;
         }
     };
     const int nfull = nsteps / CH;
     int c = 0;
-    fetch_clamped(c0, 0);
+#pragma unroll
+    for (int i = 0; i < NB - 1; ++i) fetch_clamped(q[i], i);      // q[i] = chunk c + i for i < NB - 1
     const double* yq = yp + DT;   // row of step 1 + c*CH
     double* oq = op + DT;
-    // steady state: chunks c+1 and c+2 are full, every access unconditional
-    for (; c + 3 <= nfull; c += 2) {
-        fetch(c1, yq + CH * DT);
+    // steady state: the chunks requested in an iteration (c + NB - 1 .. c + 2 NB - 2) are full, every access unconditional
+    for (; c + 2 * NB - 1 <= nfull; c += NB) {
 #pragma unroll
-        for (int k = 0; k < CH; ++k) one_step(c0.b[k], c0.l[k], oq + k * DT, k);
-        fetch(c0, yq + 2 * CH * DT);
+        for (int i = 0; i < NB; ++i) {
+            fetch(q[(i + NB - 1) % NB], yq + (i + NB - 1) * CH * DT);
 #pragma unroll
-        for (int k = 0; k < CH; ++k) one_step(c1.b[k], c1.l[k], oq + (CH + k) * DT, k);
-        yq += 2 * CH * DT;
-        oq += 2 * CH * DT;
+            for (int k = 0; k < CH; ++k) one_step(q[i].v[k], oq + (i * CH + k) * DT, k);
+        }
+        yq += NB * CH * DT;
+        oq += NB * CH * DT;
     }
-    // the last (at most three full and one partial) chunks; c0 holds chunk c
+    // the last chunks (fewer than 2 NB, the last one possibly partial); q[0 .. NB-2] hold chunks c .. c + NB - 2
     for (; c * CH < nsteps; ++c) {
-        fetch_clamped(c1, c + 1);
+        fetch_clamped(q[NB - 1], c + NB - 1);
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             if (1 + c * CH + k > nsteps) break;
-            one_step(c0.b[k], c0.l[k], oq + k * DT, k);
+            one_step(q[0].v[k], oq + k * DT, k);
         }
         oq += CH * DT;
-        c0 = c1;
+#pragma unroll
+        for (int i = 0; i + 1 < NB; ++i) q[i] = q[i + 1];
     }
     return dead ? -INFINITY : (double)esum * 0.6931471805599453;
 }
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const double* __res
             nll = (L == 0) ? 0.f : INFINITY;
         } else {
             const double* last = ab + (size_t)(Tb - 1) * RW;
-            const double tail = last[L] + (L > 0 ? last[W + L - 1] : 0.0);
+            const double tail = last[2 * L] + (L > 0 ? last[2 * (L - 1) + 1] : 0.0);      // interleaved rows: (blank, label) pairs
             nll = (tail > 0.0 && s_logc != -INFINITY) ? (float)(-(s_logc + log(tail))) : INFINITY;
         }
         nll_raw[b] = nll;
@@ -529,9 +534,9 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
             const size_t o = (size_t)row * 2 * W;
             double sum_b = 0.0, sum_l = 0.0;
             for (int i = threadIdx.x; i <= L; i += 64) {
-                const double yb = lp[o + i], yl = lp[o + W + i];
-                sum_b += yb > 0.0 ? alpha[o + i] * beta[o + i] / yb : 0.0;
-                sum_l += (i < L && yl > 0.0) ? alpha[o + W + i] * beta[o + W + i] / yl : 0.0;
+                const double yb = lp[o + 2 * i], yl = lp[o + 2 * i + 1];
+                sum_b += yb > 0.0 ? alpha[o + 2 * i] * beta[o + 2 * i] / yb : 0.0;
+                sum_l += (i < L && yl > 0.0) ? alpha[o + 2 * i + 1] * beta[o + 2 * i + 1] / yl : 0.0;
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -544,13 +549,13 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                 if (det) {   // repeated labels share a class: add their states in label order (fixed order)
                     if (threadIdx.x == 0)
                         for (int i = 0; i < L; ++i) {
-                            const double yl = lp[o + W + i];
-                            if (yl > 0.0) occ[labels[(size_t)b * Lmax + i]] += (float)(alpha[o + W + i] * beta[o + W + i] / yl / sum);
+                            const double yl = lp[o + 2 * i + 1];
+                            if (yl > 0.0) occ[labels[(size_t)b * Lmax + i]] += (float)(alpha[o + 2 * i + 1] * beta[o + 2 * i + 1] / yl / sum);
                         }
                 } else
                 for (int i = threadIdx.x; i < L; i += 64) {
-                    const double yl = lp[o + W + i];
-                    if (yl > 0.0) atomicAdd(&occ[labels[(size_t)b * Lmax + i]], (float)(alpha[o + W + i] * beta[o + W + i] / yl / sum));
+                    const double yl = lp[o + 2 * i + 1];
+                    if (yl > 0.0) atomicAdd(&occ[labels[(size_t)b * Lmax + i]], (float)(alpha[o + 2 * i + 1] * beta[o + 2 * i + 1] / yl / sum));
                 }
             }
         }
@@ -605,11 +610,12 @@ __global__ __launch_bounds__(256) void ctc_label_fix_kernel(bf16_t* __restrict__
             yl[j] = 0.0;
             lab[j] = -1;
             if (i <= L && i < W) {
-                const double yb = lp[o + i];
-                pb += yb > 0.0 ? alpha[o + i] * beta[o + i] / yb : 0.0;
+                // entry i = (blank, label) pair: one 16-byte load per array
+                const f64x2 yv = *(const f64x2*)(lp + o + 2 * i), av = *(const f64x2*)(alpha + o + 2 * i), bv = *(const f64x2*)(beta + o + 2 * i);
+                pb += yv[0] > 0.0 ? av[0] * bv[0] / yv[0] : 0.0;
                 if (i < L) {
-                    yl[j] = lp[o + W + i];
-                    pl[j] = yl[j] > 0.0 ? alpha[o + W + i] * beta[o + W + i] / yl[j] : 0.0;
+                    yl[j] = yv[1];
+                    pl[j] = yl[j] > 0.0 ? av[1] * bv[1] / yl[j] : 0.0;
                     lab[j] = labels[(size_t)b * Lmax + i];
                 }
             }
