@@ -157,8 +157,23 @@ def pmc_traffic(family):
     return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n if n else None
 
 
+def profiled_in_step_us(family, workload):
+    """(launches per step, average us per launch, file) of a GEMM family in the committed rocprofv3 --kernel-trace summary of THIS command
+    (profiles/round5_[ctc_]kernel_stats_per_step.csv, written by tools/profile_round.sh): the cross-check of the live HIP-event figure.  Events on a
+    stream also see what the launch waits for in front of its first workgroup, so they read 10 - 20 % above the trace's kernel durations."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "round5_ctc_kernel_stats_per_step.csv" if workload == "ctc" else "round5_kernel_stats_per_step.csv")
+    try:
+        rows = [r for r in csv.DictReader(open(path)) if r["Name"].startswith(family + "_")]
+    except OSError:
+        return None
+    n = sum(float(r["CallsPerStep"]) for r in rows)
+    tot = sum(float(r["TotalUsPerStep"]) for r in rows)
+    return (n, tot / n, os.path.relpath(path, ROOT)) if n else None
+
+
 MATRIX_FAMILIES = ("gemm_nt", "gemm_tn", "sdpa_fwd", "sdpa_bwd")
-KERNEL_NAMES = {"gemm_nt": "gemm_nt_spec_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16)",
+KERNEL_NAMES = {"gemm_nt": "gemm_nt_spec_kernel (asr_gemm_nt_bf16)", "gemm_tn": "gemm_tn_dma_kernel (asr_gemm_tn_bf16) + gemm_tn_grouped_kernel (the decoder layers' grouped launches)",
                 "sdpa_fwd": "sdpa_fwd_fused_bf16_kernel (asr_sdpa_fwd)",
                 "sdpa_bwd": "sdpa_bwd_fused_bf16_kernel (asr_sdpa_bwd)", "add_ln_fwd": "add_ln_fwd_kernel", "add_ln_bwd": "add_ln_bwd_kernel",
                 "ctc": "ctc_lse_gather_rows + ctc_alpha_beta + ctc_label_fix (asr_ctc_fwd_bwd)", "xent": "xent_kernel", "adam": "adam_kernel (asr_adam_step)",
@@ -260,6 +275,7 @@ class Run:
         self.gc_passes = [p for p in passes if p[0] >= 1 or p[1] >= 1.0]      # young-generation passes of microseconds are not worth a line
         gc.unfreeze()
         self.alloc_growth = torch.cuda.memory_stats().get("num_device_alloc", 0) - a0
+        self.peak_gb = torch.cuda.max_memory_allocated() / 1e9      # peak of live tensors so far in this process (the engine keeps side-stream operands alive until the step's join)
         if self.alloc_growth:
             log(f"{self.alloc_growth} device allocation(s) INSIDE the timed region ({'joint' if self.joint else 'ctc'} model, {warmup} warm-up steps)")
             if strict:
@@ -428,6 +444,7 @@ def main():
     log(f"rank {rank}/{world}: {config} model on {dev}, warm-up {args.warmup} steps")
     dt = run.timed(args.warmup, args.steps, strict=(world == 1))      # N > 1 has never run on xGMI: count and report, do not end the run
     alloc_growth = run.alloc_growth
+    headline_peak = run.peak_gb
     headline_chunks = run.chunk_ms
     headline_gc = run.gc_passes
     log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
@@ -480,9 +497,10 @@ def main():
         del run
         gc.collect()
         es, ew = max(10, min(args.steps, 50)), max(10, min(args.warmup, 15))
-        extras_alloc, extras_chunks, extras_gc = {}, {}, {}
+        extras_alloc, extras_chunks, extras_gc, extras_peak = {}, {}, {}, {}
 
         def extra(key, cfg_name, dropout, batch=None, frames=None, window=None, kernels=False):
+            torch.cuda.reset_peak_memory_stats()
             r = Run(args, cfg_name, dropout, rank, dev, False, batch=batch, frames=frames, window=window)
             d = r.timed(ew, es)
             extras[f"{key}_ms_per_step"] = 1e3 * d / es
@@ -492,6 +510,7 @@ def main():
                 extras[f"{key}_kernels"] = {k: {"avg_us": v["avg_us"], "launches_per_step": v["launches"] / min(es, 5)}
                                             for k, v in ks.items() if k in ("sdpa_fwd", "sdpa_bwd", "ctc", "gemm_nt", "gemm_tn")}
             extras_alloc[key], extras_chunks[key], extras_gc[key] = r.alloc_growth, r.chunk_ms, r.gc_passes
+            extras_peak[key] = round(r.peak_gb, 2)
             del r
             gc.collect()
 
@@ -515,6 +534,9 @@ def main():
         extras["allocator_growth_in_timed_regions"] = dict(extras_alloc, headline=alloc_growth)
         extras["ms_per_step_by_fifth_of_each_timed_region"] = dict(extras_chunks, headline=headline_chunks)
         extras["collector_passes_in_timed_regions"] = dict(extras_gc, headline=headline_gc)      # (generation, ms) each; [] = none
+        # live-tensor peak (GB) while each configuration ran (torch.cuda.max_memory_allocated, reset per configuration): includes the operands of side-stream
+        # kernels that the engine holds until the step's join instead of marking them with Tensor.record_stream
+        extras["peak_memory_allocated_gb"] = dict(extras_peak, headline=round(headline_peak, 2))
         log(f"extras: {extras}")
 
     if rank == 0:
@@ -557,7 +579,13 @@ def main():
             def roof(k):
                 a = fam[k]["work_per_s"] / 1e12
                 alone = summary[k]["work_per_s"] / 1e12 if k in summary else None
+                prof = profiled_in_step_us(k, config)
+                prof_obj = None
+                if prof:      # the same algorithmic FLOP over the committed trace's in-step kernel durations
+                    prof_tf = fam[k]["work_per_launch"] * fam[k]["launches"] / n_inst / (prof[0] * prof[1] * 1e-6) / 1e12
+                    prof_obj = {"file": prof[2], "launches_per_step": prof[0], "avg_launch_us": prof[1], "frac": prof_tf / MFMA_BF16_PEAK_TFLOPS}
                 return {"bound": "mfma", "kernel": KERNEL_NAMES[k], "achieved": a, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_BF16_PEAK_TFLOPS,
+                        "committed_rocprofv3_trace": prof_obj,
                         "condition": "in the step: HIP events on the launch stream with the weight-gradient / auxiliary streams live, as in the timed region" if in_step else
                                      "stand-alone (weight-gradient overlap off)",
                         "frac_standalone": None if alone is None else alone / MFMA_BF16_PEAK_TFLOPS,
