@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 void asr_set_error(const char* fmt, ...);
 int asr_deterministic(void);   // 1: fixed-order reductions everywhere (asr_set_deterministic / ASR_DETERMINISTIC=1)
 // tuning options (asr_set_option, misc.hip): every value of every option gives correct results
-enum { ASR_OPT_CU_LIMIT = 0, ASR_OPT_TN_MULTI = 1, ASR_OPT_COUNT = 2 };
+enum { ASR_OPT_CU_LIMIT = 0, ASR_OPT_TN_MULTI = 1, ASR_OPT_SDPA_PAIR = 2, ASR_OPT_COUNT = 3 };
 int asr_option(int key);
 int asr_option_set(int key, int value);      // returns the previous value (library-internal callers: decoder_exec.hip)
 #define ASR_FAIL(code, ...)        \

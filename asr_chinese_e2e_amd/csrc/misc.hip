@@ -38,8 +38,10 @@ extern "C" int asr_set_deterministic(int on) {
 // "cu_limit" (gemm.hip: cu_count); the kernel-variant switches of rounds 2 - 3 left with the variants.
 // "tn_multi" (round 5; default 1): asr_gemm_tn_grouped_bf16 runs problems over the same >= 4096 rows on the 128 x 128-tile kernel (one launch,
 // fewer M-splits); 0 = the 256 x 128-tile grouped kernel for every group (A/B timing inside one process).
-static const char* const g_opt_names[ASR_OPT_COUNT] = {"cu_limit", "tn_multi"};
-static int g_opt_val[ASR_OPT_COUNT] = {0, 1};
+// "sdpa_pair" (round 5; default 0): 1 = the attention forward without causal / band mask and without dropout on the kernel that takes both 32-query
+// blocks of a wave through ONE pass over the key tiles (sdpa_fwd_pair_bf16_kernel: bit-identical results, measured 33.5 vs 31.6 us - opt-in).
+static const char* const g_opt_names[ASR_OPT_COUNT] = {"cu_limit", "tn_multi", "sdpa_pair"};
+static int g_opt_val[ASR_OPT_COUNT] = {0, 1, 0};
 static void opt_init() {}
 int asr_option(int key) {
     opt_init();

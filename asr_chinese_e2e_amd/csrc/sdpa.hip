@@ -764,6 +764,195 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
     }
 }
 
+// ---------------------------------------------------------------- forward, both 32-query blocks of a wave in ONE pass over the key tiles (round 5)
+// sdpa_fwd_fused_bf16_kernel walks the key tiles twice per wave: its first 32-query block consumes the K / V stream (and waits for it), its
+// second block re-reads every K and V fragment from LDS.  Here a wave takes a tile's K fragments ONCE for the scores of both blocks and its V
+// fragments once for both P V products: half the LDS fragment reads per score element (the loop is vector-issue bound, and an LDS read costs an
+// issue slot like any vector instruction), and the stream hides behind twice the arithmetic per tile.  Same image layout, same DMA ring, same
+// arithmetic per element (exp2 domain, row sums on the matrix pipe, rescale only when the maximum moved by > 2^8) - the two kernels agree to
+// rounding of the order of accumulation only.  Key-length masking only (no causal / band, no dropout: those take the kernel above).
+// Registers: Q fragments 32, O accumulators 64, row sums 32, scores 64, V fragments of one 32-key half 16, K fragments 32 (dead before the
+// softmax): 247 at the peak, no scratch - K fragments are NOT prefetched a tile ahead here (no room).
+// MEASURED (tools/sdpa_pair_ab.py, one process): bit-identical outputs and lse, and SLOWER - 33.5 vs 31.6 us at (32, 8, 500, 500), 30.0 vs 29.4 ragged,
+// 12.1 vs 10.9 at the decoder's cross-attention shape, 20.5 vs 20.9 at (8, 8, 333, 470): what the shared fragment reads save is lost to a loop body
+// whose 64 exponentials sit between two blocks of 16 - 24 MFMAs as the compiler schedules it (the two-pass kernel's shorter phases interleave
+// better across the two waves of a SIMD).  Opt-in (tuning option "sdpa_pair"); a hand-placed schedule of this body is the open lever.
+__global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_pair_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                        bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
+                                                                        int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float scale) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_ff[];
+    const char* Kimg = smem_ff;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
+    const bf16_t* kb = k + (size_t)b * Tk * ldk + h * DK;
+    const bf16_t* vb = v + (size_t)b * Tk * ldv + h * DK;
+    const int klen = min(k_len ? k_len[b] : Tk, Tk);
+    const int ntile = (klen + TILE - 1) / TILE;
+    const float sc2 = scale * LOG2E;
+    bf16_t* ob = o + (size_t)b * Tq * ldo + h * DK;
+
+    bf16x8 qf[2][4];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_ff;
+    const int r8 = 8 * w + (lane >> 3), c8 = 8 * ((lane & 7) ^ ff_swz(r8));
+    auto dma_tile = [&](int t) {
+        const int rc = min(TILE * t + r8, klen - 1);
+        const bf16_t* sk = kb + (size_t)rc * ldk + c8;
+        const bf16_t* sv = vb + (size_t)rc * ldv + c8;
+        const unsigned dk_ = __builtin_amdgcn_readfirstlane(lds0 + (TILE * t + 8 * w) * 128), dv_ = dk_ + FF_IMG;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sk), "s"(dk_) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(sv), "s"(dv_) : "memory");
+    };
+    constexpr int FF_AHEAD = 3;
+    if (ntile > 0) dma_tile(0);
+    frags_from_global(qf[0], qb, ldq, 64 * w, Tq, lane);
+    frags_from_global(qf[1], qb, ldq, 64 * w + 32, Tq, lane);
+    asm volatile("; Q fragments landed" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3])::"memory");
+    for (int t = 1; t < min(ntile, FF_AHEAD + 1); ++t) dma_tile(t);
+    int kofs[4], vofs[2][2];
+    {
+        const int r = lane & 31, hh = lane >> 5, f = ff_swz(r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kofs[ks] = r * 128 + (((2 * ks + hh) ^ f) << 4);
+        const int G = lane >> 4, i = lane & 15, rv = 4 * (G >> 1) + (i >> 2);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int chunk = 4 * db + 2 * (G & 1) + ((i & 3) >> 1);
+                vofs[db][hi] = FF_IMG + (rv + 8 * hi) * 128 + ((chunk ^ ff_swz(rv + 8 * hi)) << 4) + 8 * (i & 1);
+            }
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+
+    bool streamed = false;
+    for (int qc = 0; qc < Tq; qc += 64 * 8) {
+        const int q0 = qc + 64 * w;                     // block 0: q0 .. q0 + 31, block 1: q0 + 32 .. q0 + 63
+        const bool stream = !streamed;
+        if (streamed) {
+            if (q0 >= Tq) break;
+            frags_from_global(qf[0], qb, ldq, q0, Tq, lane);
+            frags_from_global(qf[1], qb, ldq, q0 + 32, Tq, lane);
+        }
+        const bool act0 = q0 < Tq, act1 = q0 + 32 < Tq;      // wave-uniform; an idle wave of the first pass still keeps the rendezvous
+        f32x16 oacc[2][2], lacc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][0][i] = 0.f; oacc[0][1][i] = 0.f; oacc[1][0][i] = 0.f; oacc[1][1][i] = 0.f; lacc[0][i] = 0.f; lacc[1][i] = 0.f; }
+        float m[2] = {M_INIT, M_INIT};
+        for (int t = 0; t < ntile; ++t) {
+            const int k0 = t * TILE;
+            if (stream) {
+                if ((t & 1) == 0) {      // tiles t and t+1 must have landed; t+2 and t+3 may be in flight; t+4, t+5 go out
+                    ff_wait_tiles(min(2, max(0, ntile - 2 - t)));
+                    __syncthreads();
+                    if (t + 4 < ntile) dma_tile(t + 4);
+                    if (t + 5 < ntile) dma_tile(t + 5);
+                }
+                if (!act0) continue;
+            }
+            // ---- scores of both blocks from ONE read of the tile's K fragments
+            f32x16 st[2][2];      // [block][32-key half]
+            {
+                bf16x8 kf[2][4];
+                const char* kpt = Kimg + t * (TILE * 128);
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) kf[sub][ks] = *(const bf16x8*)(kpt + kofs[ks] + sub * 4096);
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { st[0][sub][i] = 0.f; st[1][sub][i] = 0.f; }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        st[0][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[0][ks], st[0][sub], 0, 0, 0);
+                        if (act1) st[1][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][ks], qf[1][ks], st[1][sub], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool edge = k0 + TILE > klen;
+            if (edge) {      // key-length mask: one compare per element
+                const int lim = klen - k0 - 4 * (lane >> 5);
+#pragma unroll
+                for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (32 * sub + (i & 3) + 8 * (i >> 2) >= lim) st[bk][sub][i] = -INFINITY;
+            }
+            // ---- softmax of each block (lane = query): running maximum, deferred rescale, exp2
+#pragma unroll
+            for (int bk = 0; bk < 2; ++bk) {
+                if (bk == 1 && !act1) break;
+                float tmax = M_INIT;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, st[bk][sub][i]);
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                    tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
+                if (__builtin_amdgcn_ballot_w64((tmax - m[bk]) * sc2 > 8.f) != 0) {      // wave-uniform
+                    const float mn = fmaxf(m[bk], tmax);
+                    const float alpha = __builtin_amdgcn_exp2f((m[bk] - mn) * sc2);
+                    m[bk] = mn;
+                    lacc[bk][0] *= alpha;      // every register of lacc holds the same sum; only [0] is read
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { oacc[bk][0][i] *= alpha; oacc[bk][1][i] *= alpha; }
+                }
+                const float mc = m[bk] * sc2;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[bk][sub][i] = __builtin_amdgcn_exp2f(fmaf(st[bk][sub][i], sc2, -mc));
+            }
+            // ---- O^T += V^T P^T for both blocks from ONE read of the tile's V fragments (a 32-key half at a time)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                bf16x8 vf[2][2];      // [16-key step][d half]
+                const char* vpt = Kimg + k0 * 128;      // vofs carries the V image offset
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vpt + vofs[db][0] + (32 * sub + 16 * s2) * 128));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vpt + vofs[db][1] + (32 * sub + 16 * s2) * 128));
+                        vf[s2][db] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 p0 = acc_to_frag(st[0][sub], s2);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) oacc[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][db], p0, oacc[0][db], 0, 0, 0);
+                    lacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p0, lacc[0], 0, 0, 0);
+                    if (act1) {
+                        const bf16x8 p1 = acc_to_frag(st[1][sub], s2);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) oacc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][db], p1, oacc[1][db], 0, 0, 0);
+                        lacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p1, lacc[1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        streamed = true;
+        if (!act0) break;
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk) {
+            if (bk == 1 && !act1) break;
+            const int qs = q0 + 32 * bk, qi = qs + (lane & 31);
+            const float l = lacc[bk][0];
+            const float inv = l > 0.f ? 1.f / l : 0.f;
+            store_rows_T(oacc[bk], inv, ob, ldo, qs, Tq, lane);
+            if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m[bk] * sc2 + log2f(l)) * LN2 : -INFINITY;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- backward: ONE kernel per (b, h)
 // The dQ + dK/dV pair above reads Q, K, V, dO twice and computes S and dP twice (7 products, 2 exp passes; PMC traffic
 // 1.52 x the algorithmic bytes).  When all keys of a head fit one workgroup (Tk <= 512: every encoder / decoder shape of
@@ -1370,6 +1559,7 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_fused_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_fwd_pair_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             attr = true;
         }
 #define FF_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
@@ -1377,6 +1567,7 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
         if (dthr && masked) sdpa_fwd_fused_bf16_kernel<true, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (dthr) sdpa_fwd_fused_bf16_kernel<true, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (masked) sdpa_fwd_fused_bf16_kernel<false, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
+        else if (asr_option(ASR_OPT_SDPA_PAIR)) sdpa_fwd_pair_bf16_kernel<<<B * H, FF_THREADS, FF_LDS, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, scale);
         else sdpa_fwd_fused_bf16_kernel<false, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
 #undef FF_ARGS
     } else if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o)) {

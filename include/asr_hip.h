@@ -84,6 +84,8 @@ int asr_stream_create(int priority, void** out_stream);
  * that lost their A/B left the library, see DESIGN.md section 4 "Tried".)  Initial value 0.
  * "tn_multi" (round 5; initial value 1): asr_gemm_tn_grouped_bf16 runs a group of problems over the same >= 4096 rows on the 128 x 128-tile
  * code of the single-problem kernel in one launch; 0 = always the 256 x 128-tile grouped kernel (A/B timing).
+ * "sdpa_pair" (round 5; initial value 0): 1 = asr_sdpa_fwd without causal / band mask and without dropout on the kernel that takes both 32-query
+ * blocks of a wave through one pass over the key tiles (same bits; measured slower, kept for A/B).
  * previous (may be NULL) receives the old value.  Unknown name: ASR_EINVAL. */
 int asr_set_option(const char* name, int value, int* previous);
 int asr_get_deterministic(void);

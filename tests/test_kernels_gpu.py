@@ -459,6 +459,24 @@ def test_xent_golden(K):
         assert abs(float(row.sum() / n_valid) - float(z[key])) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,ragged", [(4, 8, 500, 500, True), (3, 2, 17, 500, False), (2, 8, 333, 470, True), (2, 4, 600, 200, True)])
+def test_sdpa_fwd_pair_kernel_matches_two_pass_kernel(K, B, H, Tq, Tk, ragged):
+    """Tuning option "sdpa_pair": both 32-query blocks of a wave in one pass over the key tiles - the same arithmetic per element in the same
+    order as the two-pass kernel: outputs and log-sum-exp are bit-identical (partial last query block, more than 512 queries, ragged key lengths)."""
+    torch.manual_seed(B + Tq)
+    d = H * 64
+    q, k, v = (torch.randn(B * T_, d, device=DEV).bfloat16() for T_ in (Tq, Tk, Tk))
+    klen = torch.randint(max(1, Tk // 3), Tk + 1, (B,), dtype=torch.int32, device=DEV) if ragged else torch.full((B,), Tk, dtype=torch.int32, device=DEV)
+    out = {}
+    for mode in (0, 1):
+        prev = K.set_option("sdpa_pair", mode)
+        try:
+            out[mode] = K.sdpa_fwd(q, k, v, klen, B, H, Tq, Tk, 64, False, -1)
+        finally:
+            K.set_option("sdpa_pair", prev)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 # ------------------------------------------------------------------------------------ decoder glue
 def test_dec_preprocess_and_embed(K):
     for case in ("model_small_ragged.npz", "model_small_full.npz"):
