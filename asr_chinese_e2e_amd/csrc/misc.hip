@@ -506,10 +506,55 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* __
     }
 }
 
+// The same with 16-byte global accesses (round 5: the element-wise form above moves the step's 100 MB of weight copies at 1.9 TB/s, beside the
+// first kernels of the forward pass): rows of the source tile arrive as 16-byte pieces, the tile turns in LDS, rows of the copy leave as
+// 16-byte pieces.  Per tile, falls back to element accesses when the matrix, its offsets or the copy's row stride are not multiples of 8
+// elements (tile-uniform branch).
+__global__ __launch_bounds__(256) void transpose_batched_vec_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int32_t* __restrict__ tiles) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];      // 144-byte rows: 16-byte pieces stay aligned
+    const int32_t* e = tiles + 6 * (size_t)blockIdx.x;
+    const size_t off = (size_t)(uint32_t)e[0], doff = (size_t)(uint32_t)e[4];
+    const int N = e[1], K = e[2], r0 = (e[3] >> 16) * 64, c0 = (e[3] & 0xffff) * 64, ldd = e[5];
+    const bool vec = ((N | K | ldd) % 8 == 0) && (off % 8 == 0) && (doff % 8 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = threadIdx.x + 256 * c, r = id >> 3, ch = id & 7;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r0 + r < N && c0 + ch * 8 < K) v = *(const u32x4*)(src + off + (size_t)(r0 + r) * K + c0 + ch * 8);
+            *(u32x4*)(&tile[r][ch * 8]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = threadIdx.x + 256 * c, kk = id >> 3, ch = id & 7;      // row kk of the copy = column c0 + kk of the source
+            if (c0 + kk < K && r0 + ch * 8 < N) {
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][kk];
+                *(bf16x8*)(dst + doff + (size_t)(c0 + kk) * ldd + r0 + ch * 8) = v;
+            }
+        }
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        if (r < N && c < K) tile[ty + 4 * i][tx] = src[off + (size_t)r * K + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (r < N && c < K) dst[doff + (size_t)c * ldd + r] = tile[tx][ty + 4 * i];
+    }
+}
+
 extern "C" int asr_transpose_batched_bf16(const void* src, void* dst, const int32_t* tiles, int ntiles, void* stream) {
     if (!src || !dst || !tiles) ASR_FAIL(ASR_EINVAL, "asr_transpose_batched_bf16: null pointer");
     if (ntiles <= 0) ASR_FAIL(ASR_EINVAL, "asr_transpose_batched_bf16: ntiles=%d", ntiles);
-    transpose_batched_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)dst, tiles);
+    transpose_batched_vec_kernel<<<ntiles, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)dst, tiles);
     ASR_CHECK_LAUNCH("asr_transpose_batched_bf16");
     return ASR_OK;
 }
