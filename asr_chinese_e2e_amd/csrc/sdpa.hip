@@ -985,6 +985,7 @@ constexpr int FB_DS_BYTES = FB_KEYS * FB_QT * 2;              // 32768 per buffe
 constexpr int FB_TILE_ELEMS = FB_QT * FBS;
 constexpr int FB_STATS = (2 * 64 + 32) * 4;                   // [2 buffers][-lse log2e (32) | -delta (32)] + a row of -1e30
 constexpr int FB_LDS = FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2 + FB_STATS;   // 148096 B
+constexpr int FB_VIMG_BYTES = 64 * FBS * 2;                   // + V of <= 64 keys for the short causal heads' delta pass
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
@@ -1033,6 +1034,15 @@ __device__ __forceinline__ bf16x8 frag_tr16(const bf16_t* img, int row0, int col
 __device__ __forceinline__ uint32_t scale_bf16_pair(uint32_t x, float f) {
     const bf16_t lo = (bf16_t)(__uint_as_float(x << 16) * f), hi = (bf16_t)(__uint_as_float(x & 0xffff0000u) * f);
     return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+// sum over the 16 lanes of a DPP row, in every lane of the row: four DPP adds, no LDS
+__device__ __forceinline__ float row_sum_dpp(float v) {
+    v += wave_dpp<0xB1>(v);             // quad_perm [1,0,3,2]
+    v += wave_dpp<0x4E>(v);             // quad_perm [2,3,0,1]
+    v += wave_dpp<0x141>(v);            // row_half_mirror
+    v += wave_dpp<0x140>(v);            // row_mirror
+    return v;
 }
 
 template <bool DROP, bool MASKED, bool BAND = false>
@@ -1085,6 +1095,14 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     }
     for (int c = tid; c < 2 * FB_DS_BYTES / 16; c += FB_THREADS) *(u32x4*)((char*)dSimg + c * 16) = zero4;      // under the loads' latency
     if (tid < 32) s_neg[tid] = -1.0e30f;
+    bf16_t* Vimg = (bf16_t*)(smem_fb + FB_LDS);      // short causal heads only (FB_VIMG_BYTES more LDS in that launch): V of the 64 keys, laid out as K's image
+    if constexpr (!DROP && MASKED && !BAND) {
+        if (Tk <= 64) {
+            const int row = tid >> 3, ch = tid & 7;
+            const u32x4 raw = *(const u32x4*)(vb + (size_t)min(row, max(klen - 1, 0)) * ldv + ch * 8);
+            *(u32x4*)(Vimg + row * FBS + ((ch ^ ff_swz(row)) << 3)) = row < klen ? raw : zero4;
+        }
+    }
     // ---- this wave's V rows as B-operand fragments (key on the lane)
     bf16x8 vf[2][4];
 #pragma unroll
@@ -1174,6 +1192,50 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         const float* s_l = stats + buf * 64;
         const float* s_d = s_l + 32;
         bf16_t* dSw = dSimg + buf * (FB_DS_BYTES / 2);
+        if constexpr (!DROP && MASKED && !BAND) {
+            // Short causal heads (the decoder's self-attention, Tk <= 64: this wave holds EVERY key of the head) take delta as
+            // sum_j p_j dP_j / sum_j p_j from the p and dP of THIS kernel - what a softmax backward computes - instead of
+            // rowsum(dO o O) from the rounded O.  The two are the same number in exact arithmetic; in bf16, where the rows of V are
+            // close to one another, dP_j - delta cancels and the delta from the stored O costs ~3 x the error floor the inputs'
+            // rounding sets (1 - cos(dQ) 4.9e-4 vs 1.6e-4 on the kernel: tools/sdpa_delta_ab.py; the forms in fp64:
+            // tools/sdpa_delta_forms.py).  A first look at S and dP in 16 x 16 blocks (MFMA 16x16x32, query rows x key lanes: a
+            // rolled loop of a few registers - the same pass in the 32 x 32 form of the code below cost 40 - 90 spilled registers),
+            // V from an image staged beside K's; sums over the keys by four DPP adds; the result replaces the tile's -delta row in
+            // LDS, read back below by this wave only (no other wave has keys).
+            if (Tk <= 64) {
+                const int li = lane & 15, lg = lane >> 4;
+                float* s_dw = stats + buf * 64 + 32;
+#pragma nounroll
+                for (int qb = 0; qb < 2; ++qb) {      // 16 queries at a time: register r = query 16 qb + 4 lg + r
+                    const int row = 16 * qb + li;
+                    const int qo0 = row * FBS + ((lg ^ ff_swz(row)) << 3), qo1 = row * FBS + (((4 + lg) ^ ff_swz(row)) << 3);
+                    const f32x4_t l4 = *(const f32x4_t*)(s_l + 16 * qb + 4 * lg);
+                    f32x4_t sp = {0.f, 0.f, 0.f, 0.f}, spd = sp;
+#pragma nounroll
+                    for (int kb = 0; kb < (Tk + 15) >> 4; ++kb) {
+                        const int key = 16 * kb + li;
+                        const int ko0 = key * FBS + ((lg ^ ff_swz(key)) << 3), ko1 = key * FBS + (((4 + lg) ^ ff_swz(key)) << 3);
+                        f32x4_t sv = l4, dv4 = {0.f, 0.f, 0.f, 0.f};
+                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qt + qo0), *(const bf16x8*)(Kimg + ko0), sv, 0, 0, 0);
+                        dv4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Dt + qo0), *(const bf16x8*)(Vimg + ko0), dv4, 0, 0, 0);
+                        sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qt + qo1), *(const bf16x8*)(Kimg + ko1), sv, 0, 0, 0);
+                        dv4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Dt + qo1), *(const bf16x8*)(Vimg + ko1), dv4, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = visible(qt0 + 16 * qb + 4 * lg + r, key, klen_g, causal, window) ? __builtin_amdgcn_exp2f(sv[r]) : 0.f;
+                            sp[r] += p;
+                            spd[r] += p * dv4[r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = row_sum_dpp(sp[r]), c = row_sum_dpp(spd[r]);
+                        if (li == 0) s_dw[16 * qb + 4 * lg + r] = a > 0.f ? -c / a : 0.f;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
             const int key0 = kk0 + 32 * kbk, kj = key0 + kjl;
@@ -1625,7 +1687,7 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
-            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+            (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS + FB_VIMG_BYTES);
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
             attr = true;
@@ -1635,7 +1697,7 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         // the only kernel of this path: it may carry an armed completion event (asr_stream_arm)
         if (dthr && masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
         else if (dthr) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
-        else if (masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
+        else if (masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS + (Tk <= 64 ? FB_VIMG_BYTES : 0), st, FB_ARGS, (float*)nullptr, 0);
         else asr_launch_armed(sdpa_bwd_fused_bf16_kernel<false, false>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
 #undef FB_ARGS
     } else if (mfma && sdpa_band_shape(Tq, Tk, dk, causal, window, dtype) && delta_bytes >= asr_sdpa_bwd_workspace_bytes(B, H, Tq, Tk, dk, causal, window, dtype)

@@ -209,6 +209,36 @@ def test_sdpa(K, dtype, B, H, Tq, Tk, dk, causal, window, klens):
     close(dv.reshape(B, Tk, H, dk), vr.grad, **gt, what="sdpa dv")
 
 
+@pytest.mark.parametrize("T,ragged", [(17, False), (12, True), (64, False), (40, True)])
+def test_sdpa_bwd_short_causal_heads_reach_the_rounding_floor(K, T, ragged):
+    """The decoder's self-attention backward (causal, every key of a head in one wave) takes delta = sum p dP / sum p from its own p and
+    dP - the softmax backward the reference's autograd runs (/root/reference/Predictor/Models/attention.py:76-84) - instead of
+    rowsum(dO o O) from the bf16-rounded O.  Where the rows of V are close to one another dP - delta cancels: the flash form
+    measured 1 - cos(dQ) = 4.9e-4 here (T = 17), the floor set by rounding Q, K, V, dO to bf16 is 1.5e-4, this form 1.65e-4
+    (tools/sdpa_delta_ab.py, tools/sdpa_delta_forms.py).  The gate sits between the two."""
+    B, H, dk = 8, 8, 64
+    d = H * dk
+    g = torch.Generator().manual_seed(T)
+    q, k, do = (torch.randn(B * T, d, generator=g, dtype=torch.float64) for _ in range(3))
+    v = torch.randn(1, d, generator=g, dtype=torch.float64) + 0.1 * torch.randn(B * T, d, generator=g, dtype=torch.float64)
+    klen = torch.tensor([T - (3 * b) % 5 if ragged else T for b in range(B)], dtype=torch.int32)
+    qr, kr, vr = (x.reshape(B, T, H, dk).clone().requires_grad_(True) for x in (q, k, v))
+    o_ref, _ = sdpa_ref(qr, kr, vr, klen, True, -1, dk ** -0.5)
+    (o_ref * do.reshape(B, T, H, dk)).sum().backward()
+    qb, kb, vb, dob = (x.bfloat16().to(DEV) for x in (q, k, v, do))
+    o, lse = K.sdpa_fwd(qb, kb, vb, klen.to(DEV), B, H, T, T, dk, True, -1)
+    dq, dk_, dv = (torch.full_like(qb, float("nan")) for _ in range(3))
+    K.sdpa_bwd(qb, kb, vb, o, dob, lse, klen.to(DEV), B, H, T, T, dk, dq, dk_, dv, True, -1)
+    valid = (torch.arange(T)[None, :] < klen[:, None]).reshape(B * T).to(DEV)      # rows past an utterance's end: zero gradients of keys nobody sees
+    def one_minus_cos(a, r):
+        a, r = a.double()[valid].flatten(), r.reshape(B * T, d).to(DEV)[valid].flatten()
+        return 1.0 - float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+    assert torch.isfinite(dq).all() and torch.isfinite(dk_).all() and torch.isfinite(dv).all()
+    assert one_minus_cos(dq, qr.grad) < 2.6e-4, one_minus_cos(dq, qr.grad)
+    assert one_minus_cos(dk_, kr.grad) < 2.6e-4, one_minus_cos(dk_, kr.grad)
+    assert one_minus_cos(dv, vr.grad) < 2e-5, one_minus_cos(dv, vr.grad)
+
+
 def test_sdpa_bf16_integer_exact(K):
     """Layout check with exact small-integer data (guide section 3: asymmetric operands): with
     one visible key per query the output must equal that key's V row exactly."""

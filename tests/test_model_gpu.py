@@ -178,13 +178,14 @@ BF16_COS = 0.999
 # Tensors that cannot meet the 0.999 cosine gate, and why (measured worst cases are written to gpurun_out/bf16_parity.jsonl;
 # tools/bf16_parity.py prints every tensor).  In fp32 mode all of them agree with the oracle to 1e-6.
 #   *.w_ks.bias                         analytically zero gradient (softmax is shift-invariant): pure round-off in any implementation.
-#   decoder.*_attn.w_qs / w_ks          gradients 1e-4 .. 1e-5 of the largest one, formed as P o (dP - delta) with dP ~ delta: delta =
-#                                       rowsum(dO o O) is taken from the bf16-ROUNDED attention output, dP from fp32 accumulators, so the
-#                                       difference carries 2^-9 |delta| of rounding that the cancellation amplifies (every bf16 flash
-#                                       attention backward has this); with B*To ~ 50 query rows nothing averages it out.  Measured 0.9981.
+#   (decoder.slf_attn.w_qs / w_ks       left this list in round 5: their gradients - 1e-4 .. 1e-5 of the largest one - are formed as P o (dP - delta)
+#                                       with dP ~ delta, and delta = rowsum(dO o O) from the bf16-ROUNDED attention output carried 2^-9 |delta|
+#                                       of rounding into that difference; for heads whose keys one wave holds the backward now takes delta as
+#                                       sum p dP / sum p from its own p and dP: 0.99899 -> 0.99980 on the worst of them.  The cross-attention
+#                                       (500 keys over eight waves) keeps the flash form and measures 0.9997.)
 #   decoder.*.pos_ffn.w_1               ReLU inputs within bf16 rounding of zero fall on the other side of the ReLU; 50 rows. Measured 0.9989.
 BF16_COS_EXEMPT = ("w_ks.bias",)
-BF16_COS_RELAXED = (("decoder.", "_attn.w_qs."), ("decoder.", "_attn.w_ks."), ("decoder.", "pos_ffn.w_1."))
+BF16_COS_RELAXED = (("decoder.", "pos_ffn.w_1."),)
 BF16_COS_RELAXED_MIN = 0.997
 
 
