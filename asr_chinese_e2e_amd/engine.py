@@ -1261,9 +1261,24 @@ class Engine:
             dx, dz = self._attn_block_bwd(slf, c1, dx, dz)
             dy, dy2 = dx, dz
             self._ready(f"decoder.layer_stack.{i}.slf_attn.w_qs.weight")
-        # gradient wrt the embedding output = projection path + residual path, added inside the scatter kernel
-        K.embed_bwd(cache["ys_in"].reshape(-1), dy.contiguous(), self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1],
-                    dy2=dy2.contiguous() if dy2 is not None else None)
+        # gradient wrt the embedding output = projection path + residual path, added inside the scatter kernel.  The embedding's gradient IS
+        # the output projection's (tied weights, transformer_official.py:253-256): the scatter's atomic adds and the projection's weight-gradient
+        # GEMM (a plain read-modify-write when it has one M-split) must not overlap - the scatter goes to the weight-gradient stream, behind
+        # the launch that holds the projection's problem.  (Round 5, tools/race_stress.py: with both on their own streams a one-layer decoder
+        # replayed from a graph lost an update about once in 100 - 200 steps; in the six-layer step the two are 1.8 ms apart.)
+        ids_flat, dyc, dy2c = cache["ys_in"].reshape(-1), dy.contiguous(), (dy2.contiguous() if dy2 is not None else None)
+        self.flush_wgrads()
+        if self.overlap_wgrad:
+            self._disarm()
+            self._fork(self.side)
+            K.STREAM_OVERRIDE = self._side_handle
+            try:
+                K.embed_bwd(ids_flat, dyc, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1], dy2=dy2c)
+            finally:
+                K.STREAM_OVERRIDE = None
+            self._keep += (ids_flat, dyc) + ((dy2c,) if dy2c is not None else ())
+        else:
+            K.embed_bwd(ids_flat, dyc, self.gemb, self.d ** -0.5, drop_p=cache["drop"][0], drop_seed=cache["drop"][1], dy2=dy2c)
         if self.aux_overlap and not torch.cuda.is_current_stream_capturing():      # nothing is forked to that stream while capturing
             torch.cuda.current_stream().wait_stream(self.ctc_stream)      # d_enc is complete (CTC branch + every cross-attention add)
         self._in_decoder = False

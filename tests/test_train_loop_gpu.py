@@ -710,6 +710,51 @@ def test_graphed_shapes_keep_their_decoder_buffers():
 
 
 @pytest.mark.gpu
+def test_tied_embedding_gradient_has_one_writer_at_a_time():
+    """The decoder's embedding and its output projection are one parameter (/root/reference/Predictor/Models/transformer_official.py:253-256), so
+    their gradient rows have two writers: the scatter-add of the embedding's backward and the projection's weight-gradient GEMM (a plain
+    read-modify-write when the reduction is not split).  Round 5: on two streams with no order between them a one-layer decoder replayed
+    from a graph lost one of the two contributions about once in 100 - 200 steps (tools/race_stress.py; in the suite:
+    test_graphed_shapes_keep_their_decoder_buffers failed about once in ten runs).  Here: one captured step without the optimizer,
+    replayed 800 times - the tied gradient of every replay equals the first one up to the order of fp32 atomic adds."""
+    from asr_chinese_e2e_amd import Models
+    from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+    torch.manual_seed(5)
+    M = Models.TransformerOffical
+    cfg = M.get_default_config()()
+    cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=1, dropout=0.0, ctc_weight=0.3, dtype="bf16"))
+    m = M(cfg, Vocab.synthetic(60)).cuda()
+    pack = synthetic_pack(3, 64, 80, 60, seed=27, ragged=True, Lmin=8, Lmax=8, device="cuda", dtype=torch.bfloat16)
+    eng = m._ensure_engine(torch.device("cuda", torch.cuda.current_device()))
+    assert eng.overlap_wgrad
+
+    def body():
+        m.zero_flat_grads()
+        return m.train_step(pack)[0]
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            body()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    grad = m._flat.view(m._flat.g, "decoder.tgt_word_emb.weight")
+    g.replay()
+    ref = grad.clone()
+    scale = float(ref.abs().max())
+    assert scale > 0
+    worst = torch.zeros((), device="cuda")
+    for _ in range(800):
+        g.replay()
+        worst = torch.maximum(worst, (grad - ref).abs().max())
+    torch.cuda.synchronize()
+    assert float(worst) < 1e-4 * scale, (float(worst), scale)
+
+
 def test_step_streams_are_chosen_by_measurement():
     """The HIP runtime maps streams onto a few in-order hardware queues (and those onto fewer command-processor pipes) in the order in which a
     process first USES them; two busy streams on one queue or one pipe do not run side by side (tools/queue_probe.py: 2.2 ms for two

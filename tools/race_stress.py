@@ -1,0 +1,48 @@
+"""Four identical small joint models from one seed, two stepped eagerly and two through captured graphs (as
+tests/test_train_loop_gpu.py::test_graphed_shapes_keep_their_decoder_buffers does), over many steps and eight batch shapes, with
+unrelated allocations in between; losses and CER are compared bit for bit after every step.  What it found (round 5): ONE replica leaving the
+others within 60 - 100 steps with jumps of 1e-4 .. 1e-3 in the decoder's loss - the tied embedding / output-projection gradient had two
+unordered writers (engine.decoder_bwd; regression test: test_tied_embedding_gradient_has_one_writer_at_a_time).  What is left after the fix
+and is NOT a race: after ~2000 steps the replicas may split into groups that differ by 1e-5 relative - the order of two fp32 atomic adds
+of a weight gradient with two M-splits (the documented non-deterministic mode; ASR_DETERMINISTIC=1 removes it together with the overlap).
+python tools/race_stress.py [steps]"""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from asr_chinese_e2e_amd import Models
+from asr_chinese_e2e_amd.data_handler import Vocab, synthetic_pack
+from asr_chinese_e2e_amd.graph import GraphedModel
+from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
+
+def build():
+    torch.manual_seed(5)
+    M = Models.TransformerOffical
+    cfg = M.get_default_config()()
+    cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=1, dropout=0.0, ctc_weight=0.3, dtype="bf16"))
+    m = M(cfg, Vocab.synthetic(60)).cuda()
+    return m, NoamOpt(512, 1, 4000, FusedAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+packs = [synthetic_pack(3, 64, 80, 60, seed=20 + i, ragged=True, Lmin=2 + i, Lmax=2 + i, device="cuda", dtype=torch.bfloat16) for i in range(8)]
+ms = [build() for _ in range(4)]      # two eager, two graphed
+gs = [None, None, GraphedModel(ms[2][0]), GraphedModel(ms[3][0])]
+rng = random.Random(0)
+junk, bad = [], 0
+names = ("eager A", "eager B", "graph A", "graph B")
+for s in range(steps):
+    p = packs[rng.randrange(8)]
+    out = []
+    for i, (m, o) in enumerate(ms):
+        r, _ = (gs[i].iterate if gs[i] is not None else m.iterate)(p, optimizer=o)
+        out.append(r)
+    if rng.random() < 0.3:      # disturb the caching allocator: blocks of odd sizes come and go between steps
+        junk.append(torch.empty(rng.randrange(1, 1 << 20), device="cuda"))
+        if len(junk) > 6: junk.pop(rng.randrange(len(junk)))
+    vals = [(float(r.loss), float(r.ce), float(r.ctc), float(r.cer)) for r in out]
+    if len(set(vals)) > 1:
+        bad += 1
+        print(f"step {s} (To = {p.tgt_for_input.shape[1]}):", flush=True)
+        for n, v in zip(names, vals): print(f"   {n}: loss {v[0]!r} ce {v[1]!r} ctc {v[2]!r} cer {v[3]!r}", flush=True)
+        if bad >= 3: break
+    if s % 500 == 499: print(f"{s + 1} steps, {bad} differences", flush=True)
+print("differences:", bad)
