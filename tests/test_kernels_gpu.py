@@ -155,6 +155,8 @@ SDPA_CASES = [
     (torch.bfloat16, 2, 2, 300, 300, 64, False, 50, [300, 100]),  # band + short utterance: queries >= 151 of row 1 see NO key (lse -inf, zero gradients)
     (torch.bfloat16, 2, 2, 24, 24, 64, True, -1, [24, 11]),       # decoder self-attention shape (causal, To ~ 20)
     (torch.bfloat16, 1, 1, 40, 700, 64, False, 60, [650]),        # band on the kernel-pair path, dead rows included
+    (torch.bfloat16, 2, 4, 48, 48, 64, False, 5, [48, 31]),       # a band over <= 64 keys: the short heads' own-delta pass with a window, two query tiles
+    (torch.bfloat16, 3, 2, 64, 64, 64, True, -1, [64, 33, 1]),    # causal, exactly the 64 keys one wave holds; an utterance of one key
     # the long-form configuration's shape (BASELINE configs[4]: T = 2000 frames, +-50-frame band): single-pass band backward, one
     # workgroup per 512-key block, dQ of the tiles on a block boundary summed from two fp32 partials
     (torch.bfloat16, 1, 8, 2000, 2000, 64, False, 50, [2000]),
