@@ -16,12 +16,14 @@ from asr_chinese_e2e_amd.Trainer import FusedAdam, NoamOpt
 
 CTC_ONLY = os.environ.get("MODEL", "joint") == "ctc"
 LAYERS, DROPOUT = int(os.environ.get("LAYERS", "1")), float(os.environ.get("DROPOUT", "0"))      # dropout > 0: four eager replicas (no capture)
+WINDOW = int(os.environ.get("WINDOW", "-1"))          # +-w frame band on the encoder's self-attention (the long-form configuration)
+EVAL_EVERY = int(os.environ.get("EVAL_EVERY", "0"))   # > 0: the B replicas run an evaluation pass and a beam / greedy search on another batch every so many steps
 
 def build():
     torch.manual_seed(5)
     M = Models.TransformerCTC if CTC_ONLY else Models.TransformerOffical
     cfg = M.get_default_config()()
-    cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=LAYERS, dropout=DROPOUT, ctc_weight=1.0 if CTC_ONLY else 0.3, dtype="bf16"))
+    cfg.fn_build(dict(n_mels=80, lfr_m=1, layer_num=LAYERS, dropout=DROPOUT, ctc_weight=1.0 if CTC_ONLY else 0.3, dtype="bf16", attn_window=WINDOW))
     m = M(cfg, Vocab.synthetic(60)).cuda()
     return m, NoamOpt(512, 1, 4000, FusedAdam(m.parameters(), lr=3e-4, betas=(0.9, 0.98), eps=1e-9))
 
@@ -36,6 +38,13 @@ for s in range(steps):
     p = packs[rng.randrange(8)]
     out = []
     for i, (m, o) in enumerate(ms):
+        if EVAL_EVERY and i % 2 == 1 and s % EVAL_EVERY == EVAL_EVERY - 1:      # no side effect on the training state
+            q = packs[(s // EVAL_EVERY) % 8]
+            m.eval()
+            m.iterate(q, is_train=False)
+            if not CTC_ONLY:
+                (m.beam_search(q, beam_size=3) if (s // EVAL_EVERY) % 2 else m.greedy_search(q))
+            m.train()
         r, _ = (gs[i].iterate if gs[i] is not None else m.iterate)(p, optimizer=o)
         out.append(r)
     if rng.random() < 0.3:      # disturb the caching allocator: blocks of odd sizes come and go between steps
