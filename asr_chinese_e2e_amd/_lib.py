@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(_HERE, "libasr_hip.so")
 
 ASR_F32, ASR_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_MASK = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 DROP_PRE, DROP_POST = 1, 2
 
 P, I, F, Z, U = c_void_p, c_int, c_float, c_size_t, c_uint32
@@ -58,7 +58,7 @@ class DecLayerPlan(ctypes.Structure):
                                   "dz_s", "g_as", "g_qkv", "dx_s",
                                   "dctx", "gb_2", "gb_fc_c", "gb_fc_s",
                                   "part_f", "part_c", "part_s", "delta")] +
-                [("delta_bytes", Z), ("d_enc", P), ("wgrad_stream", P), ("aux_cus", I), ("ld_kv_c", I), ("kv_dgrad_cols", I), ("g_kv_group", P)])
+                [("delta_bytes", Z), ("d_enc", P), ("wgrad_stream", P), ("aux_cus", I), ("ld_kv_c", I), ("kv_dgrad_cols", I), ("g_kv_group", P), ("ctx_s_lo", P), ("ctx_c_lo", P)])
 
 # name -> (restype, argtypes); order and meaning exactly as in include/asr_hip.h
 SIGNATURES = {
@@ -75,9 +75,9 @@ SIGNATURES = {
     "asr_add_ln_bwd_workspace_bytes": (Z, [I, I]),
     "asr_add_ln_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, Z, I, I, I, F, U, I, I, P]),
     "asr_add_ln_bwd_reduce_batched": (I, [P, I, I, P]),
-    "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
+    "asr_sdpa_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, I, P]),
     "asr_sdpa_bwd_workspace_bytes": (Z, [I, I, I, I, I, I, I, I]),
-    "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, Z, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, I, P]),
+    "asr_sdpa_bwd": (I, [P, P, P, P, P, P, P, Z, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, F, F, U, P, I, P]),
     "asr_dropout_mask": (I, [P, I, I, F, U, P]),
     "asr_sdpa_dropout_mask": (I, [P, I, I, I, I, F, U, P]),
     "asr_ctc_workspace_bytes": (Z, [I, I, I]),

@@ -39,7 +39,7 @@ extern "C" int asr_decoder_layer_fwd(const asr_dec_layer_plan* p, void* stream) 
     // ---- self-attention (causal over the target prefix; attention.py:33-62)
     DEC_TRY(asr_gemm_small_bf16(p->x_in, p->w_qkv_s, p->b_qkv_s, nullptr, p->qkv_s, M, 3 * hd, d, d, d, 3 * hd, 0, ASR_ACT_NONE, stream));
     DEC_TRY(asr_sdpa_fwd(qkv, qkv + hd * e, qkv + 2 * hd * e, p->ctx_s, p->lse_s, p->dec_len, B, H, To, To, dk, 3 * hd, 3 * hd, 3 * hd, hd, 1, -1, scale,
-                         p->drop_p, p->seed[0], ASR_BF16, stream));
+                         p->drop_p, p->seed[0], p->ctx_s_lo, ASR_BF16, stream));
     DEC_TRY(asr_gemm_small_bf16(p->ctx_s, p->w_fc_s, p->b_fc_s, nullptr, p->a_s, M, d, hd, hd, hd, d, 0, ASR_ACT_NONE, stream));
     DEC_TRY(asr_add_ln_fwd(p->a_s, p->x_in, p->g_s, p->be_s, nullptr, p->dec_len, p->y_s, p->a_s, p->rstd_s, B, To, d, p->drop_p, p->seed[1], ASR_DROP_PRE,
                            ASR_BF16, stream));
@@ -52,7 +52,7 @@ extern "C" int asr_decoder_layer_fwd(const asr_dec_layer_plan* p, void* stream) 
     char* kv = (char*)p->kv_c;
     const int ldkv = p->ld_kv_c > 0 ? p->ld_kv_c : 2 * hd;      // the K | V of all layers may sit side by side in one buffer
     DEC_TRY(asr_sdpa_fwd(p->q_c, kv, kv + hd * e, p->ctx_c, p->lse_c, p->cross_len, B, H, To, T, dk, hd, ldkv, ldkv, hd, 0, -1, scale, p->drop_p, p->seed[2],
-                         ASR_BF16, stream));
+                         p->ctx_c_lo, ASR_BF16, stream));
     DEC_TRY(asr_gemm_small_bf16(p->ctx_c, p->w_fc_c, p->b_fc_c, nullptr, p->a_c, M, d, hd, hd, hd, d, 0, ASR_ACT_NONE, stream));
     DEC_TRY(asr_add_ln_fwd(p->a_c, p->y_s, p->g_c, p->be_c, nullptr, p->dec_len, p->y_c, p->a_c, p->rstd_c, B, To, d, p->drop_p, p->seed[3], ASR_DROP_PRE,
                            ASR_BF16, stream));
@@ -98,7 +98,7 @@ extern "C" int asr_decoder_layer_bwd(const asr_dec_layer_plan* p, const void* dy
     if (p->kv_dgrad_cols > 0 && (!p->g_kv_group || p->kv_dgrad_cols % 8 || p->kv_dgrad_cols > ldkv)) ASR_FAIL(ASR_EINVAL, "asr_decoder_layer_bwd: kv_dgrad_cols = %d needs g_kv_group, a multiple of 8, <= ld_kv_c = %d", p->kv_dgrad_cols, ldkv);
     if (kv_dgrad && aux_stream) DEC_TRY(asr_stream_arm(stream, aux_stream));
     DEC_TRY(asr_sdpa_bwd(p->q_c, kv, kv + hd * e, p->ctx_c, p->dctx, p->lse_c, p->delta, p->delta_bytes, p->g_qc, gkv, gkv + hd * e, p->cross_len, B, H, To, T, dk, hd,
-                         ldkv, ldkv, hd, 0, -1, scale, p->drop_p, p->seed[2], ASR_BF16, stream));
+                         ldkv, ldkv, hd, 0, -1, scale, p->drop_p, p->seed[2], p->ctx_c_lo, ASR_BF16, stream));
     if (kv_dgrad) {
         void* st2 = aux_stream ? aux_stream : stream;
         if (aux_stream && asr_stream_arm_pending()) DEC_TRY(asr_stream_fork(stream, aux_stream));      // the attention path taken had no armed launch
@@ -120,7 +120,7 @@ extern "C" int asr_decoder_layer_bwd(const asr_dec_layer_plan* p, const void* dy
     char* qkv = (char*)p->qkv_s;
     char* gq = (char*)p->g_qkv;
     DEC_TRY(asr_sdpa_bwd(qkv, qkv + hd * e, qkv + 2 * hd * e, p->ctx_s, p->dctx, p->lse_s, p->delta, p->delta_bytes, gq, gq + hd * e, gq + 2 * hd * e, p->dec_len, B, H, To,
-                         To, dk, 3 * hd, 3 * hd, 3 * hd, hd, 1, -1, scale, p->drop_p, p->seed[0], ASR_BF16, stream));
+                         To, dk, 3 * hd, 3 * hd, 3 * hd, hd, 1, -1, scale, p->drop_p, p->seed[0], p->ctx_s_lo, ASR_BF16, stream));
     if (p->wgrad_stream) DEC_TRY(asr_stream_arm(stream, p->wgrad_stream));      // the layer's last kernel hands over to the weight-gradient stream
     DEC_TRY(asr_gemm_small_bf16(p->g_qkv, p->w_qkv_s, nullptr, nullptr, p->dx_s, M, d, 3 * hd, 3 * hd, d, d, 1, ASR_ACT_NONE, stream));
     return ASR_OK;

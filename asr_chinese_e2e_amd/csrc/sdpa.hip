@@ -130,12 +130,40 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&acc)[2], float mul, 
         }
 }
 
+// The low-order part of the same rows: bf16(x - float(bf16(x))) of x = acc * mul, the other 8 bits of mantissa the bf16 O drops.  Only the
+// backward pass reads it, for delta = rowsum(dO o O): with O rounded to bf16 that sum carries 2^-9 |O| of error per coordinate, and where the
+// rows of K and of V have a component in common (a bias behind a LayerNorm is enough) dQ = sum_j p_j (dP_j - delta) K_j turns an error eps of
+// delta into eps * (the mean key) while the true dQ only sees the keys' DEVIATIONS from that mean: 1 - cos(dQ) 5e-2 (mean = 3 sigma) or 7e-4
+// (1 sigma) with O alone against 2e-4 / 2e-5 with the two pieces, the floor set by rounding Q, K, V, dO being 3e-5 / 7e-6
+// (tools/sdpa_delta_forms.py; at full size the encoder's top-layer Q / K projection gradients measured 0.989 against the oracle without it).
+__device__ __forceinline__ void store_rows_T_lo(const f32x16 (&acc)[2], float mul, bf16_t* __restrict__ base, size_t ld, int row0, int row_limit, int lane) {
+    const int row = row0 + (lane & 31);
+    const bool ok = row < row_limit;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            bf16x4 p0, p1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = acc[db][8 * gp + e] * mul, x1 = acc[db][8 * gp + 4 + e] * mul;
+                p0[e] = (bf16_t)(x0 - (float)(bf16_t)x0);
+                p1[e] = (bf16_t)(x1 - (float)(bf16_t)x1);
+            }
+            const u32x2 a = __builtin_bit_cast(u32x2, p0), b = __builtin_bit_cast(u32x2, p1);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+            const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+            if (ok) *(u32x4*)(base + (size_t)row * ld + 32 * db + 16 * gp + 8 * (lane >> 5)) = v;
+        }
+}
+
 // ---------------------------------------------------------------- forward
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void sdpa_fwd_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                             bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
                                                             int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
-                                                            uint32_t dseed, uint32_t dthr, float dscale) {
+                                                            uint32_t dseed, uint32_t dthr, float dscale, bf16_t* __restrict__ o_lo) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TILE_ELEMS];
     bf16_t* Kt = smem;
     bf16_t* Vt = smem + TILE_ELEMS;
@@ -245,12 +273,13 @@ __global__ __launch_bounds__(256, 2) void sdpa_fwd_bf16_kernel(const bf16_t* __r
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.f / l : 0.f;
     store_rows_T(oacc, inv, o + (size_t)b * Tq * ldo + h * DK, ldo, q0, Tq, lane);
+    if (o_lo) store_rows_T_lo(oacc, inv, o_lo + (size_t)b * Tq * ldo + h * DK, ldo, q0, Tq, lane);
     if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m * sc2 + log2f(l)) * LN2 : -INFINITY;
 }
 
 // delta[b,h,q] = sum_d dO * O   (one wave per 8 rows x 8 lanes... simple: one thread-group of 8 lanes per (row, head))
 template <typename T>
-__global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o, float* __restrict__ delta, int B, int H, int Tq,
+__global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o, const T* __restrict__ o_lo, const T* __restrict__ d_o, float* __restrict__ delta, int B, int H, int Tq,
                                                          int dk, int ldo) {
     // 8 lanes per (b, t, h); each lane strides over dk
     const int gid = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o
         const int bt = gid / H;
         b = bt / Tq; t = bt - b * Tq;
         const size_t off = (size_t)bt * ldo + (size_t)h * dk;
-        for (int c = sub; c < dk; c += 8) s += to_f32<T>(o[off + c]) * to_f32<T>(d_o[off + c]);
+        for (int c = sub; c < dk; c += 8) s += (to_f32<T>(o[off + c]) + (o_lo ? to_f32<T>(o_lo[off + c]) : 0.f)) * to_f32<T>(d_o[off + c]);
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
@@ -273,7 +302,7 @@ __global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o
 // ---------------------------------------------------------------- backward: dQ
 template <bool DROP>
 __global__ __launch_bounds__(256, 3) void sdpa_bwd_dq_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                               const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                               const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const bf16_t* __restrict__ o_lo, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16_t* __restrict__ dq, const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq,
                                                                int ldk, int ldv, int ldo, int causal, int window, float scale, uint32_t dseed, uint32_t dthr,
                                                                float dscale) {
@@ -310,6 +339,13 @@ __global__ __launch_bounds__(256, 3) void sdpa_bwd_dq_bf16_kernel(const bf16_t* 
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
+        if (o_lo) {      // the low-order piece of O (see store_rows_T_lo)
+            frags_from_global(of, o_lo + (size_t)b * Tq * ldo + h * DK, ldo, q0, Tq, lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
+        }
         dl += __shfl_xor(dl, 32, 64);
         if (lane < 32 && qi < Tq) delta[stat] = dl;
     }
@@ -532,7 +568,7 @@ template <bool DROP, bool MASKED>
 __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                          bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
                                                                          int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
-                                                                         uint32_t dseed, uint32_t dthr, float dscale) {
+                                                                         uint32_t dseed, uint32_t dthr, float dscale, bf16_t* __restrict__ o_lo) {
     extern __shared__ __attribute__((aligned(1024))) char smem_ff[];
     const char* Kimg = smem_ff;
     const char* Vimg = smem_ff + FF_IMG;
@@ -759,6 +795,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
             else l = lacc[0];      // the contraction ran over all 64 keys of every tile: no cross-half add
             const float inv = l > 0.f ? 1.f / l : 0.f;
             store_rows_T(oacc, inv, ob, ldo, q0, Tq, lane);
+            if (o_lo) store_rows_T_lo(oacc, inv, o_lo + (size_t)b * Tq * ldo + h * DK, ldo, q0, Tq, lane);
             if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m * sc2 + log2f(l)) * LN2 : -INFINITY;
         }
     }
@@ -779,7 +816,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
 // better across the two waves of a SIMD).  Opt-in (tuning option "sdpa_pair"); a hand-placed schedule of this body is the open lever.
 __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_pair_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                         bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
-                                                                        int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float scale) {
+                                                                        int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float scale, bf16_t* __restrict__ o_lo) {
     extern __shared__ __attribute__((aligned(1024))) char smem_ff[];
     const char* Kimg = smem_ff;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -948,6 +985,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_pair_bf16_kernel(const
             const float l = lacc[bk][0];
             const float inv = l > 0.f ? 1.f / l : 0.f;
             store_rows_T(oacc[bk], inv, ob, ldo, qs, Tq, lane);
+            if (o_lo) store_rows_T_lo(oacc[bk], inv, o_lo + (size_t)b * Tq * ldo + h * DK, ldo, qs, Tq, lane);
             if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m[bk] * sc2 + log2f(l)) * LN2 : -INFINITY;
         }
     }
@@ -1047,7 +1085,7 @@ __device__ __forceinline__ float row_sum_dpp(float v) {
 
 template <bool DROP, bool MASKED, bool BAND = false>
 __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                                         const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                                         const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o, const bf16_t* __restrict__ o_lo, const float* __restrict__ lse,
                                                                          bf16_t* __restrict__ dq, bf16_t* __restrict__ dk_, bf16_t* __restrict__ dv,
                                                                          const int32_t* __restrict__ k_len, int H, int Tq, int Tk, int ldq, int ldk, int ldv, int ldo,
                                                                          int causal, int window, float scale, uint32_t dseed, uint32_t dthr, float dscale,
@@ -1071,6 +1109,8 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
     const bf16_t* dob = d_o + (size_t)b * Tq * ldo + h * DK;
     const bf16_t* ob = o + (size_t)b * Tq * ldo + h * DK;
+    const bf16_t* olb = (o_lo ? o_lo : o) + (size_t)b * Tq * ldo + h * DK;      // the low-order piece of O (store_rows_T_lo); without one the load below is unused
+    const bool has_lo = o_lo != nullptr;
     const bf16_t* kb = k + ((size_t)b * Tkg + kblk0) * ldk + h * DK;
     const bf16_t* vb = v + ((size_t)b * Tkg + kblk0) * ldv + h * DK;
     const float* lseb = lse + ((size_t)b * H + h) * Tq;
@@ -1125,7 +1165,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     const bool is_do = tid >= 256;
     const bf16_t* srcA = is_do ? dob : qb;      // one code path for both halves of the workgroup
     const size_t ldA = is_do ? (size_t)ldo : (size_t)ldq;
-    u32x4 pa = zero4, po = zero4;
+    u32x4 pa = zero4, po = zero4, po2 = zero4;
     float pl = 0.f;
     // FB_PREFETCH only ISSUES the loads of a tile (rows clamped into the matrix, no use of the loaded values); FB_COMMIT, a tile later,
     // zeroes what lies past the end and stores the tile.  With the selects on the loaded values written next to the loads the compiler
@@ -1135,20 +1175,21 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         const size_t row_ = (size_t)min((Q0) + prow, Tq - 1);                                             \
         pa = *(const u32x4*)(srcA + row_ * ldA + pch * 8);                                                \
         po = *(const u32x4*)(ob + row_ * ldo + pch * 8);                                                  \
+        if (has_lo) po2 = *(const u32x4*)(olb + row_ * ldo + pch * 8);                                    \
         pl = lseb[min((Q0) + (tid & 31), Tq - 1)];                                                        \
     } while (0)
     // rows past the end / rows that saw no key get -1e30: p = 0.  (Every thread loads one lse value: no divergent path.)
 #define FB_COMMIT(BUF, Q0)                                                                                \
     do {                                                                                                  \
-        if ((Q0) + prow >= Tq) { pa = zero4; po = zero4; }                                                \
+        if ((Q0) + prow >= Tq) { pa = zero4; po = zero4; po2 = zero4; }                                   \
         const float pl_ = ((Q0) + (tid & 31) >= Tq || pl == -INFINITY) ? -1.0e30f : -pl * LOG2E;          \
         bf16_t* T_ = tiles + (BUF) * 2 * FB_TILE_ELEMS + (is_do ? FB_TILE_ELEMS : 0);                     \
         *(u32x4*)(T_ + prow * FBS + ((pch ^ ff_swz(prow)) << 3)) = pa;                                                         \
         float* st_ = stats + (BUF) * 64;                                                                  \
         float d_ = 0.f;   /* delta = rowsum(dO o O): 8 lanes per row (the Q half computes a throw-away value) */ \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                \
-            d_ += __uint_as_float(pa[e_] << 16) * __uint_as_float(po[e_] << 16);                          \
-            d_ += __uint_as_float(pa[e_] & 0xffff0000u) * __uint_as_float(po[e_] & 0xffff0000u);          \
+            d_ += __uint_as_float(pa[e_] << 16) * (__uint_as_float(po[e_] << 16) + __uint_as_float(po2[e_] << 16));                          \
+            d_ += __uint_as_float(pa[e_] & 0xffff0000u) * (__uint_as_float(po[e_] & 0xffff0000u) + __uint_as_float(po2[e_] & 0xffff0000u));  \
         }                                                                                                 \
         d_ += __shfl_xor(d_, 1, 64);                                                                      \
         d_ += __shfl_xor(d_, 2, 64);                                                                      \
@@ -1604,9 +1645,10 @@ static int check_common(const char* name, int B, int H, int Tq, int Tk, int dk, 
 }  // namespace
 
 extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* k_len, int B, int H, int Tq, int Tk, int dk,
-                            int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale, float drop_p, uint32_t dseed, int dtype,
-                            void* stream) {
+                            int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale, float drop_p, uint32_t dseed, void* o_lo,
+                            int dtype, void* stream) {
     if (!q || !k || !v || !o || !lse) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: null pointer");
+    if (o_lo && (dtype != ASR_BF16 || ((uintptr_t)o_lo % 16) != 0)) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: o_lo is the low-order piece of a bf16 output (16-byte aligned, the layout of o)");
     if (int rc = check_common("asr_sdpa_fwd", B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo)) return rc;
     if (drop_p < 0.f || drop_p >= 1.f) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: bad dropout p=%f", drop_p);
     if ((double)B * H * Tq * (Tk + 1) >= 4294967296.0) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: B*H*Tq*Tk exceeds the 32-bit dropout counter");
@@ -1624,24 +1666,28 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_pair_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             attr = true;
         }
-#define FF_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
+#define FF_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale, (bf16_t*)o_lo
         const bool masked = causal || window >= 0;
         if (dthr && masked) sdpa_fwd_fused_bf16_kernel<true, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (dthr) sdpa_fwd_fused_bf16_kernel<true, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (masked) sdpa_fwd_fused_bf16_kernel<false, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
-        else if (asr_option(ASR_OPT_SDPA_PAIR)) sdpa_fwd_pair_bf16_kernel<<<B * H, FF_THREADS, FF_LDS, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, scale);
+        else if (asr_option(ASR_OPT_SDPA_PAIR)) sdpa_fwd_pair_bf16_kernel<<<B * H, FF_THREADS, FF_LDS, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, scale, (bf16_t*)o_lo);
         else sdpa_fwd_fused_bf16_kernel<false, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
 #undef FF_ARGS
     } else if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o)) {
         const int grid = ceil_div(Tq, 128) * H * B;
-        if (dthr) sdpa_fwd_bf16_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
-        else sdpa_fwd_bf16_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
+        if (dthr) sdpa_fwd_bf16_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale, (bf16_t*)o_lo);
+        else sdpa_fwd_bf16_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale, (bf16_t*)o_lo);
     } else {
         dim3 grid(Tq, H, B);
         const size_t lds = (size_t)(Tk + dk) * sizeof(float);
         if (lds > 64 * 1024) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: generic path needs Tk+dk <= 16384");
         if (dtype == ASR_F32) sdpa_fwd_generic_kernel<float><<<grid, 64, lds, st>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, lse, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
-        else if (dtype == ASR_BF16) sdpa_fwd_generic_kernel<bf16_t><<<grid, 64, lds, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
+        else if (dtype == ASR_BF16) {
+            // this path writes no low-order piece: zeros (the backward pass then takes delta from o alone)
+            if (o_lo && hipMemset2DAsync(o_lo, (size_t)ldo * 2, 0, (size_t)H * dk * 2, (size_t)B * Tq, st) != hipSuccess) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: clearing o_lo failed");
+            sdpa_fwd_generic_kernel<bf16_t><<<grid, 64, lds, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);
+        }
         else ASR_FAIL(ASR_EDTYPE, "asr_sdpa_fwd: dtype %d", dtype);
     }
     ASR_CHECK_LAUNCH("asr_sdpa_fwd");
@@ -1667,8 +1713,9 @@ extern "C" size_t asr_sdpa_bwd_workspace_bytes(int B, int H, int Tq, int Tk, int
 
 extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, size_t delta_bytes,
                             void* dq, void* dk_, void* dv, const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk, int ldv, int ldo,
-                            int causal, int window, float scale, float drop_p, uint32_t dseed, int dtype, void* stream) {
+                            int causal, int window, float scale, float drop_p, uint32_t dseed, const void* o_lo, int dtype, void* stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk_ || !dv) ASR_FAIL(ASR_EINVAL, "asr_sdpa_bwd: null pointer");
+    if (o_lo && (dtype != ASR_BF16 || ((uintptr_t)o_lo % 16) != 0)) ASR_FAIL(ASR_EINVAL, "asr_sdpa_bwd: o_lo is the low-order piece of a bf16 output (16-byte aligned, the layout of o)");
     if (int rc = check_common("asr_sdpa_bwd", B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo)) return rc;
     if (dtype != ASR_F32 && dtype != ASR_BF16) ASR_FAIL(ASR_EDTYPE, "asr_sdpa_bwd: dtype %d", dtype);
     if (delta_bytes < (size_t)B * H * Tq * sizeof(float)) ASR_FAIL(ASR_EWORKSPACE, "asr_sdpa_bwd: scratch of %zu bytes, need at least B*H*Tq floats = %zu", delta_bytes, (size_t)B * H * Tq * sizeof(float));
@@ -1679,8 +1726,8 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
     const int ngroups = B * Tq * H;
     const bool mfma = dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, d_o) && mfma_ok(dk, ldq, ldk, ldv, ldo, dq, dk_, dv, o);
     if (!mfma) {   // the MFMA dQ kernel computes delta itself
-        if (dtype == ASR_F32) sdpa_delta_kernel<float><<<ceil_div(ngroups, 32), 256, 0, st>>>((const float*)o, (const float*)d_o, delta, B, H, Tq, dk, ldo);
-        else sdpa_delta_kernel<bf16_t><<<ceil_div(ngroups, 32), 256, 0, st>>>((const bf16_t*)o, (const bf16_t*)d_o, delta, B, H, Tq, dk, ldo);
+        if (dtype == ASR_F32) sdpa_delta_kernel<float><<<ceil_div(ngroups, 32), 256, 0, st>>>((const float*)o, (const float*)nullptr, (const float*)d_o, delta, B, H, Tq, dk, ldo);
+        else sdpa_delta_kernel<bf16_t><<<ceil_div(ngroups, 32), 256, 0, st>>>((const bf16_t*)o, (const bf16_t*)o_lo, (const bf16_t*)d_o, delta, B, H, Tq, dk, ldo);
     }
     const bool fb_fused = mfma && Tk <= FB_KEYS;      // else: the band kernel (windowed attention over many keys) or the dQ + dK/dV pair of round 1
     if (fb_fused) {   // every key of a head fits one workgroup: single-pass backward
@@ -1692,7 +1739,7 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
             attr = true;
         }
-#define FB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
+#define FB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, (const bf16_t*)o_lo, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
         const bool masked = causal || window >= 0;
         // the only kernel of this path: it may carry an armed completion event (asr_stream_arm)
         if (dthr && masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);
@@ -1711,7 +1758,7 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         }
         const int nblk = ceil_div(Tk, FB_KEYS), slots = sdpa_band_slots(window);
         const dim3 grid(B * H, nblk);
-#define FBB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale, delta, slots
+#define FBB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, (const bf16_t*)o_lo, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale, delta, slots
         if (dthr) sdpa_bwd_fused_bf16_kernel<true, true, true><<<grid, FB_THREADS, FB_LDS, st>>>(FBB_ARGS);
         else sdpa_bwd_fused_bf16_kernel<false, true, true><<<grid, FB_THREADS, FB_LDS, st>>>(FBB_ARGS);
 #undef FBB_ARGS
@@ -1720,7 +1767,7 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
         const int gq = ceil_div(Tq, 128) * H * B, gk = ceil_div(Tk, 128) * H * B;
 #define SDPA_BWD(D)                                                                                                                                        \
     do {                                                                                                                                                   \
-        sdpa_bwd_dq_bf16_kernel<D><<<gq, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, lse, delta, (bf16_t*)dq, \
+        sdpa_bwd_dq_bf16_kernel<D><<<gq, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, (const bf16_t*)o_lo, lse, delta, (bf16_t*)dq, \
                                                         k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);                  \
         sdpa_bwd_dkv_bf16_kernel<D><<<gk, 256, 0, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk_, \
                                                          (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale);    \

@@ -605,6 +605,10 @@ class Engine:
         self._arm_covers_pending = False      # set by _dec_exec_bwd while it collects a layer's weight gradients behind its armed last kernel
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
+        # ASR_SDPA_LO=0: the attention backward takes delta = rowsum(dO o O) from the bf16 O alone (rounds 1 - 4).  Default: the forward pass of a
+        # training step also stores O's low-order piece (16 MB per encoder layer at the headline shapes) and delta uses both - where K and V rows
+        # share a component (a bias behind a LayerNorm) the rounding of O otherwise reaches dQ multiplied by the mean key (sdpa.hip: store_rows_T_lo)
+        self.sdpa_lo = os.environ.get("ASR_SDPA_LO", "1") == "1"
         self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
@@ -844,10 +848,13 @@ class Engine:
             c["q"], c["kv"] = q, kv
         pa, sa = self._drop(site)          # attention probabilities (attention.py:83)
         pf, sf = self._drop(site + 1)      # after fc, before residual + LN (attention.py:59)
-        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa)
+        # the low-order piece of the bf16 attention output, for the backward pass's delta only (asr_hip.h: asr_sdpa_fwd's o_lo): a training step's
+        # forward pass (grad mode) writes it, an evaluation pass does not
+        ctx_lo = torch.empty(B * Tq, hd, dtype=q.dtype, device=q.device) if (self.sdpa_lo and q.dtype == torch.bfloat16 and torch.is_grad_enabled()) else None
+        ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa, o_lo=ctx_lo)
         a = m.fc.fwd(ctx)
         y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)
-        c.update(x=x, kv_src=kv_src, ctx=ctx, lse=lse, xhat=xhat, rstd=rstd, k_len=k_len, q_lens=q_lens, dims=(B, Tq, Tk), causal=causal,
+        c.update(x=x, kv_src=kv_src, ctx=ctx, ctx_lo=ctx_lo, lse=lse, xhat=xhat, rstd=rstd, k_len=k_len, q_lens=q_lens, dims=(B, Tq, Tk), causal=causal,
                  window=window, cross=cross, drop=(pa, sa, pf, sf))
         return y, c
 
@@ -873,7 +880,7 @@ class Engine:
             self._disarm()      # nothing was released: the arm must not leak into the attention kernel's launch
             self._arm()
             K.sdpa_bwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk,
-                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa)
+                       dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:], c["causal"], c["window"], drop_p=pa, drop_seed=sa, o_lo=c["ctx_lo"])
             self._wgrad(m.qkv, dqkv, c["x"], bias_from=dqkv)
             dx = m.qkv.dgrad(dqkv)
         else:
@@ -881,7 +888,7 @@ class Engine:
             dq = torch.empty_like(q)
             dkv = torch.empty_like(kv)
             K.sdpa_bwd(q, kv[:, :hd], kv[:, hd:], c["ctx"], dctx, c["lse"], c["k_len"], B, H, Tq, Tk, dk, dq, dkv[:, :hd], dkv[:, hd:],
-                       c["causal"], c["window"], drop_p=pa, drop_seed=sa)
+                       c["causal"], c["window"], drop_p=pa, drop_seed=sa, o_lo=c["ctx_lo"])
             self._wgrad(m.q, dq, c["x"], bias_from=dq)
             self._wgrad(m.kv, dkv, c["kv_src"], bias_from=dkv)
             dx = m.q.dgrad(dq)
@@ -1072,6 +1079,8 @@ class Engine:
                      part_s=torch.empty(part_bytes, dtype=torch.uint8, device=dev))
             if drop:      # pre-residual dropout: the gradient wrt a projection's output is its own tensor
                 t.update(g_o=bf(M, d), g_ac=bf(M, d), g_as=bf(M, d))
+            if self.sdpa_lo:      # low-order pieces of the two attention outputs (asr_sdpa_fwd's o_lo)
+                t.update(ctx_s_lo=bf(M, hd), ctx_c_lo=bf(M, hd))
             pl = _lib.DecLayerPlan()
             pl.B, pl.To, pl.T, pl.d, pl.H, pl.dk, pl.ff = B, To, T, d, H, self.dk, ff
             pl.ld_kv_c = self.L * 2 * hd

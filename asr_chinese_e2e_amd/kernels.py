@@ -231,8 +231,9 @@ def _strided_rows(t, H, dk):
     return t.stride(0)
 
 
-def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None, drop_p=0.0, drop_seed=0):
-    """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer)."""
+def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=None, o=None, lse=None, drop_p=0.0, drop_seed=0, o_lo=None):
+    """q: (B*Tq, H*dk) view, k/v: (B*Tk, H*dk) views (may be column slices of a fused buffer).
+    o_lo: a tensor of o's shape and strides for the low-order piece of the bf16 output (asr_hip.h; hand it to sdpa_bwd), or None."""
     ldq, ldk, ldv = _strided_rows(q, H, dk), _strided_rows(k, H, dk), _strided_rows(v, H, dk)
     assert q.shape[0] == B * Tq and k.shape[0] == B * Tk and v.shape[0] == B * Tk
     assert q.dtype == k.dtype == v.dtype
@@ -241,23 +242,25 @@ def sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal=False, window=-1, scale=No
     o = torch.empty(B * Tq, H * dk, dtype=q.dtype, device=q.device) if o is None else o
     ldo = _strided_rows(o, H, dk)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device) if lse is None else lse
+    assert o_lo is None or (o_lo.dtype == o.dtype == torch.bfloat16 and o_lo.shape == o.shape and o_lo.stride() == o.stride())
     scale = float(dk) ** -0.5 if scale is None else float(scale)
     e = q.element_size()
     timed("sdpa_fwd", 4.0 * B * H * Tq * Tk * dk, lambda: check(
         lib.asr_sdpa_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(k_len), B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo,
-                         int(causal), int(window), scale, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_fwd"),
+                         int(causal), int(window), scale, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(o_lo), _dt(q), _stream()), "asr_sdpa_fwd"),
           2.0 * B * H * (Tq + Tk) * dk * e)          # Q, O + K, V (4 B H T dk e at Tq = Tk)
     return o, lse
 
 
 def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=False, window=-1, scale=None, delta=None,
-             drop_p=0.0, drop_seed=0):
+             drop_p=0.0, drop_seed=0, o_lo=None):
     ldq, ldk, ldv, ldo = (_strided_rows(t, H, dk) for t in (q, k, v, o))
     assert _strided_rows(do, H, dk) == ldo and _strided_rows(dq, H, dk) == ldq
     assert _strided_rows(dk_, H, dk) == ldk and _strided_rows(dv, H, dk) == ldv
     assert q.dtype == k.dtype == v.dtype == o.dtype == do.dtype == dq.dtype == dk_.dtype == dv.dtype
     _chk_i32(k_len)
     _chk_f32(lse)
+    assert o_lo is None or (o_lo.dtype == o.dtype == torch.bfloat16 and o_lo.shape == o.shape and o_lo.stride() == o.stride())
     if delta is None:      # scratch: row sums of dO o O, or the band kernel's dQ partials of the tiles on a key-block boundary
         need = lib.asr_sdpa_bwd_workspace_bytes(B, H, Tq, Tk, dk, int(causal), int(window), _dt(q))
         delta = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
@@ -266,7 +269,7 @@ def sdpa_bwd(q, k, v, o, do, lse, k_len, B, H, Tq, Tk, dk, dq, dk_, dv, causal=F
     timed("sdpa_bwd", 10.0 * B * H * Tq * Tk * dk, lambda: check(
         lib.asr_sdpa_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), delta.numel() * 4, _p(dq), _p(dk_), _p(dv), _p(k_len),
                          B, H, Tq, Tk, dk, ldq, ldk, ldv, ldo, int(causal), int(window), scale, float(drop_p),
-                         int(drop_seed) & 0xFFFFFFFF, _dt(q), _stream()), "asr_sdpa_bwd"),
+                         int(drop_seed) & 0xFFFFFFFF, _p(o_lo), _dt(q), _stream()), "asr_sdpa_bwd"),
           B * H * (4.0 * Tq + 4.0 * Tk) * dk * e)    # Q, O, dO, dQ + K, V, dK, dV (8 x 16.4 MB at config 2); 5 products
     return dq, dk_, dv
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ASR_ABI_VERSION 9
+#define ASR_ABI_VERSION 10
 
 typedef enum { ASR_F32 = 0, ASR_BF16 = 1 } asr_dtype_t;
 
@@ -157,11 +157,16 @@ int asr_add_ln_bwd_reduce_batched(const asr_ln_reduce_item* items, int n, int d,
  * drop_p > 0: dropout on the attention probabilities after the softmax (attention.py:83): the
  * output uses p * keep / (1-p), the normaliser does not.  Mask of (b,h,q,k) = counter hash of
  * (((b*H+h)*Tq+q)*Tk_even + k, drop_seed), Tk_even = Tk rounded up to even.
+ * o_lo (ABI 10; ASR_BF16 only, may be NULL): a second buffer of o's layout that receives the LOW-ORDER piece of the output,
+ * bf16(x - float(bf16(x))) of the fp32 value x whose bf16 rounding is stored in o.  Nothing but asr_sdpa_bwd reads it: with o alone
+ * delta = rowsum(do * o) carries 2^-9 |o| of rounding per coordinate, which dq = sum_j p_j (dp_j - delta) k_j multiplies by the MEAN key
+ * (the reference's fp32 softmax backward has no such term): measured 0.989 instead of >= 0.9995 gradient cosine of the top encoder
+ * layer's Q / K projections at the full-size configuration.  (The generic bf16 path clears o_lo.)
  */
 int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
                  int ldv, int ldo, int causal, int window, float scale, float drop_p,
-                 uint32_t drop_seed, int dtype, void* stream);
+                 uint32_t drop_seed, void* o_lo, int dtype, void* stream);
 
 /* Backward: given do (same layout as o) computes dq, dk, dv (layouts/strides of q, k, v).
  * delta: f32 scratch of delta_bytes >= asr_sdpa_bwd_workspace_bytes(...) bytes, written by the call: (B, H, Tq) row sums
@@ -174,7 +179,7 @@ int asr_sdpa_bwd(const void* q, const void* k, const void* v, const void* o, con
                  const float* lse, float* delta, size_t delta_bytes, void* dq, void* dk_, void* dv,
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
                  int ldv, int ldo, int causal, int window, float scale, float drop_p,
-                 uint32_t drop_seed, int dtype, void* stream);
+                 uint32_t drop_seed, const void* o_lo, int dtype, void* stream);      /* o_lo: what asr_sdpa_fwd wrote there, or NULL */
 
 /* Test helpers: materialise the keep masks the kernels regenerate (1 = kept), uint8.
  * asr_dropout_mask: (rows, cols) mask of the LayerNorm / embedding sites;
@@ -501,6 +506,8 @@ typedef struct asr_dec_layer_plan {
                                               (B*T, kv_dgrad_cols) at row stride ld_kv_c and w_kv_c_T = the group's (d, kv_dgrad_cols) slice of the
                                               transposed weight; the other layers of the group pass d_enc = NULL */
     const void* g_kv_group;
+    /* ABI 10: the low-order pieces of the two attention outputs (asr_sdpa_fwd's o_lo), (M, H dk) each, or NULL */
+    void *ctx_s_lo, *ctx_c_lo;
 } asr_dec_layer_plan;
 int asr_decoder_layer_fwd(const asr_dec_layer_plan* plan, void* stream);
 /* (dy, dy2): gradient wrt y_f (dy2 may be NULL; the two are added).  Results: plan->dx_s and plan->dz_s = gradient wrt x_in through the

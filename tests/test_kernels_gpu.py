@@ -241,6 +241,45 @@ def test_sdpa_bwd_short_causal_heads_reach_the_rounding_floor(K, T, ragged):
     assert one_minus_cos(dv, vr.grad) < 2e-5, one_minus_cos(dv, vr.grad)
 
 
+@pytest.mark.parametrize("T,window", [(500, -1), (700, 60)])
+def test_sdpa_bwd_delta_from_both_pieces_of_the_output(K, T, window):
+    """asr_sdpa_fwd's o_lo (ABI 10): where the rows of K and of V share a component (here: one common vector of the noise's size - a bias
+    behind a LayerNorm does it in the model; twice the noise here) the bf16 rounding of O enters dQ through delta multiplied by the MEAN key, which the true
+    gradient does not contain: 1 - cos(dQ) 7e-4 with O alone, 2e-5 with the low-order piece (tools/sdpa_delta_forms.py emulates the forms
+    in fp64; at full size the top encoder layer's Q / K projection gradients went 0.989 -> 0.9998).  T = 500: the fused single-pass
+    backward; T = 700 with a band: the tiled forward and the dQ + dK/dV kernel pair."""
+    B, H, dk = 2, 4, 64
+    d = H * dk
+    g = torch.Generator().manual_seed(T)
+    q, do = (torch.randn(B * T, d, generator=g, dtype=torch.float64) for _ in range(2))
+    k = torch.randn(B * T, d, generator=g, dtype=torch.float64) + 2.0 * torch.randn(1, d, generator=g, dtype=torch.float64)
+    v = torch.randn(B * T, d, generator=g, dtype=torch.float64) + 2.0 * torch.randn(1, d, generator=g, dtype=torch.float64)
+    klen = torch.tensor([T, T - 37], dtype=torch.int32)
+    qr, kr, vr = (x.reshape(B, T, H, dk).clone().requires_grad_(True) for x in (q, k, v))
+    o_ref, _ = sdpa_ref(qr, kr, vr, klen, False, window, dk ** -0.5)
+    (o_ref * do.reshape(B, T, H, dk)).sum().backward()
+    qb, kb, vb, dob = (x.bfloat16().to(DEV) for x in (q, k, v, do))
+    valid = (torch.arange(T)[None, :] < klen[:, None]).reshape(B * T).to(DEV)
+    err = {}
+    for lo in (False, True):
+        o_lo = torch.full_like(qb, float("nan")) if lo else None
+        o, lse = K.sdpa_fwd(qb, kb, vb, klen.to(DEV), B, H, T, T, dk, False, window, o_lo=o_lo)
+        if lo:      # the two pieces together are the kernel's fp32 output to ~2^-17: against the fp64 output of the SAME rounded inputs the pair is
+            # several times closer than o alone (what is left is the bf16 rounding of the probabilities in the P V product)
+            with torch.no_grad():
+                o_rb, _ = sdpa_ref(*(x.double().cpu().reshape(B, T, H, dk) for x in (qb, kb, vb)), klen, False, window, dk ** -0.5)
+            o_rb = o_rb.reshape(B * T, d).to(DEV)[valid]
+            e_pair, e_hi = float(((o.double() + o_lo.double())[valid] - o_rb).abs().max()), float((o.double()[valid] - o_rb).abs().max())
+            assert e_pair < 0.35 * e_hi, (e_pair, e_hi)
+            assert float(o_lo[valid].abs().max()) <= float(o[valid].abs().max()) * 2.0 ** -8
+        dq, dk_, dv = (torch.full_like(qb, float("nan")) for _ in range(3))
+        K.sdpa_bwd(qb, kb, vb, o, dob, lse, klen.to(DEV), B, H, T, T, dk, dq, dk_, dv, False, window, o_lo=o_lo)
+        a, r = dq.double()[valid].flatten(), qr.grad.reshape(B * T, d).to(DEV)[valid].flatten()
+        err[lo] = 1.0 - float(torch.nn.functional.cosine_similarity(a, r, dim=0))
+        assert torch.isfinite(dk_).all() and torch.isfinite(dv).all()
+    assert err[True] < 2e-4 and err[True] < 0.2 * err[False], err
+
+
 def test_sdpa_bf16_integer_exact(K):
     """Layout check with exact small-integer data (guide section 3: asymmetric operands): with
     one visible key per query the output must equal that key's V row exactly."""

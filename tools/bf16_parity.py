@@ -7,15 +7,17 @@ from oracle import ref_model as R
 from tests.test_model_gpu import build, oracle_case, to_pack, cos
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "joint"
-over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=2)
+FULL = os.environ.get("FULL", "0") == "1"      # BASELINE configs[2] / [1] at full size (B 32, T 500, V 4232, 6 layers): ~10 s of oracle on 16 host cores
+over = dict(d_model=512, hidden_size=64, num_head=8, ff_size=1024, layer_num=6 if FULL else 2)
 over.update(dict(ctc_weight=0.3) if mode == "joint" else dict(use_decoder=False, ctc_weight=1.0))
-cfg, sd, batch = oracle_case(4, 136, 80, 56, 12, over, seed=9)
+cfg, sd, batch = oracle_case(32, 500, 80, 4232, 17, over, seed=13) if FULL else oracle_case(4, 136, 80, 56, 12, over, seed=9)
+V = 4232 if FULL else 56
 if "decoder.tgt_word_emb.weight" in sd:
     sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
     sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
 ref = R.RefTrainer(sd, cfg, warmup=25).iterate(batch)
-for dtype in ("fp32", "bf16"):
-    model = build(cfg, 56, "TransformerCTC" if mode == "ctc_only" else "TransformerOffical", dtype=dtype).cuda()
+for dtype in os.environ.get("DTYPES", "fp32,bf16").split(","):
+    model = build(cfg, V, "TransformerCTC" if mode == "ctc_only" else "TransformerOffical", dtype=dtype).cuda()
     model.load_state_dict(sd)
     model._ensure_engine("cuda")
     model.zero_flat_grads()

@@ -19,11 +19,13 @@ qkv = torch.randn(B * T, 3 * d, device="cuda").bfloat16()
 q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
 klen = torch.full((B,), T, dtype=torch.int32, device="cuda")
 DROP = float(os.environ.get("DROP", "0"))      # attention dropout
-o, lse = K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, drop_p=DROP, drop_seed=7)
+LO = os.environ.get("LO", "1") == "1"      # with the low-order piece of O (the training step's default)
+o_lo = torch.empty(B * T, d, device="cuda", dtype=torch.bfloat16) if LO else None
+o, lse = K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, drop_p=DROP, drop_seed=7, o_lo=o_lo)
 do = torch.randn_like(o)
 dqkv = torch.empty_like(qkv)
 fl = 4.0 * B * H * T * T * dk
-t = timeit(lambda: K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, o=o, lse=lse, drop_p=DROP, drop_seed=7))
+t = timeit(lambda: K.sdpa_fwd(q, k, v, klen, B, H, T, T, dk, False, window, o=o, lse=lse, drop_p=DROP, drop_seed=7, o_lo=o_lo))
 print(f"fwd  {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s  {4 * B * T * d * 2 / t / 1e6:6.2f} TB/s algorithmic")
-t = timeit(lambda: K.sdpa_bwd(q, k, v, o, do, lse, klen, B, H, T, T, dk, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], False, window, drop_p=DROP, drop_seed=7))
+t = timeit(lambda: K.sdpa_bwd(q, k, v, o, do, lse, klen, B, H, T, T, dk, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], False, window, drop_p=DROP, drop_seed=7, o_lo=o_lo))
 print(f"bwd  {t:7.1f} us  {2.5 * fl / t / 1e6:6.0f} TF/s (5 products: algorithmic)  {8 * B * T * d * 2 / t / 1e6:6.2f} TB/s algorithmic")
