@@ -605,10 +605,13 @@ class Engine:
         self._arm_covers_pending = False      # set by _dec_exec_bwd while it collects a layer's weight gradients behind its armed last kernel
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
-        # ASR_SDPA_LO=0: the attention backward takes delta = rowsum(dO o O) from the bf16 O alone (rounds 1 - 4).  Default: the forward pass of a
+        # ASR_SDPA_LO=0: the attention backward takes delta = rowsum(dO o O) from the bf16 O alone (rounds 1 - 4); "enc" / "cross": only the encoder's
+        # attention / that and the cross attention (A/B: 5.03 / 5.09 / 5.11 / 5.11 ms for 0 / enc / cross / 1 on one box, joint step).  Default: the forward pass of a
         # training step also stores O's low-order piece (16 MB per encoder layer at the headline shapes) and delta uses both - where K and V rows
         # share a component (a bias behind a LayerNorm) the rounding of O otherwise reaches dQ multiplied by the mean key (sdpa.hip: store_rows_T_lo)
-        self.sdpa_lo = os.environ.get("ASR_SDPA_LO", "1") == "1"
+        self.sdpa_lo = os.environ.get("ASR_SDPA_LO", "1") in ("1", "enc", "cross")
+        self.sdpa_lo_dec = os.environ.get("ASR_SDPA_LO", "1") in ("1", "cross")      # "enc": the encoder's attention only, "cross": + the cross attention (A/B)
+        self.sdpa_lo_self = os.environ.get("ASR_SDPA_LO", "1") == "1"
         self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
@@ -1079,8 +1082,10 @@ class Engine:
                      part_s=torch.empty(part_bytes, dtype=torch.uint8, device=dev))
             if drop:      # pre-residual dropout: the gradient wrt a projection's output is its own tensor
                 t.update(g_o=bf(M, d), g_ac=bf(M, d), g_as=bf(M, d))
-            if self.sdpa_lo:      # low-order pieces of the two attention outputs (asr_sdpa_fwd's o_lo)
-                t.update(ctx_s_lo=bf(M, hd), ctx_c_lo=bf(M, hd))
+            if self.sdpa_lo_dec:      # low-order pieces of the two attention outputs (asr_sdpa_fwd's o_lo)
+                t.update(ctx_c_lo=bf(M, hd))
+                if self.sdpa_lo_self:
+                    t.update(ctx_s_lo=bf(M, hd))
             pl = _lib.DecLayerPlan()
             pl.B, pl.To, pl.T, pl.d, pl.H, pl.dk, pl.ff = B, To, T, d, H, self.dk, ff
             pl.ld_kv_c = self.L * 2 * hd
