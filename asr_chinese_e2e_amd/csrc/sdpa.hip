@@ -1021,8 +1021,8 @@ constexpr int FBS = 64;                                       // row stride in e
 constexpr int FB_K_BYTES = FB_KEYS * FBS * 2;                 // 65536
 constexpr int FB_DS_BYTES = FB_KEYS * FB_QT * 2;              // 32768 per buffer
 constexpr int FB_TILE_ELEMS = FB_QT * FBS;
-constexpr int FB_STATS = (2 * 64 + 32) * 4;                   // [2 buffers][-lse log2e (32) | -delta (32)] + a row of -1e30
-constexpr int FB_LDS = FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2 + FB_STATS;   // 148096 B
+constexpr int FB_STATS = (2 * 64 + 32 + 64) * 4;              // [2 buffers][-lse log2e + q . mean key (32) | -delta (32)] + a row of -1e30 + the mean key (64)
+constexpr int FB_LDS = FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2 + FB_STATS;   // 148352 B
 constexpr int FB_VIMG_BYTES = 64 * FBS * 2;                   // + V of <= 64 keys for the short causal heads' delta pass
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
@@ -1069,6 +1069,10 @@ __device__ __forceinline__ bf16x8 frag_tr16(const bf16_t* img, int row0, int col
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * LD));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+__device__ __forceinline__ uint32_t scale_sub_bf16_pair(uint32_t x, float f, float sub_lo, float sub_hi) {      // (x * f - sub) per half
+    const bf16_t lo = (bf16_t)(__uint_as_float(x << 16) * f - sub_lo), hi = (bf16_t)(__uint_as_float(x & 0xffff0000u) * f - sub_hi);
+    return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+}
 __device__ __forceinline__ uint32_t scale_bf16_pair(uint32_t x, float f) {
     const bf16_t lo = (bf16_t)(__uint_as_float(x << 16) * f), hi = (bf16_t)(__uint_as_float(x & 0xffff0000u) * f);
     return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
@@ -1104,13 +1108,16 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     bf16_t* tiles = (bf16_t*)(smem_fb + FB_K_BYTES + 2 * FB_DS_BYTES);
     float* stats = (float*)(smem_fb + FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2);
     float* s_neg = stats + 128;
+    float* kbar = stats + 160;      // the head's mean key times scale * log2(e) (zeros for BAND)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
     const bf16_t* dob = d_o + (size_t)b * Tq * ldo + h * DK;
     const bf16_t* ob = o + (size_t)b * Tq * ldo + h * DK;
-    const bf16_t* olb = (o_lo ? o_lo : o) + (size_t)b * Tq * ldo + h * DK;      // the low-order piece of O (store_rows_T_lo); without one the load below is unused
-    const bool has_lo = o_lo != nullptr;
+    // BAND only: the low-order piece of O (store_rows_T_lo) for delta - the remedies of the one-block form below (centred keys, dK's mean over the
+    // keys taken out) need ONE mean for all the keys of a head, which no workgroup of the band form holds.  Without a piece the load is unused.
+    const bf16_t* olb = ((BAND && o_lo) ? o_lo : o) + (size_t)b * Tq * ldo + h * DK;
+    const bool has_lo = BAND && o_lo != nullptr;
     const bf16_t* kb = k + ((size_t)b * Tkg + kblk0) * ldk + h * DK;
     const bf16_t* vb = v + ((size_t)b * Tkg + kblk0) * ldv + h * DK;
     const float* lseb = lse + ((size_t)b * H + h) * Tq;
@@ -1135,6 +1142,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     }
     for (int c = tid; c < 2 * FB_DS_BYTES / 16; c += FB_THREADS) *(u32x4*)((char*)dSimg + c * 16) = zero4;      // under the loads' latency
     if (tid < 32) s_neg[tid] = -1.0e30f;
+    if (BAND && tid < 64) kbar[tid] = 0.f;      // read by FB_COMMIT's Q half: behind the barrier in front of the first commit
     bf16_t* Vimg = (bf16_t*)(smem_fb + FB_LDS);      // short causal heads only (FB_VIMG_BYTES more LDS in that launch): V of the 64 keys, laid out as K's image
     if constexpr (!DROP && MASKED && !BAND) {
         if (Tk <= 64) {
@@ -1165,7 +1173,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     const bool is_do = tid >= 256;
     const bf16_t* srcA = is_do ? dob : qb;      // one code path for both halves of the workgroup
     const size_t ldA = is_do ? (size_t)ldo : (size_t)ldq;
-    u32x4 pa = zero4, po = zero4, po2 = zero4;
+    u32x4 pa = zero4, po = zero4, po2 = zero4;      // po2: BAND only
     float pl = 0.f;
     // FB_PREFETCH only ISSUES the loads of a tile (rows clamped into the matrix, no use of the loaded values); FB_COMMIT, a tile later,
     // zeroes what lies past the end and stores the tile.  With the selects on the loaded values written next to the loads the compiler
@@ -1176,26 +1184,39 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         pa = *(const u32x4*)(srcA + row_ * ldA + pch * 8);                                                \
         po = *(const u32x4*)(ob + row_ * ldo + pch * 8);                                                  \
         if (has_lo) po2 = *(const u32x4*)(olb + row_ * ldo + pch * 8);                                    \
-        pl = lseb[min((Q0) + (tid & 31), Tq - 1)];                                                        \
+        pl = lseb[min((Q0) + prow, Tq - 1)];                                                              \
     } while (0)
     // rows past the end / rows that saw no key get -1e30: p = 0.  (Every thread loads one lse value: no divergent path.)
 #define FB_COMMIT(BUF, Q0)                                                                                \
     do {                                                                                                  \
         if ((Q0) + prow >= Tq) { pa = zero4; po = zero4; po2 = zero4; }                                   \
-        const float pl_ = ((Q0) + (tid & 31) >= Tq || pl == -INFINITY) ? -1.0e30f : -pl * LOG2E;          \
+        const float pl_ = ((Q0) + prow >= Tq || pl == -INFINITY) ? -1.0e30f : -pl * LOG2E;                \
         bf16_t* T_ = tiles + (BUF) * 2 * FB_TILE_ELEMS + (is_do ? FB_TILE_ELEMS : 0);                     \
         *(u32x4*)(T_ + prow * FBS + ((pch ^ ff_swz(prow)) << 3)) = pa;                                                         \
         float* st_ = stats + (BUF) * 64;                                                                  \
-        float d_ = 0.f;   /* delta = rowsum(dO o O): 8 lanes per row (the Q half computes a throw-away value) */ \
+        /* 8 lanes per row.  dO half: delta = rowsum(dO o O).  Q half: q . (mean key), the shift that the centred K image takes out of the scores */ \
+        float x_[8];                                                                                      \
+        if (is_do) {                                                                                      \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                            \
+                x_[2 * e_] = __uint_as_float(po[e_] << 16) + (BAND ? __uint_as_float(po2[e_] << 16) : 0.f);             \
+                x_[2 * e_ + 1] = __uint_as_float(po[e_] & 0xffff0000u) + (BAND ? __uint_as_float(po2[e_] & 0xffff0000u) : 0.f); \
+            }                                                                                             \
+        } else {                                                                                          \
+            const f32x4_t k0_ = *(const f32x4_t*)(kbar + 8 * pch), k1_ = *(const f32x4_t*)(kbar + 8 * pch + 4); \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { x_[e_] = k0_[e_]; x_[4 + e_] = k1_[e_]; }   \
+        }                                                                                                 \
+        float d_ = 0.f;                                                                                   \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                \
-            d_ += __uint_as_float(pa[e_] << 16) * (__uint_as_float(po[e_] << 16) + __uint_as_float(po2[e_] << 16));                          \
-            d_ += __uint_as_float(pa[e_] & 0xffff0000u) * (__uint_as_float(po[e_] & 0xffff0000u) + __uint_as_float(po2[e_] & 0xffff0000u));  \
+            d_ += __uint_as_float(pa[e_] << 16) * x_[2 * e_];                                             \
+            d_ += __uint_as_float(pa[e_] & 0xffff0000u) * x_[2 * e_ + 1];                                 \
         }                                                                                                 \
         d_ += __shfl_xor(d_, 1, 64);                                                                      \
         d_ += __shfl_xor(d_, 2, 64);                                                                      \
         d_ += __shfl_xor(d_, 4, 64);                                                                      \
-        if (is_do && pch == 0) st_[32 + prow] = -d_;                                                      \
-        if (tid < FB_QT) st_[tid] = pl_;                                                                  \
+        if (pch == 0) {                                                                                   \
+            if (is_do) st_[32 + prow] = -d_;                                                              \
+            else st_[prow] = pl_ + d_;      /* -lse log2(e) + q . mean key: p = exp2(S' + this), S' from the centred keys */ \
+        }                                                                                                 \
     } while (0)
 
     f32x16 dka[2][2], dva[2][2];
@@ -1419,13 +1440,61 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     const int t_lo = BAND ? max(0, (kblk0 - (FB_QT - 1) - window + FB_QT - 1) / FB_QT) : 0;
     const int t_hi = BAND ? min(ntiles, (kblk0 + Tk + window + FB_QT - 1) / FB_QT) : ntiles;
     FB_PREFETCH(t_lo * FB_QT);
+    // ---- the K image holds the keys MINUS their mean over the head (times scale * log2(e)).  Why: dQ = sum_j dS_j K_j with sum_j dS_j = 0
+    // in exact arithmetic, so a component common to all keys contributes nothing - but dS_j = p_j (dP_j - delta) carries delta's error eps
+    // (delta = rowsum(dO o O) from the bf16-ROUNDED O: 2^-9 |O| per coordinate) into every key alike, and the product with the uncentred
+    // keys puts eps * (mean key) into dQ: where the rows of K and of V share a component (a bias behind a LayerNorm) that term was the
+    // whole error - gradient cosine 0.989 of the top encoder layer's Q / K projections at the full-size configuration, 0.90 for the
+    // decoder's cross attention.  With centred keys eps only meets (p-weighted mean key - mean key).  1 - cos(dQ), fp64 emulation at 500
+    // keys, common component 1 / 3 sigma: 7e-4 / 5e-2 uncentred, 1e-5 / 3e-5 centred, floor from rounding the inputs 7e-6 / 3e-5
+    // (tools/sdpa_delta_forms_500.py) - better than a delta from an fp32 O (2e-5 / 2e-4), at no memory traffic.  The scores lose the
+    // per-query constant q . mean key, which FB_COMMIT adds to the row's -lse log2(e); the centred image also rounds smaller numbers.
+    // BAND: no centring (the two key blocks a tile's band touches would need one common mean).
+    float kb8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // this thread's chunk (tid & 7) of the mean key
+    if (!BAND) {
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < KPIECES; ++i) {      // K * scale * log2(e) -> LDS (rows >= klen stay zero)
+        for (int i = 0; i < KPIECES; ++i) {
+            const int row = (tid + i * FB_THREADS) >> 3;
+            if (row < klen) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    part[2 * e] += __uint_as_float(kx[i][e] << 16);
+                    part[2 * e + 1] += __uint_as_float(kx[i][e] & 0xffff0000u);
+                }
+            }
+        }
+        // lanes l, l + 8, .., l + 56 of a wave hold the same chunk: three exchanges, then the eight waves' sums through LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            part[e] += __shfl_xor(part[e], 8, 64);
+            part[e] += __shfl_xor(part[e], 16, 64);
+            part[e] += __shfl_xor(part[e], 32, 64);
+        }
+        float* red = (float*)tiles;      // [FB_WAVES][64] floats in the query tiles' space, which is written only after the barriers below
+        if (lane < 8) {
+            *(f32x4_t*)(red + w * 64 + 8 * lane) = f32x4_t{part[0], part[1], part[2], part[3]};
+            *(f32x4_t*)(red + w * 64 + 8 * lane + 4) = f32x4_t{part[4], part[5], part[6], part[7]};
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < FB_WAVES; ++wv) sum += red[wv * 64 + tid];
+            kbar[tid] = klen > 0 ? sum / (float)klen * sc2 : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kb8[e] = kbar[8 * (tid & 7) + e];
+    }
+#pragma unroll
+    for (int i = 0; i < KPIECES; ++i) {      // (K - mean) * scale * log2(e) -> LDS (rows >= klen stay zero)
         const int c = tid + i * FB_THREADS, row = c >> 3, ch = c & 7;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) kx[i][e] = row < klen ? scale_bf16_pair(kx[i][e], sc2) : 0u;
+        for (int e = 0; e < 4; ++e) kx[i][e] = row < klen ? scale_sub_bf16_pair(kx[i][e], sc2, kb8[2 * e], kb8[2 * e + 1]) : 0u;
         *(u32x4*)(Kimg + row * FBS + ((ch ^ ff_swz(row)) << 3)) = kx[i];
     }
+    if (BAND) __syncthreads();      // kbar = 0
     FB_COMMIT(t_lo & 1, t_lo * FB_QT);
     if (t_lo + 1 < t_hi) FB_PREFETCH((t_lo + 1) * FB_QT);
     __syncthreads();         // K image, zeroed dS images, first tile
@@ -1445,12 +1514,57 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     }
 #undef FB_PREFETCH
 #undef FB_COMMIT
+    // dV leaves first: its stores run under the reduction below (with both behind the two barriers the whole chip stored at once: +4 us)
     if (active) {
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk) {
-            store_rows_T(dka[kbk], scale, dk_ + ((size_t)b * Tkg + kblk0) * ldk + h * DK, ldk, kk0 + 32 * kbk, Tk, lane);
-            store_rows_T(dva[kbk], 1.f, dv + ((size_t)b * Tkg + kblk0) * ldv + h * DK, ldv, kk0 + 32 * kbk, Tk, lane);
+        for (int kbk = 0; kbk < 2; ++kbk) store_rows_T(dva[kbk], 1.f, dv + ((size_t)b * Tkg + kblk0) * ldv + h * DK, ldv, kk0 + 32 * kbk, Tk, lane);
+    }
+    // ---- the rows of dK sum to zero over the keys of a head (sum_j dK_j = sum_q Q_q sum_j dS_qj, and every query's dS sums to zero over
+    // the keys it sees, whatever the mask): what the accumulators hold beyond that is delta's error again - dS_qj = p_qj (dP_qj - delta_q)
+    // adds -eps_q p_qj Q_q to dK_j, for near-uniform p the SAME vector for every key, and the K projection's weight gradient
+    // dW_k = sum_j dK_j x_j^T multiplies that vector by T times the mean input row: the top encoder layer's w_ks measured 0.988 (cosine
+    // against the oracle at full size) with the keys centred for dQ and 0.9998 once this mean is taken out.  fp64 emulation at 500 keys,
+    // common components of 1 - 3 sigma in Q, K, V and the layer input: 1 - cos(dW_k) 7e-4 .. 4e-2 as computed, 7e-6 .. 2e-5 with the
+    // mean over the keys removed - the floor of the inputs' rounding, below a delta from the kernel's own p and dP (tools/sdpa_dk_mean.py).
+    // Once per kernel: 32 half-wave sums by DPP, 2.5 KiB through LDS, two barriers: +0.5 us at the encoder's shape, +2.5 us for the
+    // decoder's cross attention (A/B in one process against the kernel without it).  BAND: the sum is over ALL key blocks - not done.
+    // Short causal heads without dropout took delta from their own p and dP (phase_keys): nothing to remove.
+    const bool own_delta = !DROP && MASKED && !BAND && Tk <= 64;
+    if (!BAND && !own_delta) {
+        float* red = (float*)tiles;      // the query tiles are dead: every wave's last key phase lies in front of the loop's last barrier
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = dka[0][db][i] + dka[1][db][i];      // this wave's 64 keys (rows of padded keys are zeros); lanes = the 32 keys of a block
+                v += wave_dpp<0xB1>(v);             // quad_perm [1,0,3,2]
+                v += wave_dpp<0x4E>(v);             // quad_perm [2,3,0,1]
+                v += wave_dpp<0x141>(v);            // row_half_mirror
+                v += wave_dpp<0x140>(v);            // row_mirror: every lane of a 16-lane row holds the row's sum
+                v += wave_dpp<0x142, 0xA>(v);       // row_bcast15 into rows 1 and 3: lanes 16 - 31 / 48 - 63 hold the half-wave's sum
+                if ((lane & 31) == 16) red[w * 64 + 32 * db + acc_row(i, lane)] = v;
+            }
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < FB_WAVES; ++wv) sum += red[wv * 64 + tid];
+            red[FB_WAVES * 64 + tid] = klen > 0 ? sum / (float)klen : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float m = red[FB_WAVES * 64 + 32 * db + acc_row(i, lane)];
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+                    if (kk0 + 32 * kbk + (lane & 31) < klen) dka[kbk][db][i] -= m;
+            }
+    }
+    if (active) {
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) store_rows_T(dka[kbk], scale, dk_ + ((size_t)b * Tkg + kblk0) * ldk + h * DK, ldk, kk0 + 32 * kbk, Tk, lane);
     }
 }
 
@@ -1739,7 +1853,7 @@ extern "C" int asr_sdpa_bwd(const void* q, const void* k, const void* v, const v
             (void)hipFuncSetAttribute((const void*)sdpa_bwd_fused_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
             attr = true;
         }
-#define FB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, (const bf16_t*)o_lo, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
+#define FB_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, (const bf16_t*)o, (const bf16_t*)nullptr, lse, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
         const bool masked = causal || window >= 0;
         // the only kernel of this path: it may carry an armed completion event (asr_stream_arm)
         if (dthr && masked) asr_launch_armed(sdpa_bwd_fused_bf16_kernel<true, true>, dim3(B * H), dim3(FB_THREADS), FB_LDS, st, FB_ARGS, (float*)nullptr, 0);

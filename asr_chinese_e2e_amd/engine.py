@@ -605,13 +605,16 @@ class Engine:
         self._arm_covers_pending = False      # set by _dec_exec_bwd while it collects a layer's weight gradients behind its armed last kernel
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
-        # ASR_SDPA_LO=0: the attention backward takes delta = rowsum(dO o O) from the bf16 O alone (rounds 1 - 4); "enc" / "cross": only the encoder's
-        # attention / that and the cross attention (A/B: 5.03 / 5.09 / 5.11 / 5.11 ms for 0 / enc / cross / 1 on one box, joint step).  Default: the forward pass of a
-        # training step also stores O's low-order piece (16 MB per encoder layer at the headline shapes) and delta uses both - where K and V rows
-        # share a component (a bias behind a LayerNorm) the rounding of O otherwise reaches dQ multiplied by the mean key (sdpa.hip: store_rows_T_lo)
-        self.sdpa_lo = os.environ.get("ASR_SDPA_LO", "1") in ("1", "enc", "cross")
-        self.sdpa_lo_dec = os.environ.get("ASR_SDPA_LO", "1") in ("1", "cross")      # "enc": the encoder's attention only, "cross": + the cross attention (A/B)
-        self.sdpa_lo_self = os.environ.get("ASR_SDPA_LO", "1") == "1"
+        # ASR_SDPA_LO=1 (default 0; "enc" / "cross": only the encoder's attention / that and the cross attention): the forward pass of a training step
+        # also stores the low-order piece of the bf16 attention output (16 MB per encoder layer at the headline shapes) and the backward pass takes
+        # delta = rowsum(dO o O) from both pieces.  That was the first remedy for what the full-size parity test found (the rounding of O reaching dQ
+        # and dK multiplied by the mean key / the mean query: sdpa.hip, store_rows_T_lo) and cost 2 % of the step (5.03 / 5.09 / 5.11 / 5.11 ms for
+        # 0 / enc / cross / 1 on one box); the single-pass backward kernel now centres the keys and takes the mean over the keys out of dK, which
+        # reaches the same parity (0.99982 / 0.99982 against 0.99979 / 0.99979 for the top encoder layer's w_qs / w_ks) without the traffic.
+        # Heads of more than 512 keys (the long-form configuration's band form of that kernel, the two-kernel path) always get the piece.
+        self.sdpa_lo = os.environ.get("ASR_SDPA_LO", "0") in ("1", "enc", "cross")
+        self.sdpa_lo_dec = os.environ.get("ASR_SDPA_LO", "0") in ("1", "cross")
+        self.sdpa_lo_self = os.environ.get("ASR_SDPA_LO", "0") == "1"
         self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
@@ -853,7 +856,8 @@ class Engine:
         pf, sf = self._drop(site + 1)      # after fc, before residual + LN (attention.py:59)
         # the low-order piece of the bf16 attention output, for the backward pass's delta only (asr_hip.h: asr_sdpa_fwd's o_lo): a training step's
         # forward pass (grad mode) writes it, an evaluation pass does not
-        ctx_lo = torch.empty(B * Tq, hd, dtype=q.dtype, device=q.device) if (self.sdpa_lo and q.dtype == torch.bfloat16 and torch.is_grad_enabled()) else None
+        # (always for more than 512 keys: the band form of the backward kernel and the two-kernel path have no other remedy - engine.sdpa_lo)
+        ctx_lo = torch.empty(B * Tq, hd, dtype=q.dtype, device=q.device) if ((self.sdpa_lo or Tk > 512) and q.dtype == torch.bfloat16 and torch.is_grad_enabled()) else None
         ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa, o_lo=ctx_lo)
         a = m.fc.fwd(ctx)
         y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)

@@ -161,7 +161,9 @@ int asr_add_ln_bwd_reduce_batched(const asr_ln_reduce_item* items, int n, int d,
  * bf16(x - float(bf16(x))) of the fp32 value x whose bf16 rounding is stored in o.  Nothing but asr_sdpa_bwd reads it: with o alone
  * delta = rowsum(do * o) carries 2^-9 |o| of rounding per coordinate, which dq = sum_j p_j (dp_j - delta) k_j multiplies by the MEAN key
  * (the reference's fp32 softmax backward has no such term): measured 0.989 instead of >= 0.9995 gradient cosine of the top encoder
- * layer's Q / K projections at the full-size configuration.  (The generic bf16 path clears o_lo.)
+ * layer's Q / K projections at the full-size configuration.  The single-pass backward kernel (Tk <= 512) has its own remedy (centred keys,
+ * dK's mean over the keys removed) and ignores the piece; the band form (Tk > 512 inside a window) and the two-kernel path read it.
+ * (The generic bf16 path clears o_lo.)
  */
 int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
