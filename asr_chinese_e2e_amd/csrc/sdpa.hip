@@ -568,7 +568,7 @@ template <bool DROP, bool MASKED>
 __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                          bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
                                                                          int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, int causal, int window, float scale,
-                                                                         uint32_t dseed, uint32_t dthr, float dscale, bf16_t* __restrict__ o_lo) {
+                                                                         uint32_t dseed, uint32_t dthr, float dscale) {
     extern __shared__ __attribute__((aligned(1024))) char smem_ff[];
     const char* Kimg = smem_ff;
     const char* Vimg = smem_ff + FF_IMG;
@@ -795,7 +795,6 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
             else l = lacc[0];      // the contraction ran over all 64 keys of every tile: no cross-half add
             const float inv = l > 0.f ? 1.f / l : 0.f;
             store_rows_T(oacc, inv, ob, ldo, q0, Tq, lane);
-            if (o_lo) store_rows_T_lo(oacc, inv, o_lo + (size_t)b * Tq * ldo + h * DK, ldo, q0, Tq, lane);
             if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m * sc2 + log2f(l)) * LN2 : -INFINITY;
         }
     }
@@ -816,7 +815,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_fused_bf16_kernel(cons
 // better across the two waves of a SIMD).  Opt-in (tuning option "sdpa_pair"); a hand-placed schedule of this body is the open lever.
 __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_pair_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                                         bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ k_len, int H,
-                                                                        int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float scale, bf16_t* __restrict__ o_lo) {
+                                                                        int Tq, int Tk, int ldq, int ldk, int ldv, int ldo, float scale) {
     extern __shared__ __attribute__((aligned(1024))) char smem_ff[];
     const char* Kimg = smem_ff;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -985,7 +984,6 @@ __global__ __launch_bounds__(FF_THREADS, 2) void sdpa_fwd_pair_bf16_kernel(const
             const float l = lacc[bk][0];
             const float inv = l > 0.f ? 1.f / l : 0.f;
             store_rows_T(oacc[bk], inv, ob, ldo, qs, Tq, lane);
-            if (o_lo) store_rows_T_lo(oacc[bk], inv, o_lo + (size_t)b * Tq * ldo + h * DK, ldo, qs, Tq, lane);
             if (lane < 32 && qi < Tq) lse[((size_t)b * H + h) * Tq + qi] = l > 0.f ? (m[bk] * sc2 + log2f(l)) * LN2 : -INFINITY;
         }
     }
@@ -1108,7 +1106,10 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     bf16_t* tiles = (bf16_t*)(smem_fb + FB_K_BYTES + 2 * FB_DS_BYTES);
     float* stats = (float*)(smem_fb + FB_K_BYTES + 2 * FB_DS_BYTES + 4 * FB_TILE_ELEMS * 2);
     float* s_neg = stats + 128;
-    float* kbar = stats + 160;      // the head's mean key times scale * log2(e) (zeros for BAND)
+    float* kbar = stats + 160;      // the head's mean key times scale * log2(e)
+    // Short causal heads without dropout take delta from their own p and dP (phase_keys): exact, so neither remedy below is needed for them.
+    const bool own_delta = !DROP && MASKED && !BAND && Tk <= 64;
+    const bool centred = !BAND && !own_delta;      // the K image holds the keys minus their mean (workgroup-uniform)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const bf16_t* qb = q + (size_t)b * Tq * ldq + h * DK;
@@ -1142,7 +1143,6 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     }
     for (int c = tid; c < 2 * FB_DS_BYTES / 16; c += FB_THREADS) *(u32x4*)((char*)dSimg + c * 16) = zero4;      // under the loads' latency
     if (tid < 32) s_neg[tid] = -1.0e30f;
-    if (BAND && tid < 64) kbar[tid] = 0.f;      // read by FB_COMMIT's Q half: behind the barrier in front of the first commit
     bf16_t* Vimg = (bf16_t*)(smem_fb + FB_LDS);      // short causal heads only (FB_VIMG_BYTES more LDS in that launch): V of the 64 keys, laid out as K's image
     if constexpr (!DROP && MASKED && !BAND) {
         if (Tk <= 64) {
@@ -1201,9 +1201,11 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
                 x_[2 * e_] = __uint_as_float(po[e_] << 16) + (BAND ? __uint_as_float(po2[e_] << 16) : 0.f);             \
                 x_[2 * e_ + 1] = __uint_as_float(po[e_] & 0xffff0000u) + (BAND ? __uint_as_float(po2[e_] & 0xffff0000u) : 0.f); \
             }                                                                                             \
-        } else {                                                                                          \
+        } else if (centred) {                                                                             \
             const f32x4_t k0_ = *(const f32x4_t*)(kbar + 8 * pch), k1_ = *(const f32x4_t*)(kbar + 8 * pch + 4); \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { x_[e_] = k0_[e_]; x_[4 + e_] = k1_[e_]; }   \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) x_[e_] = 0.f;                                \
         }                                                                                                 \
         float d_ = 0.f;                                                                                   \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                \
@@ -1451,7 +1453,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     // per-query constant q . mean key, which FB_COMMIT adds to the row's -lse log2(e); the centred image also rounds smaller numbers.
     // BAND: no centring (the two key blocks a tile's band touches would need one common mean).
     float kb8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // this thread's chunk (tid & 7) of the mean key
-    if (!BAND) {
+    if (centred) {
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < KPIECES; ++i) {
@@ -1494,7 +1496,6 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
         for (int e = 0; e < 4; ++e) kx[i][e] = row < klen ? scale_sub_bf16_pair(kx[i][e], sc2, kb8[2 * e], kb8[2 * e + 1]) : 0u;
         *(u32x4*)(Kimg + row * FBS + ((ch ^ ff_swz(row)) << 3)) = kx[i];
     }
-    if (BAND) __syncthreads();      // kbar = 0
     FB_COMMIT(t_lo & 1, t_lo * FB_QT);
     if (t_lo + 1 < t_hi) FB_PREFETCH((t_lo + 1) * FB_QT);
     __syncthreads();         // K image, zeroed dS images, first tile
@@ -1528,9 +1529,7 @@ __global__ __launch_bounds__(FB_THREADS, 2) void sdpa_bwd_fused_bf16_kernel(cons
     // mean over the keys removed - the floor of the inputs' rounding, below a delta from the kernel's own p and dP (tools/sdpa_dk_mean.py).
     // Once per kernel: 32 half-wave sums by DPP, 2.5 KiB through LDS, two barriers: +0.5 us at the encoder's shape, +2.5 us for the
     // decoder's cross attention (A/B in one process against the kernel without it).  BAND: the sum is over ALL key blocks - not done.
-    // Short causal heads without dropout took delta from their own p and dP (phase_keys): nothing to remove.
-    const bool own_delta = !DROP && MASKED && !BAND && Tk <= 64;
-    if (!BAND && !own_delta) {
+    if (centred) {
         float* red = (float*)tiles;      // the query tiles are dead: every wave's last key phase lies in front of the loop's last barrier
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -1780,12 +1779,14 @@ extern "C" int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o
             (void)hipFuncSetAttribute((const void*)sdpa_fwd_pair_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
             attr = true;
         }
-#define FF_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale, (bf16_t*)o_lo
+        // the backward pass of these shapes (every key of a head in one workgroup) does not read a low-order piece: a buffer given anyway is cleared
+        if (o_lo && hipMemset2DAsync(o_lo, (size_t)ldo * 2, 0, (size_t)H * dk * 2, (size_t)B * Tq, st) != hipSuccess) ASR_FAIL(ASR_EINVAL, "asr_sdpa_fwd: clearing o_lo failed");
+#define FF_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, causal, window, scale, dseed, dthr, dscale
         const bool masked = causal || window >= 0;
         if (dthr && masked) sdpa_fwd_fused_bf16_kernel<true, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (dthr) sdpa_fwd_fused_bf16_kernel<true, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
         else if (masked) sdpa_fwd_fused_bf16_kernel<false, true><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
-        else if (asr_option(ASR_OPT_SDPA_PAIR)) sdpa_fwd_pair_bf16_kernel<<<B * H, FF_THREADS, FF_LDS, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, scale, (bf16_t*)o_lo);
+        else if (asr_option(ASR_OPT_SDPA_PAIR)) sdpa_fwd_pair_bf16_kernel<<<B * H, FF_THREADS, FF_LDS, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, k_len, H, Tq, Tk, ldq, ldk, ldv, ldo, scale);
         else sdpa_fwd_fused_bf16_kernel<false, false><<<B * H, FF_THREADS, FF_LDS, st>>>(FF_ARGS);
 #undef FF_ARGS
     } else if (dtype == ASR_BF16 && mfma_ok(dk, ldq, ldk, ldv, ldo, q, k, v, o)) {

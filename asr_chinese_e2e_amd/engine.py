@@ -605,16 +605,6 @@ class Engine:
         self._arm_covers_pending = False      # set by _dec_exec_bwd while it collects a layer's weight gradients behind its armed last kernel
         self._ln_part, self._ln_pending = {}, []
         self.dec_exec = os.environ.get("ASR_DEC_EXEC", "1") == "1"      # decoder layers through the native launch sequencer (_dec_exec_ok)
-        # ASR_SDPA_LO=1 (default 0; "enc" / "cross": only the encoder's attention / that and the cross attention): the forward pass of a training step
-        # also stores the low-order piece of the bf16 attention output (16 MB per encoder layer at the headline shapes) and the backward pass takes
-        # delta = rowsum(dO o O) from both pieces.  That was the first remedy for what the full-size parity test found (the rounding of O reaching dQ
-        # and dK multiplied by the mean key / the mean query: sdpa.hip, store_rows_T_lo) and cost 2 % of the step (5.03 / 5.09 / 5.11 / 5.11 ms for
-        # 0 / enc / cross / 1 on one box); the single-pass backward kernel now centres the keys and takes the mean over the keys out of dK, which
-        # reaches the same parity (0.99982 / 0.99982 against 0.99979 / 0.99979 for the top encoder layer's w_qs / w_ks) without the traffic.
-        # Heads of more than 512 keys (the long-form configuration's band form of that kernel, the two-kernel path) always get the piece.
-        self.sdpa_lo = os.environ.get("ASR_SDPA_LO", "0") in ("1", "enc", "cross")
-        self.sdpa_lo_dec = os.environ.get("ASR_SDPA_LO", "0") in ("1", "cross")
-        self.sdpa_lo_self = os.environ.get("ASR_SDPA_LO", "0") == "1"
         self._dec_cache = collections.OrderedDict()      # (B, To, T, dropout) -> persistent buffers + plans, least recently used first
         self._block_flush = self.group_wgrad == "block"
         self._in_decoder = False       # "decoder": only the decoder's weight gradients are grouped (one launch per decoder layer)
@@ -854,10 +844,10 @@ class Engine:
             c["q"], c["kv"] = q, kv
         pa, sa = self._drop(site)          # attention probabilities (attention.py:83)
         pf, sf = self._drop(site + 1)      # after fc, before residual + LN (attention.py:59)
-        # the low-order piece of the bf16 attention output, for the backward pass's delta only (asr_hip.h: asr_sdpa_fwd's o_lo): a training step's
-        # forward pass (grad mode) writes it, an evaluation pass does not
-        # (always for more than 512 keys: the band form of the backward kernel and the two-kernel path have no other remedy - engine.sdpa_lo)
-        ctx_lo = torch.empty(B * Tq, hd, dtype=q.dtype, device=q.device) if ((self.sdpa_lo or Tk > 512) and q.dtype == torch.bfloat16 and torch.is_grad_enabled()) else None
+        # Heads of more than 512 keys (the long-form configuration): the forward pass of a training step (grad mode) also stores the low-order piece of
+        # its bf16 output for the backward pass's delta (asr_hip.h: asr_sdpa_fwd's o_lo) - the band form of the backward kernel and the two-kernel path
+        # hold no head-wide mean for the remedies of the one-workgroup form (centred keys, dK's mean removed: sdpa.hip)
+        ctx_lo = torch.empty(B * Tq, hd, dtype=q.dtype, device=q.device) if (Tk > 512 and q.dtype == torch.bfloat16 and torch.is_grad_enabled()) else None
         ctx, lse = K.sdpa_fwd(q, k, v, k_len, B, H, Tq, Tk, dk, causal, window, drop_p=pa, drop_seed=sa, o_lo=ctx_lo)
         a = m.fc.fwd(ctx)
         y, xhat, rstd = K.add_ln_fwd(a, x, m.ln.g, m.ln.b, None, q_lens, B, Tq, xhat=a, drop_p=pf, drop_seed=sf, drop_mode=1)
@@ -1086,10 +1076,6 @@ class Engine:
                      part_s=torch.empty(part_bytes, dtype=torch.uint8, device=dev))
             if drop:      # pre-residual dropout: the gradient wrt a projection's output is its own tensor
                 t.update(g_o=bf(M, d), g_ac=bf(M, d), g_as=bf(M, d))
-            if self.sdpa_lo_dec:      # low-order pieces of the two attention outputs (asr_sdpa_fwd's o_lo)
-                t.update(ctx_c_lo=bf(M, hd))
-                if self.sdpa_lo_self:
-                    t.update(ctx_s_lo=bf(M, hd))
             pl = _lib.DecLayerPlan()
             pl.B, pl.To, pl.T, pl.d, pl.H, pl.dk, pl.ff = B, To, T, d, H, self.dk, ff
             pl.ld_kv_c = self.L * 2 * hd

@@ -163,7 +163,7 @@ int asr_add_ln_bwd_reduce_batched(const asr_ln_reduce_item* items, int n, int d,
  * (the reference's fp32 softmax backward has no such term): measured 0.989 instead of >= 0.9995 gradient cosine of the top encoder
  * layer's Q / K projections at the full-size configuration.  The single-pass backward kernel (Tk <= 512) has its own remedy (centred keys,
  * dK's mean over the keys removed) and ignores the piece; the band form (Tk > 512 inside a window) and the two-kernel path read it.
- * (The generic bf16 path clears o_lo.)
+ * The forward pass WRITES the piece on the tiled path (Tk > 512) and clears it everywhere else.
  */
 int asr_sdpa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                  const int32_t* k_len, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,

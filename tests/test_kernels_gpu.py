@@ -267,7 +267,9 @@ def test_sdpa_bwd_delta_from_both_pieces_of_the_output(K, T, window):
     for lo in (False, True):
         o_lo = torch.full_like(qb, float("nan")) if lo else None
         o, lse = K.sdpa_fwd(qb, kb, vb, klen.to(DEV), B, H, T, T, dk, False, window, o_lo=o_lo)
-        if lo:      # the two pieces together are the kernel's fp32 output to ~2^-17: against the fp64 output of the SAME rounded inputs the pair is
+        if lo and T <= 512:      # the backward pass of these shapes does not read the piece: the forward pass clears the buffer
+            assert not o_lo.any()
+        elif lo:      # the two pieces together are the kernel's fp32 output to ~2^-17: against the fp64 output of the SAME rounded inputs the pair is
             # several times closer than o alone (what is left is the bf16 rounding of the probabilities in the P V product)
             with torch.no_grad():
                 o_rb, _ = sdpa_ref(*(x.double().cpu().reshape(B, T, H, dk) for x in (qb, kb, vb)), klen, False, window, dk ** -0.5)

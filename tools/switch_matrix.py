@@ -13,7 +13,7 @@ DROPOUT = float(os.environ.get("DROPOUT", "0"))
 SETTINGS = [{}, {"ASR_WGRAD_OVERLAP": "0"}, {"ASR_DETERMINISTIC": "1"}, {"ASR_WGRAD_GROUP": "0"}, {"ASR_WGRAD_GROUP": "layer"}, {"ASR_WGRAD_GROUP": "block"},
             {"ASR_WGRAD_GROUP": "pair"}, {"ASR_WGRAD_GROUP": "pair_ffn"}, {"ASR_WGRAD_GROUP": "pair_attn"}, {"ASR_KV_GROUPS": "1"}, {"ASR_KV_GROUPS": "2"},
             {"ASR_KV_GROUPS": "6"}, {"ASR_WGRAD_DEFER": ""}, {"ASR_WGRAD_DEFER": "fc,w2"}, {"ASR_ARMED_FORK": "0"}, {"ASR_DEC_EXEC": "0"},
-            {"ASR_DEC_CU_LIMIT": "0"}, {"ASR_DEC_CU_LIMIT": "96"}, {"ASR_SDPA_LO": "0"}, {"ASR_WGRAD_GROUP": "block", "ASR_WGRAD_DEFER": "w2", "ASR_FUSE_RELU_BWD": "0"}]
+            {"ASR_DEC_CU_LIMIT": "0"}, {"ASR_DEC_CU_LIMIT": "96"}, {"ASR_WGRAD_GROUP": "block", "ASR_WGRAD_DEFER": "w2", "ASR_FUSE_RELU_BWD": "0"}]
 pack = synthetic_pack(B, T, 80, V, seed=27, ragged=True, Lmin=max(2, TO - 3), Lmax=TO, device="cuda", dtype=torch.bfloat16)
 names, ref, ref_loss, bad = None, None, None, 0
 for cfg_name in (("joint", "ctc") if os.environ.get("MODEL", "both") == "both" else (os.environ["MODEL"],)):
