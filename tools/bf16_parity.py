@@ -15,7 +15,10 @@ V = 4232 if FULL else 56
 if "decoder.tgt_word_emb.weight" in sd:
     sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
     sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
-ref = R.RefTrainer(sd, cfg, warmup=25).iterate(batch)
+# ORACLE_BF16_WEIGHTS=1: the oracle runs on the weight MATRICES rounded to bf16 (what the MFMA path multiplies by) - what is left of the difference
+# is then the rounding of activations and of the kernels' intermediates, not of the parameters
+sd_ref = {k: (v.bfloat16().float() if (os.environ.get("ORACLE_BF16_WEIGHTS") == "1" and v.dim() == 2) else v) for k, v in sd.items()}
+ref = R.RefTrainer(sd_ref, cfg, warmup=25).iterate(batch)
 for dtype in os.environ.get("DTYPES", "fp32,bf16").split(","):
     model = build(cfg, V, "TransformerCTC" if mode == "ctc_only" else "TransformerOffical", dtype=dtype).cuda()
     model.load_state_dict(sd)
