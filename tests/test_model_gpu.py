@@ -832,6 +832,13 @@ def test_long_form_window_matches_oracle(dtype):
         # case up to T = 500 (measured 1.7e-4 .. 4.9e-4, >= 2x headroom); here the stated bound is 2e-3 = 2x the measurement.
         assert rel < 2 * BF16_LOSS_RTOL, (float(loss[0]), float(ref["loss"]))
         assert rel_ctc < 2 * BF16_LOSS_RTOL, rel_ctc
+        # Round 5: most of those 9.3e-4 is the rounding of the PARAMETERS, not of the activations: against the oracle run on the weight
+        # matrices rounded to bf16 (the numbers the MFMA path multiplies by) the loss differs by 3.6e-4 (tools/long_form_parity.py) - gate 6e-4.
+        sd16 = {k: (v.bfloat16().float() if v.dim() == 2 else v).double() for k, v in sd.items()}
+        ref16 = R.RefTrainer(sd16, cfg, warmup=25).iterate(b64)
+        rel16 = abs(float(loss[0]) - float(ref16["loss"])) / abs(float(ref16["loss"]))
+        _report("long_form_window_bf16_oracle_on_bf16_weights", dict(loss_rel=rel16))
+        assert rel16 < 6e-4, rel16
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
