@@ -15,6 +15,11 @@ V = 4232 if FULL else 56
 if "decoder.tgt_word_emb.weight" in sd:
     sd["decoder.tgt_word_emb.weight"] = sd["decoder.tgt_word_emb.weight"] * 0.05
     sd["decoder.tgt_word_prj.weight"] = sd["decoder.tgt_word_emb.weight"]
+# SHARP=f: the attention Q / K projection weights times f (sharper attention than at initialisation: softmax rows far from uniform)
+if float(os.environ.get("SHARP", "1")) != 1.0:
+    for k in sd:
+        if ("w_qs.weight" in k or "w_ks.weight" in k):
+            sd[k] = sd[k] * float(os.environ["SHARP"])
 # ORACLE_BF16_WEIGHTS=1: the oracle runs on the weight MATRICES rounded to bf16 (what the MFMA path multiplies by) - what is left of the difference
 # is then the rounding of activations and of the kernels' intermediates, not of the parameters
 sd_ref = {k: (v.bfloat16().float() if (os.environ.get("ORACLE_BF16_WEIGHTS") == "1" and v.dim() == 2) else v) for k, v in sd.items()}
