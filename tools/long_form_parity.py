@@ -1,3 +1,5 @@
+"""The long-form case of tests/test_model_gpu.py (T = 2000, +-50-frame band, joint, 2 layers) in bf16 against the fp64 oracle run on (a) the fp32 weights and
+(b) the weight matrices rounded to bf16: how much of the loss difference is the parameters' rounding.  python tools/long_form_parity.py"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,3 +1,5 @@
+"""Attention forward / backward kernel times at the decoder's shapes (cross: 17 x 500, self: 17 x 17 causal) and the encoder's (500 x 500), with and
+without a low-order output piece (asr_sdpa_fwd's o_lo; only heads of more than 512 keys use it).  ASR_HIP_LIB=<other build> for an A/B in one call."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from asr_chinese_e2e_amd import kernels as K

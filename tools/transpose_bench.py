@@ -1,3 +1,4 @@
+"""Time of the step's batched weight transposes (asr_transpose_batched_bf16 over every matrix of the joint model) and a spot check of three copies."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from asr_chinese_e2e_amd import Models
