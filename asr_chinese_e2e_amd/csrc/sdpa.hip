@@ -1071,10 +1071,6 @@ __device__ __forceinline__ uint32_t scale_sub_bf16_pair(uint32_t x, float f, flo
     const bf16_t lo = (bf16_t)(__uint_as_float(x << 16) * f - sub_lo), hi = (bf16_t)(__uint_as_float(x & 0xffff0000u) * f - sub_hi);
     return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
 }
-__device__ __forceinline__ uint32_t scale_bf16_pair(uint32_t x, float f) {
-    const bf16_t lo = (bf16_t)(__uint_as_float(x << 16) * f), hi = (bf16_t)(__uint_as_float(x & 0xffff0000u) * f);
-    return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
-}
 
 // sum over the 16 lanes of a DPP row, in every lane of the row: four DPP adds, no LDS
 __device__ __forceinline__ float row_sum_dpp(float v) {
